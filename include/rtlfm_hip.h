@@ -1,0 +1,215 @@
+/*
+ * rtlfm_hip.h — C ABI of the MI355X (gfx950) demodulation layer.
+ *
+ * This is the drop-in boundary for rtl_fm's per-buffer hot path.  It sits
+ * exactly where the reference's async callback hands over its uint8 IQ buffer:
+ *
+ *   reference boundary                       replaced by
+ *   ---------------------------------------  -------------------------------
+ *   rtlsdr_read_async_cb_t                   rtlfm_gpu_push()
+ *     (include/rtl-sdr.h:472)
+ *   rtlsdr_callback body from the u8->i16    rtlfm_gpu_push() + rtlfm_gpu_run()
+ *     convert on (src/rtl_fm.c:1326-1343)
+ *   full_demod(&demod)                       rtlfm_gpu_run() / _run_device()
+ *     (src/rtl_fm.c:1179-1272)
+ *   memcpy into output_state + fwrite        rtlfm_gpu_fetch()
+ *     (src/rtl_fm.c:1382-1388, 1400)
+ *   struct demod_state fields that persist   rtlfm_stream_state via
+ *     across blocks (src/rtl_fm.c:172-208)     rtlfm_gpu_state_get/_set()
+ *   optimal_settings() + deemph_a            rtlfm_optimal_settings(),
+ *     (src/rtl_fm.c:1407-1445, 1929-1931)      rtlfm_deemph_a()
+ *
+ * Conventions follow include/rtl-sdr.h: every entry point returns int,
+ * 0 on success and a negative value on error (-errno style).  All pointers
+ * are plain C pointers; there are no C++ or torch types in any signature.
+ *
+ * One handle batches `nstreams` independent IQ streams that share one
+ * configuration (one rtl_fm command line) but each own their filter state.
+ * Blocks of one stream are processed in order and never dropped; this is a
+ * deliberate, documented difference from rtl_fm's lossy thread hand-off
+ * (src/rtl_fm.c:1339-1343, 1368-1371).
+ */
+#ifndef RTLFM_HIP_H
+#define RTLFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTLFM_MAX_PASSES 10          /* lp_i_hist[10][6], src/rtl_fm.c:178 */
+#define RTLFM_MAX_BLOCK_LEN 262144u  /* MAXIMUM_BUF_LENGTH, src/rtl_fm.c:88-90 */
+
+/* demod_state.mode_demod (src/rtl_fm.c:200), selected by -M (src/rtl_fm.c:1820-1841) */
+enum rtlfm_mode {
+	RTLFM_MODE_FM = 0,   /* fm_demod  src/rtl_fm.c:932  */
+	RTLFM_MODE_AM = 1,   /* am_demod  src/rtl_fm.c:961  */
+	RTLFM_MODE_USB = 2,  /* usb_demod src/rtl_fm.c:978  */
+	RTLFM_MODE_LSB = 3,  /* lsb_demod src/rtl_fm.c:990  */
+	RTLFM_MODE_RAW = 4   /* raw_demod src/rtl_fm.c:1002 */
+};
+
+/* demod_state.custom_atan, selected by -A (src/rtl_fm.c:1811-1819) */
+enum rtlfm_atan {
+	RTLFM_ATAN_STD = 0,  /* polar_discriminant src/rtl_fm.c:842 */
+	RTLFM_ATAN_FAST = 1, /* polar_disc_fast    src/rtl_fm.c:874 */
+	RTLFM_ATAN_LUT = 2   /* polar_disc_lut     src/rtl_fm.c:894 */
+};
+
+/* What runs when rate_out2 > 0 (src/rtl_fm.c:1268-1271). */
+enum rtlfm_resampler {
+	RTLFM_RESAMPLE_LOW_PASS_REAL = 0, /* live path, src/rtl_fm.c:755-775 */
+	RTLFM_RESAMPLE_ARBITRARY = 1      /* arbitrary_resample, src/rtl_fm.c:1114-1177
+	                                     (call site commented out at :1270) */
+};
+
+/*
+ * Per-handle configuration: the demod_state / dongle_state fields that are
+ * constant while samples flow (src/rtl_fm.c:172-208).  Field names are the
+ * reference's.
+ */
+typedef struct rtlfm_cfg {
+	int32_t mode;               /* enum rtlfm_mode */
+	int32_t downsample;         /* boxcar factor of low_pass() when passes == 0 */
+	int32_t downsample_passes;  /* fifth_order() iterations, 0..10 */
+	int32_t comp_fir_size;      /* 0 or 9 (generic_fir with cic_9_tables) */
+	int32_t custom_atan;        /* enum rtlfm_atan */
+	int32_t post_downsample;    /* low_pass_simple() step, 1 = off */
+	int32_t deemph;             /* deemph_filter() on/off */
+	int32_t deemph_a;           /* its divisor, see rtlfm_deemph_a() */
+	int32_t rate_out;           /* "fast" of low_pass_real() */
+	int32_t rate_out2;          /* <= 0: no resampler */
+	int32_t resampler;          /* enum rtlfm_resampler */
+	int32_t dc_block_audio;     /* dc_block_audio_filter() on/off */
+	int32_t adc_block_const;    /* default 9 */
+	int32_t dc_block_raw;       /* dc_block_raw_filter() on/off */
+	int32_t rdc_block_const;    /* default 9 */
+	int32_t offset_tuning;      /* 1: skip rotate16_neg90 (src/rtl_fm.c:1336) */
+	int32_t output_scale;       /* am/usb/lsb gain from optimal_settings() */
+	int32_t squelch_level;      /* 0 = off (src/rtl_fm.c:1204) */
+	uint32_t block_len;         /* bytes per callback buffer = lp_len, multiple of 512 */
+	int32_t max_blocks;         /* most blocks per stream one run may take */
+} rtlfm_cfg;
+
+/*
+ * Everything a stream carries from one block to the next
+ * (src/rtl_fm.c:178-199 plus deemph_filter's function-static avg, :1013).
+ */
+typedef struct rtlfm_stream_state {
+	int16_t lp_i_hist[RTLFM_MAX_PASSES][6];
+	int16_t lp_q_hist[RTLFM_MAX_PASSES][6];
+	int16_t droop_i_hist[9];
+	int16_t droop_q_hist[9];
+	int16_t pad_[2];
+	int32_t now_r, now_j, prev_index;   /* low_pass() */
+	int32_t pre_r, pre_j;               /* fm_demod() */
+	int32_t now_lpr, prev_lpr_index;    /* low_pass_real() */
+	int32_t deemph_avg;                 /* static int avg in deemph_filter() */
+	int32_t dc_avg;                     /* dc_block_audio_filter() */
+	int32_t dc_avgI, dc_avgQ;           /* dc_block_raw_filter() */
+	int32_t squelch_hits;               /* src/rtl_fm.c:1208-1213 */
+} rtlfm_stream_state;
+
+typedef struct rtlfm_gpu rtlfm_gpu;
+
+/* ---- host-side planner helpers (no GPU needed) -------------------------- */
+
+/* rtlfm_cfg with demod_init()'s defaults (src/rtl_fm.c:1608-1640). */
+void rtlfm_cfg_default(rtlfm_cfg *cfg);
+
+/*
+ * optimal_settings() (src/rtl_fm.c:1407-1445).  `use_fifth_order` is the
+ * truthy downsample_passes placeholder set by -F (src/rtl_fm.c:1807-1810).
+ * Writes downsample, downsample_passes, output_scale into cfg; returns the
+ * capture rate through *capture_rate and the tuned frequency through
+ * *capture_freq (either may be NULL).
+ */
+int rtlfm_optimal_settings(rtlfm_cfg *cfg, uint32_t freq, int32_t rate_in,
+                           int32_t min_capture_rate, int use_fifth_order,
+                           int edge, uint32_t *capture_freq,
+                           uint32_t *capture_rate);
+
+/* deemph_a = round(1/(1-exp(-1/(rate_out*tc)))) (src/rtl_fm.c:1929-1931). */
+int32_t rtlfm_deemph_a(int32_t rate_out, int32_t time_constant_us);
+
+/* Output samples one block yields, or -1 if it depends on carried state. */
+int rtlfm_result_len(const rtlfm_cfg *cfg);
+/* Upper bound of output samples per block (always defined). */
+int rtlfm_result_cap(const rtlfm_cfg *cfg);
+
+/* ---- the GPU layer ------------------------------------------------------ */
+
+/* Allocates per-stream state (demod_init() values) and work buffers on
+ * HIP device `device`.  Fails with -ENODEV if there is no usable GPU: there
+ * is no CPU fallback. */
+int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device,
+                     rtlfm_gpu **out);
+int rtlfm_gpu_destroy(rtlfm_gpu *h);
+
+/*
+ * The rtlsdr_read_async callback body: append one buffer of interleaved u8
+ * I,Q for `stream`.  `iq` is owned by the caller and may be reused as soon as
+ * this returns (the driver resubmits it, src/librtlsdr.c:2705-2707): the bytes
+ * are copied into a pinned staging ring.  len must equal cfg.block_len.
+ * Safe to call from the thread that runs rtlsdr_read_async, concurrently for
+ * different streams.  -ENOSPC when max_blocks are already queued.
+ */
+int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint32_t len);
+
+/* full_demod() for every queued block of every stream (all streams must
+ * have the same number queued, else -EAGAIN).  Asynchronous. */
+int rtlfm_gpu_run(rtlfm_gpu *h);
+
+/*
+ * The same on input already resident in device memory.
+ *   d_iq        device pointer; stream s, block b starts at
+ *               d_iq + s*stream_stride + b*block_len
+ *   d_out       device pointer; stream s writes its concatenated block
+ *               results at d_out + s*out_stride (int16 elements)
+ *   d_out_len   device pointer to nstreams int32 (total samples per stream),
+ *               may be NULL
+ * Asynchronous on the handle's stream.
+ */
+int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq,
+                         size_t stream_stride, int nblocks, int16_t *d_out,
+                         size_t out_stride, int32_t *d_out_len);
+
+/* Copy out what the last rtlfm_gpu_run() produced for `stream` (what the
+ * reference fwrite()s, src/rtl_fm.c:1400).  Blocks until the run is done. */
+int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n);
+
+int rtlfm_gpu_state_get(rtlfm_gpu *h, int stream, rtlfm_stream_state *st);
+int rtlfm_gpu_state_set(rtlfm_gpu *h, int stream, const rtlfm_stream_state *st);
+/* demod_init() values for every stream. */
+int rtlfm_gpu_reset(rtlfm_gpu *h);
+
+int rtlfm_gpu_sync(rtlfm_gpu *h);
+/* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
+int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *hip_stream);
+
+/* 0 = automatic, 1 = staged reference kernels, 2 = fused streaming kernel
+ * (fails with -ENOTSUP at run time when the configuration has no fused
+ * form).  For tests and A/B measurement. */
+int rtlfm_gpu_set_path(rtlfm_gpu *h, int path);
+/* Which path the last run took (1 or 2). */
+int rtlfm_gpu_last_path(rtlfm_gpu *h);
+
+/*
+ * HIP-event timing of the decimating front-end kernel (the dominant kernel)
+ * on the stream it is launched on.  enable(1) starts recording one event pair
+ * per run; read() synchronises and returns the summed milliseconds and the
+ * number of launches since the last read, then clears them.
+ */
+int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on);
+int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches);
+
+const char *rtlfm_gpu_strerror(int err);
+/* (major<<16)|(minor<<8)|patch */
+int rtlfm_gpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTLFM_HIP_H */

@@ -1,0 +1,103 @@
+"""The CPU oracle against the golden vectors the reference itself produced,
+and (where oracle/_ref exists) against the live reference."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from cases import CASES, make_cfg
+from rtlsdr_amd import synth
+
+
+@pytest.mark.parametrize("name", gu.fixture_names())
+def test_oracle_matches_golden(oracle_lib, name):
+    cfg, iq, want, want_state = gu.load(name)
+    got, st = oracle_lib.run_stream(cfg, iq)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)  # bit-exact, -A std included (same libm)
+    assert gu.state_dict(st) == gu.state_dict(want_state)
+
+
+def test_manifest_hashes():
+    import hashlib
+    m = gu.manifest()
+    for fn in gu.fixture_names():
+        _, _, out, _ = gu.load(fn)
+        assert hashlib.sha256(out.tobytes()).hexdigest() == m[fn]["out_sha256"]
+
+
+def test_optimal_settings_known_answers(oracle_lib):
+    import ctypes as C
+    from rtlsdr_amd.capi import RtlfmCfg
+    for row in gu.manifest()["_optimal_settings"]:
+        cfg = RtlfmCfg.default(mode=row["mode"])
+        cf, cr = C.c_uint32(), C.c_uint32()
+        oracle_lib.oracle().orc_optimal_settings(
+            C.byref(cfg), row["freq"], row["rate_in"], row["min_capture_rate"],
+            row["use_fifth_order"], 0, C.byref(cf), C.byref(cr))
+        assert (cfg.downsample, cfg.downsample_passes, cfg.output_scale, cf.value, cr.value) == (
+            row["downsample"], row["downsample_passes"], row["output_scale"],
+            row["capture_freq"], row["capture_rate"])
+
+
+def test_deemph_a_known_answers(oracle_lib):
+    # (rate_out, 75us, 50us)
+    table = {170000: (13, 9), 240000: (19, 13), 150000: (12, 8), 32000: (3, 2),
+             24000: (2, 2), 16000: (2, 1)}
+    f = oracle_lib.oracle().orc_deemph_a
+    for rate, (us, eu) in table.items():
+        assert (f(rate, 75), f(rate, 50)) == (us, eu)
+
+
+def test_fifth_order_block_boundary_quirk(oracle_lib):
+    """x[N-1] of a block never reaches the next block's history (a6)."""
+    lib = oracle_lib.oracle()
+    rng = np.random.default_rng(5)
+    x = rng.integers(-128, 129, size=64).astype(np.int16)
+    inter = np.zeros(128, dtype=np.int16)
+    inter[0::2] = x
+    hist = np.zeros(6, dtype=np.int16)
+    lib.orc_fifth_order(inter.ctypes.data, 128, hist.ctypes.data)
+    assert list(hist) == list(x[57:63])  # x[N-7 .. N-2]; x[63] is gone
+
+
+def test_arbitrary_upsample_ramp(oracle_lib):
+    # SURVEY.md §8 a18 verified sample: ramp 0,100,... 128 -> 176
+    lib = oracle_lib.oracle()
+    a = (np.arange(128) * 100).astype(np.int16)
+    b = np.zeros(176, dtype=np.int16)
+    lib.orc_arbitrary_upsample(a.ctypes.data, b.ctypes.data, 128, 176)
+    assert list(b[:4]) == [0, 72, 145, 218] and b[-1] == 12700
+
+
+def test_polar_disc_lut_quirk(oracle_lib):
+    lib = oracle_lib.oracle()
+    # tiny positive angle, neither product zero: falls into the final else
+    assert lib.orc_polar_disc_lut(1000, 1, 1000, 0) == 16384
+    assert lib.orc_polar_disc_lut(-1000, -1, 1000, 0) in (0, -0)
+
+
+@pytest.mark.parametrize("name,ov,sig", CASES[:12])
+def test_oracle_matches_live_reference(oracle_lib, name, ov, sig):
+    if not oracle_lib.have_reference():
+        pytest.skip("oracle/_ref not built here")
+    L, nb = 1024, 7
+    cfg = make_cfg(ov, L)
+    iq = synth.fm_iq_u8(1, L // 2 * nb, seed=99, **sig)[0]
+    got, st = oracle_lib.run_stream(cfg, iq)
+    ref = oracle_lib.Reference()
+    want, rst = ref.run_stream(cfg, iq)
+    ref.close()
+    assert np.array_equal(got, want)
+    assert gu.state_dict(st) == gu.state_dict(rst)
+
+
+def test_batch_threads_equal_serial(oracle_lib):
+    ov, sig = CASES[1][1], CASES[1][2]
+    cfg = make_cfg(ov, 2048)
+    iq = synth.fm_iq_u8(5, 1024 * 3, **sig)
+    o1, n1, _ = oracle_lib.run_batch(cfg, iq, nthreads=1)
+    o4, n4, _ = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    assert np.array_equal(o1, o4) and np.array_equal(n1, n4)
+    for s in range(5):
+        o, _ = oracle_lib.run_stream(cfg, iq[s])
+        assert np.array_equal(o, o1[s, :n1[s]])
