@@ -1,0 +1,48 @@
+"""Build the HIP product for gfx950 with hipcc (in-tree, so the .so travels
+with the repository snapshot to the GPU box)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "librtlfm_hip.so")
+SOURCES = ["rtlfm_hip.hip"]
+HEADERS = ["dsp_device.h", "staged_kernels.h", "fused_kernel.h",
+           os.path.join("..", "..", "include", "rtlfm_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise FileNotFoundError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
+           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + (extra or [])
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,752 @@
+// rtlfm_hip.hip — the C ABI of include/rtlfm_hip.h on HIP / gfx950.
+//
+// Host side: handle, HBM buffers, stage sequencing that reproduces the order
+// of full_demod() (reference src/rtl_fm.c:1179-1272) behind the
+// rtlsdr_read_async callback boundary (include/rtl-sdr.h:472-492).
+// There is deliberately no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rtlfm_hip.h"
+#include "staged_kernels.h"
+#include "fused_kernel.h"
+
+using namespace rtlfm;
+
+#define HIP_TRY(expr)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (expr);                                                    \
+		if (e_ != hipSuccess) {                                                    \
+			fprintf(stderr, "rtlfm_hip: %s -> %s (%s:%d)\n", #expr,                \
+			        hipGetErrorString(e_), __FILE__, __LINE__);                    \
+			return e_ == hipErrorOutOfMemory ? -ENOMEM : -EIO;                     \
+		}                                                                          \
+	} while (0)
+
+struct rtlfm_gpu {
+	rtlfm_cfg cfg;
+	int nstreams = 0;
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	int path = 0, last_path = 0;
+
+	// geometry
+	size_t xstride = 0;   // dwords per stream in a work buffer
+	size_t rstride = 0;   // int16 per stream in a result buffer
+	int cap_blocks = 0;
+
+	// device memory
+	uint32_t *bufA = nullptr, *bufB = nullptr;
+	int16_t *resA = nullptr, *resB = nullptr;
+	int16_t *d_result = nullptr;      // run()/fetch() result, rstride
+	int32_t *d_result_len = nullptr;  // [nstreams]
+	int32_t *d_cnt = nullptr, *d_cnt2 = nullptr;
+	state_t *st[2] = {nullptr, nullptr};
+	int st_cur = 0;
+	int32_t *d_lut = nullptr;
+	int32_t *d_mute = nullptr;        // [nstreams*cap_blocks]
+	long long *d_sums = nullptr;      // [nstreams*cap_blocks*2]
+	int2 *d_rdc_avg = nullptr;        // [nstreams*cap_blocks]
+	int32_t *d_adc_avg = nullptr;
+	uint8_t *d_in = nullptr;          // push() landing zone
+	uint8_t *h_stage = nullptr;       // pinned
+	std::vector<int> pushed;
+	std::mutex push_mu;
+	int last_run_blocks = 0;
+	fused::Workspace fws;
+
+	// timing of the decimating front end
+	bool timing = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+};
+
+// ------------------------------------------------------------ host planner ----
+
+extern "C" void rtlfm_cfg_default(rtlfm_cfg *c)
+{
+	// demod_init(), src/rtl_fm.c:1608-1640
+	memset(c, 0, sizeof(*c));
+	c->mode = RTLFM_MODE_FM;
+	c->downsample = 1;
+	c->post_downsample = 1;
+	c->rate_out = 24000;
+	c->rate_out2 = -1;
+	c->adc_block_const = 9;
+	c->rdc_block_const = 9;
+	c->output_scale = 1;
+	c->block_len = 16384;  // dongle_init(), src/rtl_fm.c:1605
+	c->max_blocks = 1;
+}
+
+extern "C" int rtlfm_optimal_settings(rtlfm_cfg *cfg, uint32_t freq, int32_t rate_in,
+                                      int32_t min_capture_rate, int use_fifth_order, int edge,
+                                      uint32_t *capture_freq, uint32_t *capture_rate)
+{
+	// optimal_settings(), src/rtl_fm.c:1407-1445
+	if (!cfg || rate_in <= 0) return -EINVAL;
+	cfg->downsample = min_capture_rate / rate_in + 1;
+	cfg->downsample_passes = 0;
+	if (use_fifth_order) {
+		cfg->downsample_passes = (int)log2((double)cfg->downsample) + 1;
+		cfg->downsample = 1 << cfg->downsample_passes;
+	}
+	uint32_t rate = (uint32_t)cfg->downsample * (uint32_t)rate_in;
+	uint32_t f = freq;
+	if (!cfg->offset_tuning) f = freq - rate / 4;
+	f += (uint32_t)(edge * rate_in / 2);
+	cfg->output_scale = (1 << 15) / (128 * cfg->downsample);
+	if (cfg->output_scale < 1) cfg->output_scale = 1;
+	if (cfg->mode == RTLFM_MODE_FM) cfg->output_scale = 1;
+	if (capture_freq) *capture_freq = f;
+	if (capture_rate) *capture_rate = rate;
+	return 0;
+}
+
+extern "C" int32_t rtlfm_deemph_a(int32_t rate_out, int32_t tc_us)
+{
+	// src/rtl_fm.c:1929-1931
+	double tc = (double)tc_us * 1e-6;
+	return (int32_t)round(1.0 / (1.0 - exp(-1.0 / (rate_out * tc))));
+}
+
+// per-block decimated complex samples, or -1 when the boxcar phase makes it vary
+static int dec_per_block(const rtlfm_cfg *c)
+{
+	int n0 = (int)(c->block_len / 2);
+	if (c->downsample_passes > 0) return n0 >> c->downsample_passes;
+	if (c->downsample <= 1) return n0;
+	return n0 % c->downsample == 0 ? n0 / c->downsample : -1;
+}
+
+extern "C" int rtlfm_result_len(const rtlfm_cfg *c)
+{
+	if (!c) return -EINVAL;
+	int n = dec_per_block(c);
+	if (n < 0) return -1;
+	if (c->mode == RTLFM_MODE_RAW) return 2 * n;
+	if (c->post_downsample > 1) n /= c->post_downsample;
+	if (c->rate_out2 > 0) {
+		if (c->resampler == RTLFM_RESAMPLE_ARBITRARY)
+			return (int)((long long)n * c->rate_out2 / c->rate_out);
+		return -1;
+	}
+	return n;
+}
+
+extern "C" int rtlfm_result_cap(const rtlfm_cfg *c)
+{
+	if (!c) return -EINVAL;
+	int n0 = (int)(c->block_len / 2);
+	int n = c->downsample_passes > 0 ? n0 >> c->downsample_passes
+	                                  : (c->downsample > 1 ? n0 / c->downsample + 1 : n0);
+	if (c->mode == RTLFM_MODE_RAW) return 2 * n;
+	if (c->rate_out2 > 0 && c->resampler == RTLFM_RESAMPLE_ARBITRARY && c->rate_out > 0) {
+		long long up = (long long)n * c->rate_out2 / c->rate_out + 2;
+		if (up > n) n = (int)up;
+	}
+	return n + 2;
+}
+
+static int validate_cfg(const rtlfm_cfg *c)
+{
+	if (c->mode < RTLFM_MODE_FM || c->mode > RTLFM_MODE_RAW) return -EINVAL;
+	if (c->block_len < 512 || c->block_len > RTLFM_MAX_BLOCK_LEN || c->block_len % 512) return -EINVAL;
+	if (c->downsample_passes < 0 || c->downsample_passes > RTLFM_MAX_PASSES) return -EINVAL;
+	// every fifth_order call must see a length that is a multiple of 4 elements
+	if (c->downsample_passes > 0 && c->block_len % (2u << c->downsample_passes)) return -EINVAL;
+	if (c->downsample_passes == 0 && (c->downsample < 1 || c->downsample > 256)) return -EINVAL;
+	if (c->comp_fir_size != 0 && c->comp_fir_size != 9) return -EINVAL;
+	if (c->custom_atan < RTLFM_ATAN_STD || c->custom_atan > RTLFM_ATAN_LUT) return -EINVAL;
+	if (c->max_blocks < 1) return -EINVAL;
+	if (c->post_downsample < 1 || c->post_downsample > 16) return -EINVAL;
+	if (c->deemph && c->deemph_a < 1) return -EINVAL;
+	if (c->mode != RTLFM_MODE_RAW) {
+		int per = dec_per_block(c);
+		bool need_uniform = c->post_downsample > 1 || c->dc_block_audio ||
+		                    (c->rate_out2 > 0 && c->resampler == RTLFM_RESAMPLE_ARBITRARY);
+		if (need_uniform && per < 0) return -ENOTSUP;
+		if (c->post_downsample > 1 && per % c->post_downsample) return -EINVAL;
+		if (c->rate_out2 > 0) {
+			if (c->rate_out <= 0) return -EINVAL;
+			if (c->resampler == RTLFM_RESAMPLE_LOW_PASS_REAL) {
+				// the reference divides by zero here (src/rtl_fm.c:769)
+				if (c->rate_out / c->rate_out2 == 0) return -EDOM;
+			} else if (c->resampler == RTLFM_RESAMPLE_ARBITRARY) {
+				int n = per / c->post_downsample;
+				long long len2 = (long long)n * c->rate_out2 / c->rate_out;
+				if (len2 < 1 || n < 2) return -EINVAL;
+			} else {
+				return -EINVAL;
+			}
+		}
+	}
+	return 0;
+}
+
+// ----------------------------------------------------------------- handle ----
+
+static void init_states_host(std::vector<state_t> &v)
+{
+	for (auto &s : v) {
+		memset(&s, 0, sizeof(s));
+		s.squelch_hits = 11;  // demod_init(), src/rtl_fm.c:1615
+	}
+}
+
+extern "C" int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device, rtlfm_gpu **out)
+{
+	if (!cfg || !out || nstreams < 1) return -EINVAL;
+	int v = validate_cfg(cfg);
+	if (v < 0) return v;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+		fprintf(stderr, "rtlfm_hip: no usable HIP device (count=%d, asked %d); there is no CPU fallback\n",
+		        ndev, device);
+		return -ENODEV;
+	}
+	HIP_TRY(hipSetDevice(device));
+	rtlfm_gpu *h = new rtlfm_gpu();
+	h->cfg = *cfg;
+	h->nstreams = nstreams;
+	h->device = device;
+	h->cap_blocks = cfg->max_blocks;
+	const size_t L = cfg->block_len;
+	h->xstride = (size_t)h->cap_blocks * (L / 2) + 16;
+	size_t rs = (size_t)h->cap_blocks * L + 64;  // raw mode: 2 int16 per complex sample
+	if (cfg->rate_out2 > 0 && cfg->resampler == RTLFM_RESAMPLE_ARBITRARY && cfg->rate_out2 > cfg->rate_out)
+		rs = (size_t)((double)rs * cfg->rate_out2 / cfg->rate_out) + 64;
+	h->rstride = (rs + 7) & ~(size_t)7;
+	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+	h->stream = h->own_stream;
+	const size_t S = (size_t)nstreams;
+	HIP_TRY(hipMalloc(&h->st[0], S * sizeof(state_t)));
+	HIP_TRY(hipMalloc(&h->st[1], S * sizeof(state_t)));
+	HIP_TRY(hipMalloc(&h->d_cnt, S * sizeof(int32_t)));
+	HIP_TRY(hipMalloc(&h->d_cnt2, S * sizeof(int32_t)));
+	HIP_TRY(hipMalloc(&h->d_result_len, S * sizeof(int32_t)));
+	HIP_TRY(hipMalloc(&h->d_mute, S * h->cap_blocks * sizeof(int32_t)));
+	HIP_TRY(hipMalloc(&h->d_sums, S * h->cap_blocks * 2 * sizeof(long long)));
+	HIP_TRY(hipMalloc(&h->d_rdc_avg, S * h->cap_blocks * sizeof(int2)));
+	HIP_TRY(hipMalloc(&h->d_adc_avg, S * h->cap_blocks * sizeof(int32_t)));
+	if (cfg->custom_atan == RTLFM_ATAN_LUT) {
+		// atan_lut_init(), src/rtl_fm.c:881-892 — built with the host libm, as
+		// the reference builds it
+		std::vector<int32_t> lut(131072);
+		for (int i = 0; i < 131072; i++)
+			lut[i] = (int32_t)(atan((double)i / 256.0) / 3.14159 * 16384.0);
+		HIP_TRY(hipMalloc(&h->d_lut, lut.size() * sizeof(int32_t)));
+		HIP_TRY(hipMemcpy(h->d_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+	}
+	h->pushed.assign(S, 0);
+	*out = h;
+	return rtlfm_gpu_reset(h);
+}
+
+static int ensure_work_buffers(rtlfm_gpu *h)
+{
+	const size_t S = (size_t)h->nstreams;
+	if (!h->bufA) {
+		HIP_TRY(hipMalloc(&h->bufA, S * h->xstride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc(&h->bufB, S * h->xstride * sizeof(uint32_t)));
+	}
+	return 0;
+}
+static int ensure_res_buffers(rtlfm_gpu *h)
+{
+	const size_t S = (size_t)h->nstreams;
+	if (!h->resA) {
+		HIP_TRY(hipMalloc(&h->resA, S * h->rstride * sizeof(int16_t)));
+		HIP_TRY(hipMalloc(&h->resB, S * h->rstride * sizeof(int16_t)));
+	}
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
+{
+	if (!h) return -EINVAL;
+	hipSetDevice(h->device);
+	hipStreamSynchronize(h->stream);
+	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+	void *ptrs[] = {h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
+	                h->st[0], h->st[1], h->d_lut, h->d_mute, h->d_sums, h->d_rdc_avg, h->d_adc_avg, h->d_in};
+	for (void *p : ptrs)
+		if (p) hipFree(p);
+	h->fws.release();
+	if (h->h_stage) hipHostFree(h->h_stage);
+	if (h->own_stream) hipStreamDestroy(h->own_stream);
+	delete h;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_reset(rtlfm_gpu *h)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	std::vector<state_t> init((size_t)h->nstreams);
+	init_states_host(init);
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipMemcpy(h->st[h->st_cur], init.data(), init.size() * sizeof(state_t), hipMemcpyHostToDevice));
+	std::lock_guard<std::mutex> g(h->push_mu);
+	std::fill(h->pushed.begin(), h->pushed.end(), 0);
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_state_get(rtlfm_gpu *h, int stream, rtlfm_stream_state *st)
+{
+	if (!h || !st || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipMemcpy(st, h->st[h->st_cur] + stream, sizeof(*st), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_state_set(rtlfm_gpu *h, int stream, const rtlfm_stream_state *st)
+{
+	if (!h || !st || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipMemcpy(h->st[h->st_cur] + stream, st, sizeof(*st), hipMemcpyHostToDevice));
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_sync(rtlfm_gpu *h)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *s)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	h->stream = s ? (hipStream_t)s : h->own_stream;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_set_path(rtlfm_gpu *h, int path)
+{
+	if (!h || path < 0 || path > 2) return -EINVAL;
+	h->path = path;
+	return 0;
+}
+extern "C" int rtlfm_gpu_last_path(rtlfm_gpu *h) { return h ? h->last_path : -EINVAL; }
+
+extern "C" int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on)
+{
+	if (!h) return -EINVAL;
+	h->timing = on != 0;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	double total = 0;
+	int n = 0;
+	for (auto &p : h->ev_pending) {
+		float ms = 0;
+		HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+		total += ms;
+		n++;
+		h->ev_free.push_back(p);
+	}
+	h->ev_pending.clear();
+	if (front_ms) *front_ms = total;
+	if (launches) *launches = n;
+	return 0;
+}
+
+static int timing_begin(rtlfm_gpu *h, std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+	if (!h->timing) return 0;
+	if (!h->ev_free.empty()) {
+		ev = h->ev_free.back();
+		h->ev_free.pop_back();
+	} else {
+		HIP_TRY(hipEventCreate(&ev.first));
+		HIP_TRY(hipEventCreate(&ev.second));
+	}
+	HIP_TRY(hipEventRecord(ev.first, h->stream));
+	return 0;
+}
+static int timing_end(rtlfm_gpu *h, std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+	if (!h->timing) return 0;
+	HIP_TRY(hipEventRecord(ev.second, h->stream));
+	h->ev_pending.push_back(ev);
+	return 0;
+}
+
+// ------------------------------------------------------------ the chain ----
+
+static inline int grid_for(size_t work, int block = 256, int cap = 256 * 16)
+{
+	size_t g = (work + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > (size_t)cap) g = cap;
+	return (int)g;
+}
+
+// Audio tail shared by both paths: everything full_demod() does after
+// mode_demod() (src/rtl_fm.c:1260-1271).  `src` holds per-stream demodulated
+// samples (uniform count T, or per-stream d_cnt when `varcnt`); the final
+// result is left in dst with dst_stride and its per-stream length in
+// d_out_len (may be NULL).
+struct TailPlan {
+	bool post, deemph, adc, lpr, arb;
+	int oop() const { return (post ? 1 : 0) + ((lpr || arb) ? 1 : 0); }
+	bool any() const { return post || deemph || adc || lpr || arb; }
+};
+static TailPlan plan_tail(const rtlfm_cfg &c)
+{
+	TailPlan t{};
+	if (c.mode == RTLFM_MODE_RAW) return t;
+	t.post = c.post_downsample > 1;
+	t.deemph = c.deemph != 0;
+	t.adc = c.dc_block_audio != 0;
+	t.lpr = c.rate_out2 > 0 && c.resampler == RTLFM_RESAMPLE_LOW_PASS_REAL;
+	t.arb = c.rate_out2 > 0 && c.resampler == RTLFM_RESAMPLE_ARBITRARY;
+	return t;
+}
+
+// Where mode_demod() should write so that the chain ends in `final`.
+static void tail_route(rtlfm_gpu *h, const TailPlan &tp, int16_t *final_dst, size_t final_stride,
+                       int16_t **demod_dst, size_t *demod_stride)
+{
+	if (tp.oop() == 0) {
+		*demod_dst = final_dst;
+		*demod_stride = final_stride;
+	} else {
+		*demod_dst = h->resA;
+		*demod_stride = h->rstride;
+	}
+}
+
+static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_stride, int T, bool varcnt,
+                    int nblocks, int16_t *final_dst, size_t final_stride, int32_t *d_out_len)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	hipStream_t q = h->stream;
+	const state_t *sin = h->st[h->st_cur];
+	state_t *sout = h->st[h->st_cur ^ 1];
+	int remaining_oop = tp.oop();
+	int per_block = T / nblocks;  // only used by stages that require a uniform count
+	int32_t *cnt = varcnt ? h->d_cnt : nullptr;
+	auto next_dst = [&](int16_t **d, size_t *ds) {
+		remaining_oop--;
+		if (remaining_oop == 0) { *d = final_dst; *ds = final_stride; }
+		else { *d = (cur == h->resA) ? h->resB : h->resA; *ds = h->rstride; }
+	};
+	if (tp.post) {
+		int16_t *d; size_t ds;
+		next_dst(&d, &ds);
+		int Tout = T / c.post_downsample;
+		k_post_downsample<<<grid_for((size_t)S * Tout), 256, 0, q>>>(cur, cur_stride, d, ds, Tout, S,
+		                                                           c.post_downsample);
+		cur = d; cur_stride = ds; T = Tout; per_block = T / nblocks;
+	}
+	if (tp.deemph)
+		k_deemph<<<grid_for(S, 64), 64, 0, q>>>(cur, cur_stride, T, cnt, S, c.deemph_a, sin, sout);
+	if (tp.adc) {
+		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, per_block, nblocks, h->d_sums);
+		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, per_block, nblocks, S, c.adc_block_const, sin,
+		                                           sout, h->d_adc_avg);
+		k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, per_block, nblocks, S,
+		                                                  h->d_adc_avg);
+	}
+	if (tp.lpr) {
+		int16_t *d; size_t ds;
+		next_dst(&d, &ds);
+		int maxout = (int)(((long long)c.rate_out - 1 + (long long)T * c.rate_out2) / c.rate_out);
+		k_low_pass_real<<<grid_for((size_t)S * (maxout + 1)), 256, 0, q>>>(
+		    cur, cur_stride, d, ds, T, cnt, S, c.rate_out, c.rate_out2, sin, sout, h->d_cnt2);
+		cur = d; cur_stride = ds;
+		if (d_out_len)
+			HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt2, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+		return 0;
+	}
+	if (tp.arb) {
+		int16_t *d; size_t ds;
+		next_dst(&d, &ds);
+		int len1 = per_block;
+		int len2 = (int)((long long)len1 * c.rate_out2 / c.rate_out);
+		if (len1 < len2)
+			k_arb_upsample<<<grid_for((size_t)S * nblocks * len2), 256, 0, q>>>(cur, cur_stride, d, ds, len1,
+			                                                                  len2, nblocks, S);
+		else
+			k_arb_downsample<<<grid_for((size_t)S * nblocks, 64), 64, 0, q>>>(cur, cur_stride, d, ds, len1,
+			                                                                len2, nblocks, S);
+		cur = d; cur_stride = ds; T = len2 * nblocks;
+	}
+	if (cur != final_dst) return -EFAULT;  // routing bug
+	if (d_out_len) {
+		if (varcnt)
+			HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+		else
+			k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, T);
+	}
+	return 0;
+}
+
+static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
+                      size_t out_stride, int32_t *d_out_len)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	const uint32_t L = c.block_len;
+	const int N0 = (int)(L / 2);
+	hipStream_t q = h->stream;
+	int r = ensure_work_buffers(h);
+	if (r < 0) return r;
+	const state_t *sin = h->st[h->st_cur];
+	state_t *sout = h->st[h->st_cur ^ 1];
+	std::pair<hipEvent_t, hipEvent_t> ev;
+
+	r = timing_begin(h, ev);
+	if (r < 0) return r;
+	// --- rtlsdr_callback: convert, raw DC block, rotate (src/rtl_fm.c:1326-1338)
+	const int2 *rdc = nullptr;
+	if (c.dc_block_raw) {
+		k_rdc_sums<<<S * nblocks, 256, 0, q>>>(d_iq, stream_stride, L, nblocks, h->d_sums);
+		k_rdc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, L, nblocks, S, c.rdc_block_const, sin, sout,
+		                                           h->d_rdc_avg);
+		rdc = h->d_rdc_avg;
+	}
+	k_convert<<<grid_for((size_t)S * nblocks * (L / 16)), 256, 0, q>>>(d_iq, stream_stride, L, nblocks, S,
+	                                                                  h->bufA, h->xstride,
+	                                                                  c.offset_tuning ? 0 : 1, rdc);
+	uint32_t *cur = h->bufA, *oth = h->bufB;
+	// --- decimation (src/rtl_fm.c:1187-1202)
+	int T;          // decimated complex samples per stream (upper bound if varcnt)
+	int Nblk, D;    // block geometry for "first output of a block" tests
+	bool varcnt = false;
+	if (c.downsample_passes > 0) {
+		for (int p = 0; p < c.downsample_passes; p++) {
+			int N = N0 >> p;
+			k_fifth<<<grid_for((size_t)S * nblocks * (N / 2)), 256, 0, q>>>(cur, oth, h->xstride, N, nblocks, S,
+			                                                              p, sin, sout);
+			std::swap(cur, oth);
+		}
+		Nblk = N0 >> c.downsample_passes;
+		D = 1;
+		T = nblocks * Nblk;
+		if (c.comp_fir_size == 9) {
+			k_fir9<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, oth, h->xstride, T, S, c.downsample_passes,
+			                                              sin, sout);
+			std::swap(cur, oth);
+		}
+	} else {
+		Nblk = N0;
+		D = c.downsample;
+		int Tin = nblocks * N0;
+		int maxout = Tin / D + 1;
+		k_boxcar<<<grid_for((size_t)S * (maxout + 1)), 256, 0, q>>>(cur, oth, h->xstride, Tin, S, D, sin, sout,
+		                                                          h->d_cnt);
+		std::swap(cur, oth);
+		varcnt = (N0 % D) != 0;
+		T = varcnt ? maxout : Tin / D;
+	}
+	r = timing_end(h, ev);
+	if (r < 0) return r;
+	// --- power squelch (src/rtl_fm.c:1204-1215)
+	if (c.squelch_level) {
+		k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->xstride, Nblk, D, nblocks, sin, c.squelch_level,
+		                                         c.dc_block_raw, h->d_mute);
+		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
+		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, Nblk, D, nblocks, S, T, sin,
+		                                                     h->d_mute);
+	}
+	// --- mode_demod (src/rtl_fm.c:1256-1259)
+	TailPlan tp = plan_tail(c);
+	if (tp.any()) {
+		r = ensure_res_buffers(h);
+		if (r < 0) return r;
+	}
+	int16_t *dd; size_t dds;
+	tail_route(h, tp, d_out, out_stride, &dd, &dds);
+	const int32_t *cnt = varcnt ? h->d_cnt : nullptr;
+	if (c.mode == RTLFM_MODE_FM)
+		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, dd, dds, T, S, Nblk, D,
+		                                                 c.custom_atan, h->d_lut, cnt, sin, sout);
+	else
+		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, dd, dds, T, S, c.mode,
+		                                                     c.output_scale, cnt);
+	if (c.mode == RTLFM_MODE_RAW) {
+		if (d_out_len) {
+			if (varcnt) {
+				HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+				k_scale_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2, 1);
+			} else {
+				k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T);
+			}
+		}
+		return 0;
+	}
+	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, d_out, out_stride, d_out_len);
+}
+
+static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
+                     size_t out_stride, int32_t *d_out_len)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	hipStream_t q = h->stream;
+	const state_t *sin = h->st[h->st_cur];
+	state_t *sout = h->st[h->st_cur ^ 1];
+	TailPlan tp = plan_tail(c);
+	if (tp.any()) {
+		int r = ensure_res_buffers(h);
+		if (r < 0) return r;
+	}
+	int16_t *dd; size_t dds;
+	tail_route(h, tp, d_out, out_stride, &dd, &dds);
+	std::pair<hipEvent_t, hipEvent_t> ev;
+	int r = timing_begin(h, ev);
+	if (r < 0) return r;
+	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q);
+	if (r < 0) return r;
+	r = timing_end(h, ev);
+	if (r < 0) return r;
+	const int T = nblocks * (int)((c.block_len / 2) >> c.downsample_passes);
+	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
+}
+
+extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
+                                    int16_t *d_out, size_t out_stride, int32_t *d_out_len)
+{
+	if (!h || !d_iq || !d_out || nblocks < 1) return -EINVAL;
+	if (nblocks > h->cap_blocks) return -E2BIG;
+	if (((uintptr_t)d_iq & 15) || (stream_stride & 15) || ((uintptr_t)d_out & 3) || (out_stride & 1)) return -EINVAL;
+	if (stream_stride < (size_t)nblocks * h->cfg.block_len) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	const size_t S = (size_t)h->nstreams;
+	// state is double-buffered: kernels read st[cur], write st[cur^1]
+	HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
+	                       hipMemcpyDeviceToDevice, h->stream));
+	bool can_fuse = fused::supported(h->cfg, nblocks);
+	int r;
+	if (h->path == 2 && !can_fuse) return -ENOTSUP;
+	if (h->path != 1 && can_fuse) {
+		r = run_fused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+		h->last_path = 2;
+	} else {
+		r = run_staged(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+		h->last_path = 1;
+	}
+	if (r < 0) return r;
+	HIP_TRY(hipGetLastError());
+	h->st_cur ^= 1;
+	return 0;
+}
+
+// --------------------------------------------- callback-side: push / fetch ----
+
+static int ensure_push_buffers(rtlfm_gpu *h)
+{
+	if (h->h_stage) return 0;
+	const size_t bytes = (size_t)h->nstreams * h->cap_blocks * h->cfg.block_len;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipHostMalloc(&h->h_stage, bytes, hipHostMallocDefault));
+	HIP_TRY(hipMalloc(&h->d_in, bytes));
+	HIP_TRY(hipMalloc(&h->d_result, (size_t)h->nstreams * h->rstride * sizeof(int16_t)));
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint32_t len)
+{
+	if (!h || !iq || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	if (len != h->cfg.block_len) return -EINVAL;
+	int slot;
+	{
+		std::lock_guard<std::mutex> g(h->push_mu);
+		int r = ensure_push_buffers(h);
+		if (r < 0) return r;
+		if (h->pushed[stream] >= h->cap_blocks) return -ENOSPC;
+		slot = h->pushed[stream]++;
+	}
+	// the caller's buffer goes back to the USB queue the moment we return
+	// (src/librtlsdr.c:2705-2707): copy now
+	memcpy(h->h_stage + ((size_t)stream * h->cap_blocks + slot) * len, iq, len);
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
+{
+	if (!h) return -EINVAL;
+	int nb;
+	{
+		std::lock_guard<std::mutex> g(h->push_mu);
+		int r = ensure_push_buffers(h);
+		if (r < 0) return r;
+		nb = h->pushed[0];
+		for (int v : h->pushed)
+			if (v != nb) return -EAGAIN;
+		if (nb == 0) return -EAGAIN;
+		std::fill(h->pushed.begin(), h->pushed.end(), 0);
+	}
+	HIP_TRY(hipSetDevice(h->device));
+	const size_t stride = (size_t)h->cap_blocks * h->cfg.block_len;
+	if (nb == h->cap_blocks) {
+		HIP_TRY(hipMemcpyAsync(h->d_in, h->h_stage, stride * h->nstreams, hipMemcpyHostToDevice, h->stream));
+	} else {
+		HIP_TRY(hipMemcpy2DAsync(h->d_in, stride, h->h_stage, stride, (size_t)nb * h->cfg.block_len,
+		                         h->nstreams, hipMemcpyHostToDevice, h->stream));
+	}
+	h->last_run_blocks = nb;
+	int r = rtlfm_gpu_run_device(h, h->d_in, stride, nb, h->d_result, h->rstride, h->d_result_len);
+	if (r < 0) return r;
+	// the staging ring may be refilled once the H2D copy has been consumed
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n)
+{
+	if (!h || !out || !n || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	if (!h->d_result) return -EAGAIN;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	int32_t len = 0;
+	HIP_TRY(hipMemcpy(&len, h->d_result_len + stream, sizeof(len), hipMemcpyDeviceToHost));
+	*n = len;
+	if (len > cap) return -ENOBUFS;
+	if (len > 0)
+		HIP_TRY(hipMemcpy(out, h->d_result + (size_t)stream * h->rstride, (size_t)len * sizeof(int16_t),
+		                  hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" const char *rtlfm_gpu_strerror(int err)
+{
+	switch (err) {
+	case 0: return "ok";
+	case -EINVAL: return "invalid argument or configuration";
+	case -ENODEV: return "no usable HIP device (there is no CPU fallback)";
+	case -ENOMEM: return "out of device memory";
+	case -ENOSPC: return "max_blocks already queued for this stream";
+	case -EAGAIN: return "streams have unequal / zero queued blocks";
+	case -ENOTSUP: return "configuration not supported on this path";
+	case -EDOM: return "rate_out2 > rate_out with low_pass_real: the reference divides by zero here";
+	case -E2BIG: return "more blocks than cfg.max_blocks";
+	case -ENOBUFS: return "output buffer too small";
+	case -EIO: return "HIP runtime error";
+	default: return strerror(-err);
+	}
+}
+
+extern "C" int rtlfm_gpu_version(void) { return (0 << 16) | (1 << 8) | 0; }

@@ -1,0 +1,651 @@
+// staged_kernels.h — the pass-major ("staged") form of rtl_fm's chain.
+//
+// Every stage of full_demod() (reference src/rtl_fm.c:1179-1272) is its own
+// launch over ALL streams and ALL queued blocks at once; intermediate data
+// lives in HBM work buffers as packed int16 I,Q dwords.  Because a stage runs
+// for every block before the next stage starts, the history a block needs from
+// its predecessor is simply read from the predecessor's input in the work
+// buffer; only block 0 reads the carried rtlfm_stream_state.  This form exists
+// for every configuration the reference accepts and is the cross-check for the
+// fused streaming kernel (fused_kernel.h), which is what the roofline is
+// measured on.
+//
+// Layout: a work buffer holds, for stream s, `xstride` dwords; at decimation
+// level p block b's N_p complex samples start at s*xstride + b*N_p (blocks stay
+// contiguous at every level).  State is double-buffered: kernels read `sin`,
+// write `sout` (which starts as a copy of `sin`).
+#pragma once
+
+#include "dsp_device.h"
+
+namespace rtlfm {
+
+using state_t = rtlfm_stream_state;
+
+#define RTLFM_GRID_STRIDE(i, n) \
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- convert ----
+// u8 -> int16 (-127) (src/rtl_fm.c:1326-1328), optional raw DC subtraction
+// (:1330-1332, second half of dc_block_raw_filter :1058-1061), rotate16_neg90
+// (:424-434) whose phase restarts with every buffer.  One thread per 16 input
+// bytes = 8 complex samples.
+__global__ void __launch_bounds__(256)
+k_convert(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, int nblocks, int nstreams,
+          uint32_t *__restrict__ X, size_t xstride, int rotate, const int2 *__restrict__ rdc_avg)
+{
+	const size_t per_block = L / 16;
+	const size_t total = (size_t)nstreams * nblocks * per_block;
+	RTLFM_GRID_STRIDE(g, total) {
+		size_t j = g % per_block;
+		size_t sb = g / per_block;
+		int b = (int)(sb % nblocks);
+		size_t s = sb / nblocks;
+		const uint4 raw = *reinterpret_cast<const uint4 *>(iq + s * stream_stride + (size_t)b * L + j * 16);
+		uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+		int ai = 0, aq = 0;
+		if (rdc_avg) {
+			int2 a = rdc_avg[s * nblocks + b];
+			ai = a.x; aq = a.y;
+		}
+		uint32_t o[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			uint32_t pair = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+			int16_t re = (int16_t)((int)(pair & 0xff) - 127 - ai);
+			int16_t im = (int16_t)((int)(pair >> 8) - 127 - aq);
+			int16_t orr = re, oi = im;
+			if (rotate) {
+				switch (k & 3) {
+				case 1: orr = im; oi = (int16_t)(-re); break;
+				case 2: orr = (int16_t)(-re); oi = (int16_t)(-im); break;
+				case 3: orr = (int16_t)(-im); oi = re; break;
+				default: break;
+				}
+			}
+			o[k] = pack_iq(orr, oi);
+		}
+		uint4 *dst = reinterpret_cast<uint4 *>(X + s * xstride + (size_t)b * (L / 2) + j * 8);
+		dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+		dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+	}
+}
+
+// First half of dc_block_raw_filter (src/rtl_fm.c:1049-1055): per (stream,
+// block) sums of I-127 and Q-127.  One workgroup per (stream, block).
+__global__ void __launch_bounds__(256)
+k_rdc_sums(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, int nblocks,
+           long long *__restrict__ sums /* [s][b][2] */)
+{
+	const int sb = blockIdx.x;
+	const int b = sb % nblocks;
+	const size_t s = sb / nblocks;
+	const uint8_t *src = iq + s * stream_stride + (size_t)b * L;
+	long long si = 0, sq = 0;
+	for (uint32_t k = threadIdx.x * 4; k < L; k += blockDim.x * 4) {
+		uint32_t w = *reinterpret_cast<const uint32_t *>(src + k);
+		si += (int)(w & 0xff) - 127 + (int)((w >> 16) & 0xff) - 127;
+		sq += (int)((w >> 8) & 0xff) - 127 + (int)(w >> 24) - 127;
+	}
+	__shared__ long long red[2][256];
+	red[0][threadIdx.x] = si;
+	red[1][threadIdx.x] = sq;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) {
+			red[0][threadIdx.x] += red[0][threadIdx.x + off];
+			red[1][threadIdx.x] += red[1][threadIdx.x + off];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		sums[(size_t)sb * 2] = red[0][0];
+		sums[(size_t)sb * 2 + 1] = red[1][0];
+	}
+}
+
+// The smoothing recurrence of dc_block_raw_filter (src/rtl_fm.c:1054-1057,
+// :1062-1063), sequential over a stream's blocks.  One thread per stream.
+__global__ void k_rdc_smooth(const long long *__restrict__ sums, uint32_t L, int nblocks, int nstreams,
+                             int k, const state_t *__restrict__ sin, state_t *__restrict__ sout,
+                             int2 *__restrict__ avg)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) {
+		int pi = sin[s].dc_avgI, pq = sin[s].dc_avgQ;
+		const int pairs = (int)(L / 2);
+		for (int b = 0; b < nblocks; b++) {
+			int mi = (int)(sums[(s * nblocks + b) * 2] / pairs);
+			int mq = (int)(sums[(s * nblocks + b) * 2 + 1] / pairs);
+			mi = (mi + pi * k) / (k + 1);
+			mq = (mq + pq * k) / (k + 1);
+			avg[s * nblocks + b] = make_int2(mi, mq);
+			pi = mi; pq = mq;
+		}
+		sout[s].dc_avgI = pi;
+		sout[s].dc_avgQ = pq;
+	}
+}
+
+// ------------------------------------------------------------ fifth_order ----
+// e_b[idx] for idx < 0 is the history a block starts with: hist[6+idx] of the
+// state for block 0, otherwise sample N-1+idx of the previous block — the
+// archive holds x[N-7..N-2] (src/rtl_fm.c:800-805), the final sample x[N-1] is
+// never kept.
+__device__ __forceinline__ iq16 fifth_fetch(const uint32_t *__restrict__ Xs, int N, int b, int idx,
+                                            const state_t *__restrict__ st, int p)
+{
+	while (idx < 0) {
+		if (b == 0) {
+			iq16 r;
+			r.i = st->lp_i_hist[p][6 + idx];
+			r.q = st->lp_q_hist[p][6 + idx];
+			return r;
+		}
+		b -= 1;
+		idx = N - 1 + idx;
+	}
+	return unpack_iq(Xs[(size_t)b * N + idx]);
+}
+
+// One pass of fifth_order on I and Q (src/rtl_fm.c:1188-1191, 777-806): one
+// thread per complex output.  N = complex samples per block going in.
+__global__ void __launch_bounds__(256)
+k_fifth(const uint32_t *__restrict__ X, uint32_t *__restrict__ Y, size_t xstride, int N, int nblocks,
+        int nstreams, int p, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	const int M = N / 2;
+	const size_t total = (size_t)nstreams * nblocks * M;
+	RTLFM_GRID_STRIDE(g, total) {
+		int m = (int)(g % M);
+		size_t sb = g / M;
+		int b = (int)(sb % nblocks);
+		size_t s = sb / nblocks;
+		const uint32_t *Xs = X + s * xstride;
+		iq16 e[6];
+		if (m >= 3) {
+			const uint32_t *src = Xs + (size_t)b * N + 2 * m - 5;
+#pragma unroll
+			for (int k = 0; k < 6; k++) e[k] = unpack_iq(src[k]);
+		} else {
+#pragma unroll
+			for (int k = 0; k < 6; k++) e[k] = fifth_fetch(Xs, N, b, 2 * m - 5 + k, &sin[s], p);
+		}
+		int yi = fifth_tap(e[0].i, e[1].i, e[2].i, e[3].i, e[4].i, e[5].i);
+		int yq = fifth_tap(e[0].q, e[1].q, e[2].q, e[3].q, e[4].q, e[5].q);
+		Y[s * xstride + (size_t)b * M + m] = pack_iq((int16_t)yi, (int16_t)yq);
+		if (b == nblocks - 1 && m == M - 1) {
+			// archive: the window of the last output (src/rtl_fm.c:800-805)
+#pragma unroll
+			for (int k = 0; k < 6; k++) {
+				sout[s].lp_i_hist[p][k] = e[k].i;
+				sout[s].lp_q_hist[p][k] = e[k].q;
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------ generic_fir ----
+// Output t is the 9-tap sum over samples t-9..t-1 of the stream (history is
+// continuous across blocks, src/rtl_fm.c:808-831).  T = samples per stream.
+__global__ void __launch_bounds__(256)
+k_fir9(const uint32_t *__restrict__ X, uint32_t *__restrict__ Y, size_t xstride, int T, int nstreams,
+       int passes, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	const size_t total = (size_t)nstreams * T;
+	RTLFM_GRID_STRIDE(g, total) {
+		int t = (int)(g % T);
+		size_t s = g / T;
+		const uint32_t *Xs = X + s * xstride;
+		int hi[9], hq[9];
+#pragma unroll
+		for (int k = 0; k < 9; k++) {
+			int idx = t - 9 + k;
+			if (idx >= 0) {
+				iq16 v = unpack_iq(Xs[idx]);
+				hi[k] = v.i; hq[k] = v.q;
+			} else {
+				hi[k] = sin[s].droop_i_hist[9 + idx];
+				hq[k] = sin[s].droop_q_hist[9 + idx];
+			}
+		}
+		int yi = fir9_tap(hi, k_cic9[passes]);
+		int yq = fir9_tap(hq, k_cic9[passes]);
+		Y[s * xstride + t] = pack_iq((int16_t)yi, (int16_t)yq);
+		if (t == T - 1) {
+			iq16 cur = unpack_iq(Xs[t]);
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				sout[s].droop_i_hist[k] = (int16_t)hi[k + 1];
+				sout[s].droop_q_hist[k] = (int16_t)hq[k + 1];
+			}
+			sout[s].droop_i_hist[8] = cur.i;
+			sout[s].droop_q_hist[8] = cur.q;
+		}
+	}
+}
+
+// ---------------------------------------------------------------- low_pass ----
+// Boxcar sum of `D` complex samples (src/rtl_fm.c:461-481) over the stream's
+// whole run: with p0 samples already accumulated in (now_r, now_j), output k
+// covers run samples [k*D - p0, (k+1)*D - p0).  T = run length in samples.
+// cnt[s] receives the number of outputs.
+__global__ void __launch_bounds__(256)
+k_boxcar(const uint32_t *__restrict__ X, uint32_t *__restrict__ Y, size_t xstride, int T, int nstreams,
+         int D, const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt)
+{
+	const int maxout = T / D + 1;
+	const size_t total = (size_t)nstreams * (maxout + 1);
+	RTLFM_GRID_STRIDE(g, total) {
+		int k = (int)(g % (maxout + 1));
+		size_t s = g / (maxout + 1);
+		const int p0 = sin[s].prev_index;
+		const int E = (p0 + T) / D;
+		const uint32_t *Xs = X + s * xstride;
+		if (k < E) {
+			int lo = k * D - p0, hi = lo + D;
+			uint32_t ar = 0, aj = 0;
+			if (k == 0) { ar = (uint32_t)sin[s].now_r; aj = (uint32_t)sin[s].now_j; lo = 0; }
+			for (int n = lo; n < hi; n++) {
+				iq16 v = unpack_iq(Xs[n]);
+				ar += (uint32_t)(int)v.i; aj += (uint32_t)(int)v.q;
+			}
+			Y[s * xstride + k] = pack_iq((int16_t)(int)ar, (int16_t)(int)aj);
+		} else if (k == E) {
+			// the partial sum that stays behind
+			int lo = E * D - p0;
+			uint32_t ar = 0, aj = 0;
+			if (E == 0) { ar = (uint32_t)sin[s].now_r; aj = (uint32_t)sin[s].now_j; lo = 0; }
+			for (int n = lo; n < T; n++) {
+				iq16 v = unpack_iq(Xs[n]);
+				ar += (uint32_t)(int)v.i; aj += (uint32_t)(int)v.q;
+			}
+			sout[s].now_r = (int)ar;
+			sout[s].now_j = (int)aj;
+			sout[s].prev_index = p0 + T - E * D;
+			cnt[s] = E;
+		}
+	}
+}
+
+// Which block does decimated sample t belong to, and is it that block's first?
+// Blocks of N input samples each; boxcar D with p0 pre-accumulated (D == 1,
+// p0 == 0 describes the fifth_order path with N already the decimated size).
+__device__ __forceinline__ int dec_block_of(int t, int N, int D, int p0)
+{
+	return (int)((((long long)t + 1) * D - p0 - 1) / N);
+}
+__device__ __forceinline__ bool dec_block_first(int t, int N, int D, int p0)
+{
+	if (t == 0) return true;
+	return dec_block_of(t - 1, N, D, p0) < dec_block_of(t, N, D, p0);
+}
+// first decimated index of block b / one past its last
+__device__ __forceinline__ int dec_block_begin(int b, int N, int D, int p0)
+{
+	return (int)(((long long)p0 + (long long)b * N) / D);
+}
+
+// ----------------------------------------------------------------- squelch ----
+// rms() of a block's decimated samples (src/rtl_fm.c:1083-1112) and the
+// squelch decision (:1204-1215).  One workgroup per (stream, block); writes
+// mute[s*nblocks+b] = 1 when the block is to be zeroed.
+__global__ void __launch_bounds__(256)
+k_squelch_rms(const uint32_t *__restrict__ X, size_t xstride, int N, int D, int nblocks,
+              const state_t *__restrict__ sin, int level, int omit_dc_fix, int32_t *__restrict__ mute)
+{
+	const int sb = blockIdx.x;
+	const int b = sb % nblocks;
+	const size_t s = sb / nblocks;
+	const int p0 = D > 1 ? sin[s].prev_index : 0;
+	const int t0 = dec_block_begin(b, N, D, p0), t1 = dec_block_begin(b + 1, N, D, p0);
+	const int16_t *lp = reinterpret_cast<const int16_t *>(X + s * xstride + t0);
+	const int len = 2 * (t1 - t0);
+	int step = 1;
+	while (len > step * 32768) ++step;
+	uint32_t p = 0;
+	int32_t t = 0;
+	for (int i = threadIdx.x * step; i < len; i += blockDim.x * step) {
+		int v = lp[i];
+		t += v;
+		p += (uint32_t)(v * v);
+	}
+	__shared__ uint32_t rp[256];
+	__shared__ int32_t rt[256];
+	rp[threadIdx.x] = p; rt[threadIdx.x] = t;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) {
+			rp[threadIdx.x] += rp[threadIdx.x + off];
+			rt[threadIdx.x] = (int32_t)((uint32_t)rt[threadIdx.x] + (uint32_t)rt[threadIdx.x + off]);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		p = rp[0]; t = rt[0];
+		int sr;
+		if (omit_dc_fix) {
+			int num = len / step;
+			sr = (int)sqrt((double)p / num);
+		} else {
+			double dc = (double)(int32_t)((uint32_t)t * (uint32_t)step) / (double)len;
+			double err = t * 2 * dc - dc * dc * len;
+			sr = (int)sqrt((p - err) / len);
+		}
+		mute[sb] = (sr >= 0 && sr < level) ? 1 : (sr >= 0 ? 0 : 2);
+	}
+}
+
+// squelch_hits bookkeeping, sequential over a stream's blocks.
+__global__ void k_squelch_hits(const int32_t *__restrict__ mute, int nblocks, int nstreams,
+                               const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) {
+		int hits = sin[s].squelch_hits;
+		for (int b = 0; b < nblocks; b++) {
+			int m = mute[s * nblocks + b];
+			if (m == 1) hits++;
+			else if (m == 0) hits = 0;
+		}
+		sout[s].squelch_hits = hits;
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_squelch_zero(uint32_t *__restrict__ X, size_t xstride, int N, int D, int nblocks, int nstreams, int T,
+               const state_t *__restrict__ sin, const int32_t *__restrict__ mute)
+{
+	const size_t total = (size_t)nstreams * T;
+	RTLFM_GRID_STRIDE(g, total) {
+		int t = (int)(g % T);
+		size_t s = g / T;
+		const int p0 = D > 1 ? sin[s].prev_index : 0;
+		int b = dec_block_of(t, N, D, p0);
+		if (b < nblocks && mute[s * nblocks + b] == 1)
+			X[s * xstride + t] = 0;
+	}
+}
+
+// ------------------------------------------------------------------ demods ----
+// fm_demod (src/rtl_fm.c:932-959): output t pairs sample t with t-1 (or with
+// the carried pre_r/pre_j); the FIRST output of every block always uses
+// polar_discriminant.  cnt == nullptr: every stream has T samples.
+__global__ void __launch_bounds__(256)
+k_fm_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restrict__ R, size_t rstride,
+           int T, int nstreams, int N, int D, int variant, const int32_t *__restrict__ lut,
+           const int32_t *__restrict__ cnt, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	const size_t total = (size_t)nstreams * T;
+	RTLFM_GRID_STRIDE(g, total) {
+		int t = (int)(g % T);
+		size_t s = g / T;
+		const int Ts = cnt ? cnt[s] : T;
+		if (t >= Ts) continue;
+		const uint32_t *Xs = X + s * xstride;
+		iq16 cur = unpack_iq(Xs[t]);
+		int br, bj;
+		if (t > 0) {
+			iq16 pv = unpack_iq(Xs[t - 1]);
+			br = pv.i; bj = pv.q;
+		} else {
+			br = sin[s].pre_r; bj = sin[s].pre_j;
+		}
+		const int p0 = D > 1 ? sin[s].prev_index : 0;
+		int v = dec_block_first(t, N, D, p0) ? disc_std(cur.i, cur.q, br, bj)
+		                                     : discriminate(variant, cur.i, cur.q, br, bj, lut);
+		R[s * rstride + t] = (int16_t)v;
+		if (t == Ts - 1) {
+			sout[s].pre_r = cur.i;
+			sout[s].pre_j = cur.q;
+		}
+	}
+}
+
+// am_demod / usb_demod / lsb_demod / raw_demod (src/rtl_fm.c:961-1009)
+__global__ void __launch_bounds__(256)
+k_simple_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restrict__ R, size_t rstride,
+               int T, int nstreams, int mode, int output_scale, const int32_t *__restrict__ cnt)
+{
+	const size_t total = (size_t)nstreams * T;
+	RTLFM_GRID_STRIDE(g, total) {
+		int t = (int)(g % T);
+		size_t s = g / T;
+		const int Ts = cnt ? cnt[s] : T;
+		if (t >= Ts) continue;
+		uint32_t w = X[s * xstride + t];
+		iq16 v = unpack_iq(w);
+		if (mode == RTLFM_MODE_RAW) {
+			reinterpret_cast<uint32_t *>(R + s * rstride)[t] = w;
+			continue;
+		}
+		int16_t base;
+		if (mode == RTLFM_MODE_AM) {
+			int pcm = v.i * v.i + v.q * v.q;
+			base = (int16_t)sqrt((double)pcm);
+		} else if (mode == RTLFM_MODE_USB) {
+			base = (int16_t)(v.i + v.q);
+		} else {
+			base = (int16_t)(v.i - v.q);
+		}
+		R[s * rstride + t] = (int16_t)(int)((uint32_t)(int)base * (uint32_t)output_scale);
+	}
+}
+
+// ------------------------------------------------------------- audio tail ----
+// low_pass_simple (src/rtl_fm.c:739-753): sums of `step`, no divide.
+__global__ void __launch_bounds__(256)
+k_post_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
+                  int Tout, int nstreams, int step)
+{
+	const size_t total = (size_t)nstreams * Tout;
+	RTLFM_GRID_STRIDE(g, total) {
+		int t = (int)(g % Tout);
+		size_t s = g / Tout;
+		const int16_t *src = A + s * astride + (size_t)t * step;
+		int acc = 0;
+		for (int k = 0; k < step; k++) acc += src[k];
+		B[s * bstride + t] = (int16_t)acc;
+	}
+}
+
+// deemph_filter (src/rtl_fm.c:1011-1026): non-linear one-pole IIR, one lane
+// per stream walks the stream's run in order.  len[s] (or T) samples.
+__global__ void k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt,
+                         int nstreams, int a, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) {
+		int avg = sin[s].deemph_avg;
+		const int n = cnt ? cnt[s] : T;
+		int16_t *r = R + s * rstride;
+		const int half = a / 2;
+		for (int k = 0; k < n; k++) {
+			int d = r[k] - avg;
+			avg += d > 0 ? (d + half) / a : (d - half) / a;
+			r[k] = (int16_t)avg;
+		}
+		sout[s].deemph_avg = avg;
+	}
+}
+
+// dc_block_audio_filter (src/rtl_fm.c:1028-1041).  Block sums in parallel ...
+__global__ void __launch_bounds__(256)
+k_adc_sums(const int16_t *__restrict__ R, size_t rstride, int per_block, int nblocks,
+           long long *__restrict__ sums)
+{
+	const int sb = blockIdx.x;
+	const int b = sb % nblocks;
+	const size_t s = sb / nblocks;
+	const int16_t *r = R + s * rstride + (size_t)b * per_block;
+	long long acc = 0;
+	for (int k = threadIdx.x; k < per_block; k += blockDim.x) acc += r[k];
+	__shared__ long long red[256];
+	red[threadIdx.x] = acc;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) sums[sb] = red[0];
+}
+// ... the smoothing recurrence sequentially per stream ...
+__global__ void k_adc_smooth(const long long *__restrict__ sums, int per_block, int nblocks, int nstreams,
+                             int k, const state_t *__restrict__ sin, state_t *__restrict__ sout,
+                             int32_t *__restrict__ avg)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) {
+		int prev = sin[s].dc_avg;
+		for (int b = 0; b < nblocks; b++) {
+			int m = (int)(sums[s * nblocks + b] / per_block);
+			m = (m + prev * k) / (k + 1);
+			avg[s * nblocks + b] = m;
+			prev = m;
+		}
+		sout[s].dc_avg = prev;
+	}
+}
+// ... and the subtraction.
+__global__ void __launch_bounds__(256)
+k_adc_apply(int16_t *__restrict__ R, size_t rstride, int per_block, int nblocks, int nstreams,
+            const int32_t *__restrict__ avg)
+{
+	const size_t total = (size_t)nstreams * nblocks * per_block;
+	RTLFM_GRID_STRIDE(g, total) {
+		size_t sb = g / per_block;
+		int k = (int)(g % per_block);
+		size_t s = sb / nblocks;
+		int b = (int)(sb % nblocks);
+		int16_t *r = R + s * rstride + (size_t)b * per_block + k;
+		*r = (int16_t)(*r - avg[sb]);
+	}
+}
+
+// low_pass_real (src/rtl_fm.c:755-775) in closed form over the stream's run:
+// with phase p0 = prev_lpr_index (< fast) and slow <= fast, the number of
+// outputs after i+1 inputs is floor((p0 + (i+1)*slow)/fast); output m is
+// emitted at input ceil(((m+1)*fast - p0)/slow) - 1 and is the sum since the
+// previous emission (plus the carried now_lpr for m == 0) divided by
+// fast/slow (truncating).  n_in[s] (or T) inputs; cnt_out[s] outputs.
+__global__ void __launch_bounds__(256)
+k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
+                int T, const int32_t *__restrict__ n_in, int nstreams, int fast, int slow,
+                const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out)
+{
+	const int div = fast / slow;
+	const int maxout = (int)(((long long)fast - 1 + (long long)T * slow) / fast);
+	const size_t total = (size_t)nstreams * (maxout + 1);
+	RTLFM_GRID_STRIDE(g, total) {
+		int m = (int)(g % (maxout + 1));
+		size_t s = g / (maxout + 1);
+		const int n = n_in ? n_in[s] : T;
+		const long long p0 = sin[s].prev_lpr_index;
+		const int E = (int)((p0 + (long long)n * slow) / fast);
+		const int16_t *a = A + s * astride;
+		// first input index NOT yet consumed by outputs 0..m-1
+		auto end_of = [&](int mm) -> long long {  // inputs consumed once output mm is out
+			long long need = ((long long)mm + 1) * fast - p0;
+			return (need + slow - 1) / slow;
+		};
+		if (m < E) {
+			long long lo = m == 0 ? 0 : end_of(m - 1), hi = end_of(m);
+			uint32_t acc = m == 0 ? (uint32_t)sin[s].now_lpr : 0u;
+			for (long long k = lo; k < hi; k++) acc += (uint32_t)(int)a[k];
+			B[s * bstride + m] = (int16_t)((int)acc / div);
+		} else if (m == E) {
+			long long lo = E == 0 ? 0 : end_of(E - 1);
+			uint32_t acc = E == 0 ? (uint32_t)sin[s].now_lpr : 0u;
+			for (long long k = lo; k < n; k++) acc += (uint32_t)(int)a[k];
+			sout[s].now_lpr = (int)acc;
+			sout[s].prev_lpr_index = (int)(p0 + (long long)n * slow - (long long)E * fast);
+			cnt_out[s] = E;
+		}
+	}
+}
+
+// arbitrary_upsample (src/rtl_fm.c:1114-1135), stateless per block, closed
+// form per output j.  The reference advances (i, tick) after each output:
+// tick += len1; if (tick > len2) {tick -= len2; i++}; clamp at the end.  Before
+// the clamp engages, after j outputs the total advance is j*len1 = (i-1)*len2 +
+// tick with 0 < tick <= len2 (tick == 0 only for j == 0).  The clamp sets
+// (i = len1-1, tick = len2) and is sticky.
+__global__ void __launch_bounds__(256)
+k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
+               int len1, int len2, int nblocks, int nstreams)
+{
+	const size_t total = (size_t)nstreams * nblocks * len2;
+	RTLFM_GRID_STRIDE(g, total) {
+		int j = (int)(g % len2);
+		size_t sb = g / len2;
+		int b = (int)(sb % nblocks);
+		size_t s = sb / nblocks;
+		const int16_t *a = A + s * astride + (size_t)b * len1;
+		long long adv = (long long)j * len1;
+		int i, tick;
+		if (adv == 0) {
+			i = 1; tick = 0;
+		} else {
+			long long q = (adv - 1) / len2;
+			i = 1 + (int)q;
+			tick = (int)(adv - q * len2);
+		}
+		if (i >= len1) { i = len1 - 1; tick = len2; }
+		double frac = (double)tick / (double)len2;
+		B[s * bstride + (size_t)b * len2 + j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
+	}
+}
+
+// arbitrary_downsample (src/rtl_fm.c:1137-1166): the double remainder makes it
+// order-dependent, so one lane walks one (stream, block) in order.
+__global__ void k_arb_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B,
+                                 size_t bstride, int len1, int len2, int nblocks, int nstreams)
+{
+	const size_t total = (size_t)nstreams * nblocks;
+	RTLFM_GRID_STRIDE(g, total) {
+		int b = (int)(g % nblocks);
+		size_t s = g / nblocks;
+		const int16_t *b1 = A + s * astride + (size_t)b * len1;
+		int16_t *b2 = B + s * bstride + (size_t)b * len2;
+		int src = 1, j = 0, tick = 0;
+		double carry = 0;
+		int16_t cur = 0;  // b2[j] while it is being accumulated
+		while (j < len2) {
+			double frac = 1.0;
+			if (tick + len2 > len1) frac = (double)(len1 - tick) / (double)len2;
+			cur = (int16_t)(cur + (int16_t)((double)b1[src] * frac + carry));
+			carry = (double)b1[src] * (1.0 - frac);
+			tick += len2;
+			src++;
+			if (tick > len1) {
+				b2[j] = (int16_t)(cur * len2 / len1);
+				j++;
+				cur = 0;
+				tick -= len1;
+			}
+			if (src >= len1) { src = len1 - 1; tick = len1; }
+		}
+	}
+}
+
+// Plain strided copy of per-stream results (used when a tail stage left the
+// final result in a work buffer).
+__global__ void __launch_bounds__(256)
+k_copy_i16(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride, int T,
+           const int32_t *__restrict__ cnt, int nstreams)
+{
+	const size_t total = (size_t)nstreams * T;
+	RTLFM_GRID_STRIDE(g, total) {
+		int t = (int)(g % T);
+		size_t s = g / T;
+		if (cnt && t >= cnt[s]) continue;
+		B[s * bstride + t] = A[s * astride + t];
+	}
+}
+
+__global__ void k_fill_cnt(int32_t *cnt, int nstreams, int v)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) cnt[s] = v;
+}
+__global__ void k_scale_cnt(int32_t *cnt, int nstreams, int mul, int div)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) cnt[s] = cnt[s] * mul / div;
+}
+
+}  // namespace rtlfm
