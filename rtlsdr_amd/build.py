@@ -35,7 +35,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
     if not force and not needs_build():
         return OUT
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
            "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + (extra or [])
     if verbose:

@@ -170,6 +170,15 @@ def load(path: str | None = None) -> C.CDLL:
         raise FileNotFoundError(
             f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and
+    # libhsa-runtime64 under the same sonames as /opt/rocm's.  If this library
+    # is opened first it binds /opt/rocm's copy, torch then brings a second HSA
+    # runtime and the device disappears for whoever comes second.  Importing
+    # torch first (when it is installed) makes both share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, res, args in _SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
