@@ -1,9 +1,598 @@
-// fused_kernel.h — placeholder until the streaming kernel lands.
+// fused_kernel.h — the streaming form of rtl_fm's FM chain for gfx950.
+//
+// ONE launch does, for every stream and every queued callback buffer,
+//   u8 -> int16 (-127)        src/rtl_fm.c:1326-1328
+//   rotate16_neg90            src/rtl_fm.c:424-434 (phase restarts per buffer)
+//   fifth_order x P           src/rtl_fm.c:777-806, 1188-1191 (incl. the per-buffer
+//                             history quirk: x[N-1] never reaches the next buffer)
+//   generic_fir (9 taps)      src/rtl_fm.c:808-831 (optional)
+//   fm_demod                  src/rtl_fm.c:932-959 (first output of a buffer: atan2)
+// reading each input byte from HBM exactly once and writing only int16 PCM.
+//
+// Mapping (CDNA4, wave64):
+//  * One wave owns one (stream, run of consecutive buffers) and walks it tile by
+//    tile; there is no workgroup barrier anywhere (workgroup == one wave).
+//  * A tile is 4096 complex samples = 8 KiB.  Lane l owns the contiguous run of
+//    64 samples [64l, 64l+64): eight 16-byte loads per lane, issued one tile
+//    ahead of use.
+//  * Pass 0 works on the raw bytes: each output is four v_dot4_i32_i8 per
+//    component against tap vectors that already contain the -j^n rotation signs
+//    and the I/Q swap, with the "-127" folded into the accumulator's start
+//    value; no unpack, no separate rotate.
+//  * Passes 1-2 run on packed (I,Q) int16 pairs with v_pk_* arithmetic (sums
+//    stay below 2^15 there); later passes, the droop FIR and the discriminator
+//    use 32-bit lanes.
+//  * The only cross-lane traffic is each lane's last few outputs per pass,
+//    handed to lane l+1 through a tiny wave-private LDS slot array (slot 0
+//    carries lane 63's tail into the next tile).  Arrays that have fewer than 6
+//    values per lane go through a linear LDS ring instead.
+//  * A wave that starts in the middle of a stream first runs ONE warm-up tile
+//    (the last tile of the previous buffer, outputs discarded): every carried
+//    quantity depends on fewer than 4096 earlier samples for P <= 6.
 #pragma once
+
 #include "dsp_device.h"
-namespace rtlfm { namespace fused {
-struct Workspace { void release() {} };
-inline bool supported(const rtlfm_cfg &, int) { return false; }
-inline int launch(Workspace &, const rtlfm_cfg &, int, const uint8_t *, size_t, int, int16_t *, size_t,
-                  const rtlfm_stream_state *, rtlfm_stream_state *, const int32_t *, hipStream_t) { return -ENOTSUP; }
-}}
+
+namespace rtlfm {
+namespace fused {
+
+using state_t = rtlfm_stream_state;
+
+constexpr int kLaneSamples = 64;
+constexpr int kTileSamples = 64 * kLaneSamples;  // 4096
+constexpr int kTileBytes = 2 * kTileSamples;     // 8192
+constexpr int kPre = 16;                         // prefix entries of a linear ring
+constexpr int kMaxP = 6;
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ short2_t as_s2(uint32_t v) { return __builtin_bit_cast(short2_t, v); }
+__device__ __forceinline__ uint32_t as_u32(short2_t v) { return __builtin_bit_cast(uint32_t, v); }
+
+// fifth_order on a packed (I,Q) pair, 16-bit lanes (valid while 32*|x| < 2^15)
+__device__ __forceinline__ uint32_t tap_pk16(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e,
+                                             uint32_t f)
+{
+	short2_t s = (as_s2(a) + as_s2(f)) + (as_s2(b) + as_s2(e)) * (short)5 + (as_s2(c) + as_s2(d)) * (short)10;
+	s = s >> 4;
+	return as_u32(s);
+}
+
+// the same with 32-bit lanes and the int16 store wrap
+__device__ __forceinline__ uint32_t tap_i32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e,
+                                            uint32_t f)
+{
+	iq16 A = unpack_iq(a), B = unpack_iq(b), C = unpack_iq(c), D = unpack_iq(d), E = unpack_iq(e),
+	     F = unpack_iq(f);
+	int yi = fifth_tap(A.i, B.i, C.i, D.i, E.i, F.i);
+	int yq = fifth_tap(A.q, B.q, C.q, D.q, E.q, F.q);
+	return pack_iq((int16_t)yi, (int16_t)yq);
+}
+
+// Tap vectors of pass 0 as packed int8x4 against a raw dword (I0,Q0,I1,Q1),
+// for even / odd output index m; bytes are first XORed with 0x80 (u-128), so
+// x-127 = s+1 and the constant sum of the taps goes into the bias.
+struct Pass0Taps {
+	int32_t ti[2][4], tq[2][4];
+	int32_t bi[2], bq[2];
+};
+
+__host__ __device__ inline Pass0Taps make_taps(bool rotate)
+{
+	Pass0Taps t{};
+	if (rotate) {
+		// I'(n): +I, +Q, -I, -Q for n%4 = 0..3 ; Q'(n): +Q, -I, -Q, +I
+		const int32_t iA = 0x01000000, iB = 0x0A000005, iC = 0x0500000A, iD = 0x00000001;
+		const int32_t nA = (int32_t)0xFF000000, nB = (int32_t)0xF60000FB, nC = (int32_t)0xFB0000F6,
+		              nD = 0x000000FF;
+		// m even: -A +B -C +D ; m odd: negated
+		t.ti[0][0] = nA; t.ti[0][1] = iB; t.ti[0][2] = nC; t.ti[0][3] = iD;
+		t.ti[1][0] = iA; t.ti[1][1] = nB; t.ti[1][2] = iC; t.ti[1][3] = nD;
+		t.bi[0] = 0; t.bi[1] = 0;
+		t.tq[0][0] = 0x00010000; t.tq[0][1] = 0x00F60500; t.tq[0][2] = 0x0005F600; t.tq[0][3] = 0x00000100;
+		t.tq[1][0] = 0x00FF0000; t.tq[1][1] = 0x000AFB00; t.tq[1][2] = 0x00FB0A00; t.tq[1][3] = 0x0000FF00;
+		t.bq[0] = -8; t.bq[1] = 8;
+	} else {
+		for (int p = 0; p < 2; p++) {
+			t.ti[p][0] = 0x00010000; t.ti[p][1] = 0x000A0005; t.ti[p][2] = 0x0005000A; t.ti[p][3] = 0x00000001;
+			t.tq[p][0] = 0x01000000; t.tq[p][1] = 0x0A000500; t.tq[p][2] = 0x05000A00; t.tq[p][3] = 0x00000100;
+			t.bi[p] = 32; t.bq[p] = 32;
+		}
+	}
+	return t;
+}
+
+struct Params {
+	const uint8_t *iq;
+	size_t stream_stride;
+	uint32_t block_len;
+	int nblocks, nstreams;
+	int16_t *out;
+	size_t out_stride;
+	const state_t *sin;
+	state_t *sout;
+	const int32_t *lut;
+	int variant, rotate;
+	int segs, blocks_per_seg;
+	Pass0Taps taps;
+};
+
+// ---- LDS layout of one wave (dword offsets) -----------------------------------
+template <int P, bool FIR9>
+struct Lds {
+	static constexpr int cz = 64 >> P;  // values per lane of the decimated array Z = Y[P-1]
+	static constexpr int raw = 0;                 // [64][4]
+	static constexpr int xh = raw + 64 * 4;       // [8]
+	static constexpr int y0 = xh + 8;             // Y0 tails [64][6]   (P >= 2)
+	static constexpr int y1 = y0 + (P >= 2 ? 64 * 6 : 0);  // Y1 tails (P >= 3)
+	static constexpr int y2 = y1 + (P >= 3 ? 64 * 6 : 0);  // Y2 tails (P >= 4)
+	static constexpr int y3 = y2 + (P >= 4 ? 64 * 6 : 0);  // Y3 ring, c=4 (P >= 5)
+	static constexpr int y4 = y3 + (P >= 5 ? kPre + 64 * 4 : 0);  // Y4 ring, c=2 (P >= 6)
+	static constexpr int fz = y4 + (P >= 6 ? kPre + 64 * 2 : 0);  // FIR input history
+	static constexpr bool fz_slots = cz >= 9;                     // else ring
+	static constexpr int fz_size = !FIR9 ? 0 : (fz_slots ? 64 * 10 : kPre + 64 * cz);
+	static constexpr int zd = fz + fz_size;       // demod input tails [64][2]
+	static constexpr int total = zd + 64 * 2;
+};
+
+// lane l publishes `mine`; returns what lane l-1 published (lane 0: what lane 63
+// published during the previous tile).  Wave-private, no barrier: the LDS
+// queue of one wave is in order.
+template <int W>
+__device__ __forceinline__ void slot_exchange(uint32_t *slots, const uint32_t (&mine)[W], uint32_t (&prev)[W],
+                                              int lane)
+{
+	if (lane < 63) {
+#pragma unroll
+		for (int k = 0; k < W; k++) slots[(lane + 1) * W + k] = mine[k];
+	}
+	__builtin_amdgcn_wave_barrier();
+#pragma unroll
+	for (int k = 0; k < W; k++) prev[k] = slots[lane * W + k];
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 63) {
+#pragma unroll
+		for (int k = 0; k < W; k++) slots[k] = mine[k];
+	}
+	__builtin_amdgcn_wave_barrier();
+}
+
+// linear ring: write this tile's C values per lane, read H entries before the
+// lane's first, then move the tile's tail into the prefix for the next tile.
+// QUIRK: at a buffer start the entries that lie before the buffer are read one
+// position further back (the newest sample of the previous buffer was never
+// archived, src/rtl_fm.c:800-805); with fewer than five values per lane that
+// reaches lanes 1 and 2 as well, so it is applied per position, not per lane.
+template <int C, int H, bool QUIRK>
+__device__ __forceinline__ void ring_exchange(uint32_t *ring, const uint32_t (&mine)[C], uint32_t (&hist)[H],
+                                              int lane, bool buffer_start)
+{
+#pragma unroll
+	for (int k = 0; k < C; k++) ring[kPre + lane * C + k] = mine[k];
+	__builtin_amdgcn_wave_barrier();
+#pragma unroll
+	for (int k = 0; k < H; k++) {
+		int pos = lane * C - H + k;
+		if (QUIRK && buffer_start && pos < 0) pos -= 1;
+		hist[k] = ring[kPre + pos];
+	}
+	__builtin_amdgcn_wave_barrier();
+	uint32_t t = 0;
+	if (lane < kPre) t = ring[64 * C + lane];
+	__builtin_amdgcn_wave_barrier();
+	if (lane < kPre) ring[lane] = t;
+	__builtin_amdgcn_wave_barrier();
+}
+
+// unpack one raw dword (samples 2j, 2j+1 of a buffer) into two rotated packed
+// (I,Q) int16 pairs: reference convert (:1326-1328) + rotate16_neg90 (:424-434)
+__device__ __forceinline__ void unpack_rot(uint32_t raw, int j_odd, int rotate, uint32_t &s0, uint32_t &s1)
+{
+	int a0 = (int)(raw & 0xff) - 127, b0 = (int)((raw >> 8) & 0xff) - 127;
+	int a1 = (int)((raw >> 16) & 0xff) - 127, b1 = (int)(raw >> 24) - 127;
+	if (!rotate) {
+		s0 = pack_iq(a0, b0); s1 = pack_iq(a1, b1);
+	} else if (!j_odd) {
+		s0 = pack_iq(a0, b0);    // n%4 == 0
+		s1 = pack_iq(b1, -a1);   // n%4 == 1: (b, -a)
+	} else {
+		s0 = pack_iq(-a0, -b0);  // n%4 == 2
+		s1 = pack_iq(-b1, a1);   // n%4 == 3: (-b, a)
+	}
+}
+
+// fifth_order over a lane's CIN inputs with its five predecessors e[-5..-1]
+template <int CIN, bool PK16>
+__device__ __forceinline__ void fifth_lane(const uint32_t (&x)[CIN], const uint32_t (&h)[5],
+                                           uint32_t (&y)[CIN / 2])
+{
+	auto e = [&](int idx) -> uint32_t { return idx < 0 ? h[5 + idx] : x[idx]; };
+#pragma unroll
+	for (int m = 0; m < CIN / 2; m++) {
+		if constexpr (PK16)
+			y[m] = tap_pk16(e(2 * m - 5), e(2 * m - 4), e(2 * m - 3), e(2 * m - 2), e(2 * m - 1), e(2 * m));
+		else
+			y[m] = tap_i32(e(2 * m - 5), e(2 * m - 4), e(2 * m - 3), e(2 * m - 2), e(2 * m - 1), e(2 * m));
+	}
+}
+
+// choose e[-5..-1] out of the six values t[0..5] = Y[c-6..c-1] of the
+// predecessor: normally the newest five; at a buffer start (lane 0 only) the
+// newest one was never archived (src/rtl_fm.c:800-805)
+__device__ __forceinline__ void quirk_select(const uint32_t (&t)[6], bool drop_newest, uint32_t (&h)[5])
+{
+#pragma unroll
+	for (int k = 0; k < 5; k++) h[k] = drop_newest ? t[k] : t[k + 1];
+}
+
+template <int P, bool FIR9>
+__global__ void __launch_bounds__(64) k_fused(const Params p)
+{
+	using L = Lds<P, FIR9>;
+	constexpr int CZ = L::cz;
+	__shared__ uint32_t lds[L::total];
+	const int lane = threadIdx.x;
+	const int wave = blockIdx.x;
+	const int seg = wave % p.segs;
+	const int s = wave / p.segs;
+	if (s >= p.nstreams) return;
+	const int tpb = (int)(p.block_len / kTileBytes);
+	const int b0 = seg * p.blocks_per_seg;
+	int b1 = b0 + p.blocks_per_seg;
+	if (b1 > p.nblocks) b1 = p.nblocks;
+	if (b0 >= b1) return;
+	const bool from_state = (b0 == 0);
+	const bool writes_state = (b1 == p.nblocks);
+	const state_t *sin = p.sin + s;
+	state_t *sout = p.sout + s;
+	const int rotate = p.rotate;
+
+	// ---- carried history at the start of the segment ---------------------------
+	for (int k = lane; k < L::total; k += 64) lds[k] = 0;
+	__builtin_amdgcn_wave_barrier();
+	if (from_state && lane == 0) {
+		for (int j = 0; j < 6; j++) lds[L::xh + j] = pack_iq(sin->lp_i_hist[0][j], sin->lp_q_hist[0][j]);
+		auto put_slots = [&](int off, int pass) {  // t[k] = hist[k+1]
+			for (int k = 0; k < 5; k++) lds[off + k] = pack_iq(sin->lp_i_hist[pass][k + 1], sin->lp_q_hist[pass][k + 1]);
+		};
+		auto put_ring = [&](int off, int pass) {  // A[kPre-7+j] = hist[j]
+			for (int j = 0; j < 6; j++) lds[off + kPre - 7 + j] = pack_iq(sin->lp_i_hist[pass][j], sin->lp_q_hist[pass][j]);
+		};
+		if (P >= 2) put_slots(L::y0, 1);
+		if (P >= 3) put_slots(L::y1, 2);
+		if (P >= 4) put_slots(L::y2, 3);
+		if (P >= 5) put_ring(L::y3, 4);
+		if (P >= 6) put_ring(L::y4, 5);
+		if (FIR9) {
+			for (int j = 0; j < 9; j++) {
+				uint32_t v = pack_iq(sin->droop_i_hist[j], sin->droop_q_hist[j]);
+				if (L::fz_slots) lds[L::fz + 1 + j] = v; else lds[L::fz + kPre - 9 + j] = v;
+			}
+		}
+		lds[L::zd + 1] = pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j);
+	}
+	__builtin_amdgcn_wave_barrier();
+
+	const int gt_first = b0 * tpb;
+	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
+	const int gt_end = b1 * tpb;
+	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
+	const int out_per_tile = 64 * CZ;
+	int16_t *out_base = p.out + (size_t)s * p.out_stride;
+
+	uint4 cur[8], nxt[8];
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)gt_begin * kTileBytes + lane * 128);
+#pragma unroll
+		for (int k = 0; k < 8; k++) cur[k] = src[k];
+	}
+
+	for (int gt = gt_begin; gt < gt_end; gt++) {
+		const bool more = gt + 1 < gt_end;
+		if (more) {
+			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)(gt + 1) * kTileBytes + lane * 128);
+#pragma unroll
+			for (int k = 0; k < 8; k++) nxt[k] = src[k];
+		}
+		const int tib = gt % tpb;
+		const bool bs = tib == 0;
+		const bool q0 = bs && lane == 0;  // the one place a buffer boundary shows
+		const bool emit = gt >= gt_first;
+		const bool last = gt + 1 == gt_end;
+
+		// ---------------------------------------------------------------- pass 0 ----
+		uint32_t D[32];
+#pragma unroll
+		for (int k = 0; k < 8; k++) { D[4 * k] = cur[k].x; D[4 * k + 1] = cur[k].y; D[4 * k + 2] = cur[k].z; D[4 * k + 3] = cur[k].w; }
+		uint32_t Y0[32];
+		{
+			uint32_t mine[4] = {D[28], D[29], D[30], D[31]}, prev[4];
+			slot_exchange<4>(lds + L::raw, mine, prev, lane);
+			uint32_t sx[35];
+			sx[0] = prev[1] ^ 0x80808080u; sx[1] = prev[2] ^ 0x80808080u; sx[2] = prev[3] ^ 0x80808080u;
+#pragma unroll
+			for (int j = 0; j < 32; j++) sx[3 + j] = D[j] ^ 0x80808080u;
+#pragma unroll
+			for (int m = 0; m < 32; m++) {
+				const int par = m & 1;
+				int ai = p.taps.bi[par], aq = p.taps.bq[par];
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					ai = __builtin_amdgcn_sdot4((int)sx[m + k], p.taps.ti[par][k], ai, false);
+					aq = __builtin_amdgcn_sdot4((int)sx[m + k], p.taps.tq[par][k], aq, false);
+				}
+				uint32_t pk = __builtin_amdgcn_perm((uint32_t)aq, (uint32_t)ai, 0x05040100u);
+				Y0[m] = as_u32(as_s2(pk) >> 4);
+			}
+		}
+		if (bs) {
+			// first three outputs of a buffer: history is the archived x' of the
+			// previous buffer (one sample older, previous buffer's rotation phase)
+			uint32_t e[11];
+#pragma unroll
+			for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
+			unpack_rot(D[0], 0, rotate, e[5], e[6]);
+			unpack_rot(D[1], 1, rotate, e[7], e[8]);
+			unpack_rot(D[2], 0, rotate, e[9], e[10]);
+			uint32_t f0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
+			uint32_t f1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
+			uint32_t f2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
+			if (lane == 0) { Y0[0] = f0; Y0[1] = f1; Y0[2] = f2; }
+		}
+		__builtin_amdgcn_wave_barrier();
+		{
+			// archive x'[N-7..N-2] of this tile (lane 63's samples 57..62)
+			const bool need = (((gt + 1) % tpb) == 0);
+			if (need) {
+				uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
+				unpack_rot(D[28], 0, rotate, a0, a1);
+				unpack_rot(D[29], 1, rotate, a2, a3);
+				unpack_rot(D[30], 0, rotate, a4, a5);
+				unpack_rot(D[31], 1, rotate, a6, a7);
+				if (lane == 63) {
+					lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
+					lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
+					if (last && writes_state) {
+						uint32_t v[6] = {a1, a2, a3, a4, a5, a6};
+						for (int j = 0; j < 6; j++) { iq16 w = unpack_iq(v[j]); sout->lp_i_hist[0][j] = w.i; sout->lp_q_hist[0][j] = w.q; }
+					}
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+
+		// helper: archive hist[pass] = Y[c-7..c-2] of lane 63 from registers
+		auto archive_regs = [&](auto &Y, int c, int pass) {
+			if (last && writes_state && lane == 63) {
+#pragma unroll
+				for (int j = 0; j < 6; j++) {
+					iq16 w = unpack_iq(Y[c - 7 + j]);
+					sout->lp_i_hist[pass][j] = w.i; sout->lp_q_hist[pass][j] = w.q;
+				}
+			}
+		};
+		auto archive_ring = [&](int off, int c, int pass) {
+			if (last && writes_state && lane == 63) {
+				// the tail was already moved into the prefix: A[kPre-7+j]
+				for (int j = 0; j < 6; j++) {
+					iq16 w = unpack_iq(lds[off + kPre - 7 + j]);
+					sout->lp_i_hist[pass][j] = w.i; sout->lp_q_hist[pass][j] = w.q;
+				}
+			}
+		};
+
+		// ------------------------------------------------------------ passes 1.. ----
+		uint32_t Z[CZ];  // output of the last pass
+		if constexpr (P == 1) {
+#pragma unroll
+			for (int k = 0; k < 32; k++) Z[k] = Y0[k];
+		} else {
+			uint32_t t6[6], h5[5];
+			uint32_t Y1[16];
+			{
+				uint32_t mine[6] = {Y0[26], Y0[27], Y0[28], Y0[29], Y0[30], Y0[31]};
+				slot_exchange<6>(lds + L::y0, mine, t6, lane);
+				quirk_select(t6, q0, h5);
+				fifth_lane<32, true>(Y0, h5, Y1);
+				archive_regs(Y0, 32, 1);
+			}
+			if constexpr (P == 2) {
+#pragma unroll
+				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
+			} else {
+				uint32_t Y2[8];
+				{
+					uint32_t mine[6] = {Y1[10], Y1[11], Y1[12], Y1[13], Y1[14], Y1[15]};
+					slot_exchange<6>(lds + L::y1, mine, t6, lane);
+					quirk_select(t6, q0, h5);
+					fifth_lane<16, true>(Y1, h5, Y2);
+					archive_regs(Y1, 16, 2);
+				}
+				if constexpr (P == 3) {
+#pragma unroll
+					for (int k = 0; k < 8; k++) Z[k] = Y2[k];
+				} else {
+					uint32_t Y3[4];
+					{
+						uint32_t mine[6] = {Y2[2], Y2[3], Y2[4], Y2[5], Y2[6], Y2[7]};
+						slot_exchange<6>(lds + L::y2, mine, t6, lane);
+						quirk_select(t6, q0, h5);
+						fifth_lane<8, false>(Y2, h5, Y3);
+						archive_regs(Y2, 8, 3);
+					}
+					if constexpr (P == 4) {
+#pragma unroll
+						for (int k = 0; k < 4; k++) Z[k] = Y3[k];
+					} else {
+						uint32_t Y4[2];
+						ring_exchange<4, 5, true>(lds + L::y3, Y3, h5, lane, bs);
+						fifth_lane<4, false>(Y3, h5, Y4);
+						archive_ring(L::y3, 4, 4);
+						if constexpr (P == 5) {
+							Z[0] = Y4[0]; Z[1] = Y4[1];
+						} else {
+							uint32_t Y5[1];
+							ring_exchange<2, 5, true>(lds + L::y4, Y4, h5, lane, bs);
+							fifth_lane<2, false>(Y4, h5, Y5);
+							archive_ring(L::y4, 2, 5);
+							Z[0] = Y5[0];
+						}
+					}
+				}
+			}
+		}
+
+		// --------------------------------------------------------- generic_fir ----
+		uint32_t V[CZ];  // what fm_demod sees
+		if constexpr (FIR9) {
+			uint32_t h9[9];
+			if constexpr (L::fz_slots) {
+				uint32_t mine[10], prev[10];
+#pragma unroll
+				for (int k = 0; k < 10; k++) mine[k] = Z[CZ - 10 + k];
+				slot_exchange<10>(lds + L::fz, mine, prev, lane);
+#pragma unroll
+				for (int k = 0; k < 9; k++) h9[k] = prev[1 + k];
+				if (last && writes_state && lane == 63) {
+#pragma unroll
+					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(Z[CZ - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
+				}
+			} else {
+				ring_exchange<CZ, 9, false>(lds + L::fz, Z, h9, lane, false);
+				if (last && writes_state && lane == 63) {
+					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(lds[L::fz + kPre - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
+				}
+			}
+			// output n = taps over the nine samples before n (src/rtl_fm.c:815-821)
+			auto e = [&](int idx) -> uint32_t { return idx < 0 ? h9[9 + idx] : Z[idx]; };
+#pragma unroll
+			for (int n = 0; n < CZ; n++) {
+				int hi[9], hq[9];
+#pragma unroll
+				for (int k = 0; k < 9; k++) { iq16 w = unpack_iq(e(n - 9 + k)); hi[k] = w.i; hq[k] = w.q; }
+				int yi = fir9_tap(hi, k_cic9[P]);
+				int yq = fir9_tap(hq, k_cic9[P]);
+				V[n] = pack_iq((int16_t)yi, (int16_t)yq);
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < CZ; k++) V[k] = Z[k];
+		}
+
+		// ------------------------------------------------------------ fm_demod ----
+		uint32_t pv;
+		{
+			uint32_t mine[2] = {0u, V[CZ - 1]}, prev[2];
+			slot_exchange<2>(lds + L::zd, mine, prev, lane);
+			pv = prev[1];
+			if (last && writes_state && lane == 63) {
+				iq16 w = unpack_iq(V[CZ - 1]);
+				sout->pre_r = w.i; sout->pre_j = w.q;
+			}
+		}
+		int16_t pcm[CZ];
+#pragma unroll
+		for (int n = 0; n < CZ; n++) {
+			iq16 c = unpack_iq(V[n]);
+			iq16 b = unpack_iq(n == 0 ? pv : V[n > 0 ? n - 1 : 0]);
+			int v;
+			if (p.variant == RTLFM_ATAN_STD) {
+				v = disc_std(c.i, c.q, b.i, b.q);
+			} else {
+				// first output of a buffer is always polar_discriminant (:935-937)
+				const bool first = (n == 0) && q0;
+				if (p.variant == RTLFM_ATAN_FAST) v = disc_fast(c.i, c.q, b.i, b.q);
+				else v = disc_lut(c.i, c.q, b.i, b.q, p.lut);
+				if (n == 0 && bs) {
+					int vs = disc_std(c.i, c.q, b.i, b.q);
+					if (first) v = vs;
+				}
+			}
+			pcm[n] = (int16_t)v;
+		}
+		if (emit) {
+			int16_t *dst = out_base + (size_t)(gt - 0) * out_per_tile + lane * CZ;
+			if constexpr (CZ >= 8) {
+				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+				for (int k = 0; k < CZ / 8; k++) {
+					uint4 w;
+					w.x = pack_iq(pcm[8 * k], pcm[8 * k + 1]); w.y = pack_iq(pcm[8 * k + 2], pcm[8 * k + 3]);
+					w.z = pack_iq(pcm[8 * k + 4], pcm[8 * k + 5]); w.w = pack_iq(pcm[8 * k + 6], pcm[8 * k + 7]);
+					d4[k] = w;
+				}
+			} else if constexpr (CZ == 4) {
+				*reinterpret_cast<uint2 *>(dst) = make_uint2(pack_iq(pcm[0], pcm[1]), pack_iq(pcm[2], pcm[3]));
+			} else if constexpr (CZ == 2) {
+				*reinterpret_cast<uint32_t *>(dst) = pack_iq(pcm[0], pcm[1]);
+			} else {
+				dst[0] = pcm[0];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+	}
+}
+
+struct Workspace {
+	void release() {}
+};
+
+inline bool supported(const rtlfm_cfg &c, int nblocks)
+{
+	if (c.mode != RTLFM_MODE_FM) return false;
+	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
+	if (c.block_len % kTileBytes) return false;
+	if (c.dc_block_raw || c.squelch_level) return false;
+	(void)nblocks;
+	return true;
+}
+
+template <int P, bool FIR9>
+static int launch_one(const Params &p, int waves, hipStream_t q)
+{
+	hipLaunchKernelGGL((k_fused<P, FIR9>), dim3(waves), dim3(64), 0, q, p);
+	return hipGetLastError() == hipSuccess ? 0 : -EIO;
+}
+
+inline int launch(Workspace &, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
+                  int nblocks, int16_t *d_out, size_t out_stride, const state_t *sin, state_t *sout,
+                  const int32_t *lut, hipStream_t q)
+{
+	if (((uintptr_t)d_out & 15) || (out_stride & 7)) return -EINVAL;
+	Params p{};
+	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
+	p.nblocks = nblocks; p.nstreams = nstreams;
+	p.out = d_out; p.out_stride = out_stride;
+	p.sin = sin; p.sout = sout; p.lut = lut;
+	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
+	p.taps = make_taps(p.rotate != 0);
+	// enough waves to fill 256 CUs several times over; a segment is a run of whole buffers
+	const int target_waves = 8192;
+	int segs = (target_waves + nstreams - 1) / nstreams;
+	if (segs > nblocks) segs = nblocks;
+	if (segs < 1) segs = 1;
+	int bps = (nblocks + segs - 1) / segs;
+	segs = (nblocks + bps - 1) / bps;
+	p.segs = segs; p.blocks_per_seg = bps;
+	const int waves = nstreams * segs;
+	const bool fir = c.comp_fir_size == 9;
+	switch (c.downsample_passes * 2 + (fir ? 1 : 0)) {
+	case 2: return launch_one<1, false>(p, waves, q);
+	case 3: return launch_one<1, true>(p, waves, q);
+	case 4: return launch_one<2, false>(p, waves, q);
+	case 5: return launch_one<2, true>(p, waves, q);
+	case 6: return launch_one<3, false>(p, waves, q);
+	case 7: return launch_one<3, true>(p, waves, q);
+	case 8: return launch_one<4, false>(p, waves, q);
+	case 9: return launch_one<4, true>(p, waves, q);
+	case 10: return launch_one<5, false>(p, waves, q);
+	case 11: return launch_one<5, true>(p, waves, q);
+	case 12: return launch_one<6, false>(p, waves, q);
+	case 13: return launch_one<6, true>(p, waves, q);
+	default: return -ENOTSUP;
+	}
+}
+
+}  // namespace fused
+}  // namespace rtlfm

@@ -639,6 +639,8 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
 	                       hipMemcpyDeviceToDevice, h->stream));
 	bool can_fuse = fused::supported(h->cfg, nblocks);
+	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
+		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	int r;
 	if (h->path == 2 && !can_fuse) return -ENOTSUP;
 	if (h->path != 1 && can_fuse) {

@@ -171,3 +171,54 @@ def test_state_get_set_roundtrip(oracle_lib):
         for s in range(2):
             got = np.concatenate([o1[s, :n1[s]].cpu().numpy(), o2[s, :n2[s]].cpu().numpy()])
             assert_parity(got, want[s, :want_len[s]], cfg, "checkpoint")
+
+
+FUSED_CASES = [
+    # passes, fir9, atan, offset_tuning
+    (1, 0, 0, 0), (1, 1, 1, 0), (2, 0, 2, 0), (2, 1, 0, 0), (3, 0, 0, 0), (3, 1, 2, 0),
+    (4, 0, 0, 0), (4, 1, 1, 0), (4, 0, 2, 1), (5, 0, 0, 0), (5, 1, 0, 0), (6, 0, 0, 0),
+    (6, 1, 0, 0), (6, 1, 2, 1), (4, 0, 0, 1),
+]
+
+
+@pytest.mark.parametrize("passes,fir9,atan,offs", FUSED_CASES)
+@pytest.mark.parametrize("L,nb,ns", [(8192, 5, 3), (16384, 4, 40), (262144, 3, 2)])
+def test_fused_kernel_vs_oracle_and_staged(oracle_lib, passes, fir9, atan, offs, L, nb, ns):
+    """The fused streaming kernel (path 2): bit-exact against the oracle and the
+    staged kernels, including runs split into several segments with warm-up tiles
+    (ns small => several segments per stream) and carried state."""
+    ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0,
+              custom_atan=atan, offset_tuning=offs, rate_out=int(2.4e6) >> passes)
+    cfg = make_cfg(ov, L, nb)
+    amp = 30.0 if atan == 1 else 60.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=1000 + passes, fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    want, want_len, wstates = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    fo, fs_, used = gpu_run(cfg, iq, path=2)
+    assert used == 2
+    so, ss, used1 = gpu_run(cfg, iq, path=1)
+    assert used1 == 1
+    for s in range(ns):
+        assert np.array_equal(fo[s], so[s]), f"fused != staged, stream {s}"
+        assert_parity(fo[s], want[s, :want_len[s]], cfg, f"fused[{s}]")
+        assert gu.state_dict(fs_[s], False) == gu.state_dict(wstates[s], False)
+    # same data in two runs: carried state written by the fused kernel is complete
+    if nb >= 3:
+        fo2, fs2, _ = gpu_run(cfg, iq, path=2, splits=[(0, 1), (1, nb)])
+        for s in range(ns):
+            assert np.array_equal(fo2[s], fo[s])
+            assert gu.state_dict(fs2[s], False) == gu.state_dict(fs_[s], False)
+
+
+def test_fused_fullscale_random_bytes(oracle_lib):
+    """Full-scale random bytes: every integer stage of the fused kernel wraps like the reference."""
+    for passes, fir9 in ((4, 0), (6, 1), (3, 1)):
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0,
+                  custom_atan=2)  # LUT discriminator: integer only
+        L, nb, ns = 16384, 3, 12
+        cfg = make_cfg(ov, L, nb)
+        iq = synth.random_u8(ns, L * nb, seed=50 + passes)
+        want, want_len, _ = oracle_lib.run_batch(cfg, iq, nthreads=4)
+        outs, _, used = gpu_run(cfg, iq, path=2)
+        assert used == 2
+        for s in range(ns):
+            assert np.array_equal(outs[s], want[s, :want_len[s]]), (passes, fir9, s)
