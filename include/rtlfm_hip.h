@@ -205,6 +205,14 @@ int rtlfm_gpu_last_path(rtlfm_gpu *h);
 int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on);
 int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches);
 
+/*
+ * Diagnostic: evaluates the kernels' atan2 -> Q14 routine (the arithmetic of
+ * polar_discriminant, src/rtl_fm.c:842-849) and the device math library's
+ * atan2 chain on n host pairs yx[2k] = y, yx[2k+1] = x.  Either output may be
+ * NULL.  Used by the parity tests to pin one against the other.
+ */
+int rtlfm_gpu_selftest_atan2(int device, const int32_t *yx, int n, int32_t *q14, int32_t *q14_libm);
+
 const char *rtlfm_gpu_strerror(int err);
 /* (major<<16)|(minor<<8)|patch */
 int rtlfm_gpu_version(void);

@@ -71,22 +71,91 @@ __device__ __forceinline__ void conj_product(int ar, int aj, int br, int bj, int
 	cj = (int)((uint32_t)aj * (uint32_t)br - (uint32_t)ar * (uint32_t)bj);
 }
 
-// polar_discriminant (src/rtl_fm.c:842-849): fp64 atan2, the literal 3.14159,
-// truncation toward zero.
+// ---- atan2 -> Q14 ----------------------------------------------------------
+// polar_discriminant (src/rtl_fm.c:842-849) ends in
+//     (int)(atan2((double)cj, (double)cr) / 3.14159 * (1<<14))
+// i.e. trunc(theta * K) with K = 16384/3.14159 (note the literal).  The library
+// atan2 costs ~135 VALU instructions per call on gfx950; at one call per
+// decimated sample it would dominate the fused kernel.  atan2_q14 computes the
+// same integer with ~45 instructions, everything in fp64:
+//   * octant folding to w = atan(mn/mx), mn <= mx;
+//   * mn/mx is located in one of 17 nodes c = i/16 (fp32 estimate), and
+//     atan(mn/mx) = atan(c) + atan(t), t = (mn - c*mx)/(mx + c*mn), |t| <= 1/32
+//     (numerator and denominator are exact in fp64 for 32-bit inputs);
+//   * K*atan(t) = t*(K - K/3 t^2 + K/5 t^4 - K/7 t^6), truncation error
+//     K*t^9/9 < 2e-11 LSB; K*atan(c) comes from a 17-entry table rounded from
+//     long double.
+// The result differs from trunc() of the correctly rounded chain only when
+// theta*K lies within ~1e-11 of an integer.
+#define RTLFM_ATAN_K 0x1.45f318e7adaf4p+12     /* 16384/3.14159            */
+#define RTLFM_ATAN_K3 -0x1.b299768a3ce9bp+10   /* -K/3                     */
+#define RTLFM_ATAN_K5 0x1.04c27a52f1590p+10    /*  K/5                     */
+#define RTLFM_ATAN_K7 -0x1.74838a2d58c85p+9    /* -K/7                     */
+#define RTLFM_ATAN_H 0x1.00000e2bce869p+13     /* (pi/2)*K = 8192.0069...  */
+#define RTLFM_ATAN_PIK 0x1.00000e2bce869p+14   /* pi*K     = 16384.0138... */
+
+// K*atan(i/16), i = 0..16
+__constant__ const double k_atan_nodes[17] = {
+	0x0.0p+0, 0x1.4586b38c3d5d7p+8, 0x1.444486fab2e62p+9, 0x1.e3500e621f45ep+9, 0x1.3f671d1a270f7p+10,
+	0x1.8ae69b2cc786ap+10, 0x1.d3c3be67b1e47p+10, 0x1.0cd99bf47b146p+11, 0x1.2e4062951c4edp+11,
+	0x1.4e06ba27c2404p+11, 0x1.6c2683974a150p+11, 0x1.88a17177cd652p+11, 0x1.a37f7385017cap+11,
+	0x1.bccd369d2515fp+11, 0x1.d49acd9d30f62p+11, 0x1.eafa8d1c75877p+11, 0x1.00000e2bce869p+12,
+};
+
+struct AtanNodesConst {
+	__device__ __forceinline__ double operator()(int i) const { return k_atan_nodes[i]; }
+};
+
+template <class Nodes>
+__device__ __forceinline__ int atan2_q14(int y, int x, Nodes nodes)
+{
+	const double fx = (double)x, fy = (double)y;
+	const double ax = fabs(fx), ay = fabs(fy);
+	const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+	// node index from an fp32 estimate of mn/mx (mx == 0 gives NaN -> 0)
+	const float q = (float)mn * __builtin_amdgcn_rcpf((float)mx);
+	int i = (int)__builtin_fmaf(q, 16.0f, 0.5f);
+	i = i > 16 ? 16 : i;
+	const double c = (double)i * 0.0625;
+	const double num = __builtin_fma(-c, mx, mn);  // exact
+	const double den = __builtin_fma(c, mn, mx);   // exact
+	double r = __builtin_amdgcn_rcp(den);
+	r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+	r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+	const double t = num * r;
+	const double t2 = t * t;
+	double p = __builtin_fma(t2, RTLFM_ATAN_K7, RTLFM_ATAN_K5);
+	p = __builtin_fma(t2, p, RTLFM_ATAN_K3);
+	p = __builtin_fma(t2, p, RTLFM_ATAN_K);
+	const double w = __builtin_fma(t, p, nodes(i));  // K*atan(mn/mx) in [0, 4096.004]
+	const bool swap = ay > ax, neg = x < 0;
+	// x>=0: swap ? H - w : w ;  x<0: swap ? H + w : PIK - w
+	const double base = neg ? (swap ? RTLFM_ATAN_H : RTLFM_ATAN_PIK) : (swap ? RTLFM_ATAN_H : 0.0);
+	const double v = (neg != swap) ? base - w : base + w;
+	int n = (int)v;
+	n = (mx == 0.0) ? 0 : n;
+	return y < 0 ? -n : n;
+}
+
+// The library path, kept for A/B checks of atan2_q14 (rtlfm_gpu_selftest_atan2).
+__device__ __forceinline__ int atan2_q14_libm(int y, int x)
+{
+	double angle = atan2((double)y, (double)x);
+	return (int)(angle / 3.14159 * 16384.0);
+}
+
+// polar_discriminant (src/rtl_fm.c:842-849)
 __device__ __forceinline__ int disc_std(int ar, int aj, int br, int bj)
 {
 	int cr, cj;
 	conj_product(ar, aj, br, bj, cr, cj);
-	double angle = atan2((double)cj, (double)cr);
-	return (int)(angle / 3.14159 * 16384.0);
+	return atan2_q14(cj, cr, AtanNodesConst());
 }
 
-// fast_atan2 (src/rtl_fm.c:851-872) behind polar_disc_fast (:874-879); the
-// 4096*(...) products wrap in 32 bits exactly as the x86 build does.
-__device__ __forceinline__ int disc_fast(int ar, int aj, int br, int bj)
+// fast_atan2 (src/rtl_fm.c:851-872); the 4096*(...) products wrap in 32 bits
+// exactly as the x86 build does.
+__device__ __forceinline__ int fast_atan2_q14(int y, int x)
 {
-	int x, y;
-	conj_product(ar, aj, br, bj, x, y);
 	if (x == 0 && y == 0)
 		return 0;
 	int ay = y < 0 ? (int)(0u - (uint32_t)y) : y;
@@ -105,12 +174,18 @@ __device__ __forceinline__ int disc_fast(int ar, int aj, int br, int bj)
 	return y < 0 ? -angle : angle;
 }
 
-// polar_disc_lut (src/rtl_fm.c:894-930) over the host-built atan_lut
-// (src/rtl_fm.c:881-892), including the x == 0 fall-through.
-__device__ __forceinline__ int disc_lut(int ar, int aj, int br, int bj, const int32_t *__restrict__ lut)
+// polar_disc_fast (src/rtl_fm.c:874-879)
+__device__ __forceinline__ int disc_fast(int ar, int aj, int br, int bj)
 {
-	int cr, cj;
-	conj_product(ar, aj, br, bj, cr, cj);
+	int x, y;
+	conj_product(ar, aj, br, bj, x, y);
+	return fast_atan2_q14(y, x);
+}
+
+// the body of polar_disc_lut (src/rtl_fm.c:899-930) over the host-built atan_lut
+// (src/rtl_fm.c:881-892), including the x == 0 fall-through
+__device__ __forceinline__ int lut_atan2_q14(int cj, int cr, const int32_t *__restrict__ lut)
+{
 	if (cr == 0 || cj == 0) {
 		if (cr == 0 && cj == 0) return 0;
 		if (cr == 0) return cj > 0 ? 8192 : -8192;
@@ -124,6 +199,13 @@ __device__ __forceinline__ int disc_lut(int ar, int aj, int br, int bj, const in
 	if (x > 0)
 		return cj > 0 ? lut[x] : lut[x] - 16384;
 	return cj > 0 ? 16384 - lut[-x] : -lut[-x];
+}
+
+__device__ __forceinline__ int disc_lut(int ar, int aj, int br, int bj, const int32_t *__restrict__ lut)
+{
+	int cr, cj;
+	conj_product(ar, aj, br, bj, cr, cj);
+	return lut_atan2_q14(cj, cr, lut);
 }
 
 __device__ __forceinline__ int discriminate(int variant, int ar, int aj, int br, int bj,

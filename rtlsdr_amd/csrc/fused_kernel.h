@@ -9,27 +9,36 @@
 //   fm_demod                  src/rtl_fm.c:932-959 (first output of a buffer: atan2)
 // reading each input byte from HBM exactly once and writing only int16 PCM.
 //
-// Mapping (CDNA4, wave64):
+// Mapping (CDNA4, wave64).  The kernel is VALU-bound before it is HBM-bound
+// (integer VALU issues 16 lanes/clk/SIMD), so everything below is about
+// instructions per input sample:
 //  * One wave owns one (stream, run of consecutive buffers) and walks it tile by
 //    tile; there is no workgroup barrier anywhere (workgroup == one wave).
 //  * A tile is 4096 complex samples = 8 KiB.  Lane l owns the contiguous run of
-//    64 samples [64l, 64l+64): eight 16-byte loads per lane, issued one tile
-//    ahead of use.
-//  * Pass 0 works on the raw bytes: each output is four v_dot4_i32_i8 per
-//    component against tap vectors that already contain the -j^n rotation signs
-//    and the I/Q swap, with the "-127" folded into the accumulator's start
-//    value; no unpack, no separate rotate.
-//  * Passes 1-2 run on packed (I,Q) int16 pairs with v_pk_* arithmetic (sums
-//    stay below 2^15 there); later passes, the droop FIR and the discriminator
-//    use 32-bit lanes.
-//  * The only cross-lane traffic is each lane's last few outputs per pass,
-//    handed to lane l+1 through a tiny wave-private LDS slot array (slot 0
-//    carries lane 63's tail into the next tile).  Arrays that have fewer than 6
-//    values per lane go through a linear LDS ring instead.
+//    64 samples [64l, 64l+64): eight 16-byte loads per lane (this pattern reads
+//    HBM as fast as a fully coalesced one, tools/bw_probe.hip), re-issued into
+//    the same registers as soon as pass 0 has consumed them.
+//  * Pass 0 works on the raw bytes: two v_perm_b32 per input dword gather the
+//    bytes one output component needs, then each output is two v_dot4_i32_i8
+//    per component against tap vectors that already contain the -j^n rotation
+//    signs and the I/Q swap; the "-127" is folded into the accumulator's start
+//    value.  No unpack, no separate rotate.
+//  * Passes 1-2 (and 3 when rotating) run on packed (I,Q) int16 pairs with
+//    v_pk_* arithmetic (the sums stay below 2^15 there); later passes, the
+//    droop FIR and the tails use 32-bit lanes.
+//  * The conjugate product of the discriminator is two v_dot2_i32_i16; the
+//    angle is atan2_q14 (dsp_device.h) with its node table in LDS.
+//  * The only cross-lane traffic is each lane's last five outputs per pass,
+//    handed to lane l+1 through a small wave-private LDS slot array; lane 63
+//    leaves what lane 0 of the next tile needs in slot 0, already shifted by
+//    one when that tile starts a buffer.  Arrays with fewer than 5 values per
+//    lane go through a linear LDS ring instead.
 //  * A wave that starts in the middle of a stream first runs ONE warm-up tile
 //    (the last tile of the previous buffer, outputs discarded): every carried
 //    quantity depends on fewer than 4096 earlier samples for P <= 6.
 #pragma once
+
+#include <type_traits>
 
 #include "dsp_device.h"
 
@@ -69,33 +78,36 @@ __device__ __forceinline__ uint32_t tap_i32(uint32_t a, uint32_t b, uint32_t c, 
 	return pack_iq((int16_t)yi, (int16_t)yq);
 }
 
-// Tap vectors of pass 0 as packed int8x4 against a raw dword (I0,Q0,I1,Q1),
-// for even / odd output index m; bytes are first XORed with 0x80 (u-128), so
-// x-127 = s+1 and the constant sum of the taps goes into the bias.
+// Pass 0 constants.  S_j = raw dword j (I_2j, Q_2j, I_2j+1, Q_2j+1) XOR 0x80808080
+// (bytes become u-128, so x-127 = s+1 and the tap sum goes into the bias).
+//   G_j = perm(S_j-1, S_j, selG), H_j = perm(S_j-1, S_j, selH)
+//   I'[m] = bias_i + dot4(G_m, ti[par][0]) + dot4(G_m-2, ti[par][1])      (par = m & 1)
+//   Q'[m] = bias_q + dot4(H_m, tq[par][0]) + dot4(H_m-2, tq[par][1])
+// With rotation, sample n of a buffer is multiplied by (-j)^n:
+//   I'(n) = +I,+Q,-I,-Q and Q'(n) = +Q,-I,-Q,+I for n%4 = 0..3,
+// so G gathers (I_2j, Q_2j+1) and H gathers (Q_2j, I_2j+1) and the signs sit in
+// the taps; without it G gathers the I bytes, H the Q bytes.
 struct Pass0Taps {
-	int32_t ti[2][4], tq[2][4];
+	uint32_t selG, selH;
+	int32_t ti[2][2], tq[2][2];
 	int32_t bi[2], bq[2];
 };
 
-__host__ __device__ inline Pass0Taps make_taps(bool rotate)
+inline Pass0Taps make_taps(bool rotate)
 {
 	Pass0Taps t{};
 	if (rotate) {
-		// I'(n): +I, +Q, -I, -Q for n%4 = 0..3 ; Q'(n): +Q, -I, -Q, +I
-		const int32_t iA = 0x01000000, iB = 0x0A000005, iC = 0x0500000A, iD = 0x00000001;
-		const int32_t nA = (int32_t)0xFF000000, nB = (int32_t)0xF60000FB, nC = (int32_t)0xFB0000F6,
-		              nD = 0x000000FF;
-		// m even: -A +B -C +D ; m odd: negated
-		t.ti[0][0] = nA; t.ti[0][1] = iB; t.ti[0][2] = nC; t.ti[0][3] = iD;
-		t.ti[1][0] = iA; t.ti[1][1] = nB; t.ti[1][2] = iC; t.ti[1][3] = nD;
-		t.bi[0] = 0; t.bi[1] = 0;
-		t.tq[0][0] = 0x00010000; t.tq[0][1] = 0x00F60500; t.tq[0][2] = 0x0005F600; t.tq[0][3] = 0x00000100;
-		t.tq[1][0] = 0x00FF0000; t.tq[1][1] = 0x000AFB00; t.tq[1][2] = 0x00FB0A00; t.tq[1][3] = 0x0000FF00;
-		t.bq[0] = -8; t.bq[1] = 8;
+		t.selG = 0x07040300u; t.selH = 0x06050201u;
+		t.ti[0][0] = (int32_t)0xFBF60001; t.ti[0][1] = (int32_t)0xFF000A05;  // (1,0,-10,-5) (5,10,0,-1)
+		t.ti[1][0] = 0x050A00FF; t.ti[1][1] = 0x0100F6FB;                    // negated
+		t.tq[0][0] = 0x05F60001; t.tq[0][1] = 0x0100F605;                    // (1,0,-10,5) (5,-10,0,1)
+		t.tq[1][0] = (int32_t)0xFB0A00FF; t.tq[1][1] = (int32_t)0xFF000AFB;  // negated
+		t.bi[0] = 0; t.bi[1] = 0; t.bq[0] = -8; t.bq[1] = 8;
 	} else {
+		t.selG = 0x06040200u; t.selH = 0x07050301u;
 		for (int p = 0; p < 2; p++) {
-			t.ti[p][0] = 0x00010000; t.ti[p][1] = 0x000A0005; t.ti[p][2] = 0x0005000A; t.ti[p][3] = 0x00000001;
-			t.tq[p][0] = 0x01000000; t.tq[p][1] = 0x0A000500; t.tq[p][2] = 0x05000A00; t.tq[p][3] = 0x00000100;
+			t.ti[p][0] = 0x050A0001; t.ti[p][1] = 0x01000A05;  // (1,0,10,5) (5,10,0,1)
+			t.tq[p][0] = 0x050A0001; t.tq[p][1] = 0x01000A05;
 			t.bi[p] = 32; t.bq[p] = 32;
 		}
 	}
@@ -121,48 +133,67 @@ struct Params {
 template <int P, bool FIR9>
 struct Lds {
 	static constexpr int cz = 64 >> P;  // values per lane of the decimated array Z = Y[P-1]
-	static constexpr int raw = 0;                 // [64][4]
-	static constexpr int xh = raw + 64 * 4;       // [8]
-	static constexpr int y0 = xh + 8;             // Y0 tails [64][6]   (P >= 2)
-	static constexpr int y1 = y0 + (P >= 2 ? 64 * 6 : 0);  // Y1 tails (P >= 3)
-	static constexpr int y2 = y1 + (P >= 3 ? 64 * 6 : 0);  // Y2 tails (P >= 4)
-	static constexpr int y3 = y2 + (P >= 4 ? 64 * 6 : 0);  // Y3 ring, c=4 (P >= 5)
+	static constexpr int atan = 0;                 // 17 doubles
+	static constexpr int raw = atan + 36;          // [65][3]
+	static constexpr int xh = raw + 65 * 3 + 1;    // [8]
+	static constexpr int y0 = xh + 8;              // Y0 tails [65][5]   (P >= 2)
+	static constexpr int y1 = y0 + (P >= 2 ? 65 * 5 : 0);  // Y1 tails (P >= 3)
+	static constexpr int y2 = y1 + (P >= 3 ? 65 * 5 : 0);  // Y2 tails (P >= 4)
+	static constexpr int y3 = y2 + (P >= 4 ? 65 * 5 : 0);  // Y3 ring, c=4 (P >= 5)
 	static constexpr int y4 = y3 + (P >= 5 ? kPre + 64 * 4 : 0);  // Y4 ring, c=2 (P >= 6)
 	static constexpr int fz = y4 + (P >= 6 ? kPre + 64 * 2 : 0);  // FIR input history
 	static constexpr bool fz_slots = cz >= 9;                     // else ring
-	static constexpr int fz_size = !FIR9 ? 0 : (fz_slots ? 64 * 10 : kPre + 64 * cz);
-	static constexpr int zd = fz + fz_size;       // demod input tails [64][2]
-	static constexpr int total = zd + 64 * 2;
+	static constexpr int fz_size = !FIR9 ? 0 : (fz_slots ? 65 * 9 : kPre + 64 * cz);
+	static constexpr int zd = fz + fz_size;        // demod input tails [65]
+	static constexpr int total = zd + 65 + 1;
 };
 
-// lane l publishes `mine`; returns what lane l-1 published (lane 0: what lane 63
-// published during the previous tile).  Wave-private, no barrier: the LDS
-// queue of one wave is in order.
+// Lane l publishes `mine` for lane l+1 and receives lane l-1's; lane 0 receives
+// what lane 63 left in slot 0 during the previous tile (`carry`, stored after the
+// reads).  Wave-private, no barrier: one wave's LDS queue is in order.
 template <int W>
-__device__ __forceinline__ void slot_exchange(uint32_t *slots, const uint32_t (&mine)[W], uint32_t (&prev)[W],
-                                              int lane)
+__device__ __forceinline__ void hand_off(uint32_t *slots, const uint32_t (&mine)[W], uint32_t (&prev)[W], int lane)
 {
-	if (lane < 63) {
 #pragma unroll
-		for (int k = 0; k < W; k++) slots[(lane + 1) * W + k] = mine[k];
-	}
+	for (int k = 0; k < W; k++) slots[(lane + 1) * W + k] = mine[k];
 	__builtin_amdgcn_wave_barrier();
 #pragma unroll
 	for (int k = 0; k < W; k++) prev[k] = slots[lane * W + k];
 	__builtin_amdgcn_wave_barrier();
+}
+template <int W>
+__device__ __forceinline__ void leave_carry(uint32_t *slots, const uint32_t (&carry)[W], int lane)
+{
 	if (lane == 63) {
 #pragma unroll
-		for (int k = 0; k < W; k++) slots[k] = mine[k];
+		for (int k = 0; k < W; k++) slots[k] = carry[k];
 	}
 	__builtin_amdgcn_wave_barrier();
+}
+
+// The five predecessors e[-5..-1] of a lane for one fifth_order pass over an
+// array with C >= 6 values per lane.  `drop_newest_next`: the next tile starts
+// a buffer, whose history is one sample older (the archive of
+// src/rtl_fm.c:800-805 never holds the newest input).
+template <int C>
+__device__ __forceinline__ void fifth_history(uint32_t *slots, const uint32_t (&Y)[C], uint32_t (&h)[5], int lane,
+                                              bool drop_newest_next)
+{
+	uint32_t mine[5] = {Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2], Y[C - 1]};
+	hand_off<5>(slots, mine, h, lane);
+	if (drop_newest_next) {
+		uint32_t carry[5] = {Y[C - 6], Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2]};
+		leave_carry<5>(slots, carry, lane);
+	} else {
+		leave_carry<5>(slots, mine, lane);
+	}
 }
 
 // linear ring: write this tile's C values per lane, read H entries before the
 // lane's first, then move the tile's tail into the prefix for the next tile.
 // QUIRK: at a buffer start the entries that lie before the buffer are read one
-// position further back (the newest sample of the previous buffer was never
-// archived, src/rtl_fm.c:800-805); with fewer than five values per lane that
-// reaches lanes 1 and 2 as well, so it is applied per position, not per lane.
+// position further back (see fifth_history); with fewer than five values per
+// lane that reaches lanes 1 and 2 as well, so it is applied per position.
 template <int C, int H, bool QUIRK>
 __device__ __forceinline__ void ring_exchange(uint32_t *ring, const uint32_t (&mine)[C], uint32_t (&hist)[H],
                                               int lane, bool buffer_start)
@@ -216,21 +247,17 @@ __device__ __forceinline__ void fifth_lane(const uint32_t (&x)[CIN], const uint3
 	}
 }
 
-// choose e[-5..-1] out of the six values t[0..5] = Y[c-6..c-1] of the
-// predecessor: normally the newest five; at a buffer start (lane 0 only) the
-// newest one was never archived (src/rtl_fm.c:800-805)
-__device__ __forceinline__ void quirk_select(const uint32_t (&t)[6], bool drop_newest, uint32_t (&h)[5])
-{
-#pragma unroll
-	for (int k = 0; k < 5; k++) h[k] = drop_newest ? t[k] : t[k + 1];
-}
+struct AtanNodesLds {
+	const double *t;
+	__device__ __forceinline__ double operator()(int i) const { return t[i]; }
+};
 
 template <int P, bool FIR9>
 __global__ void __launch_bounds__(64) k_fused(const Params p)
 {
 	using L = Lds<P, FIR9>;
 	constexpr int CZ = L::cz;
-	__shared__ uint32_t lds[L::total];
+	__shared__ __attribute__((aligned(16))) uint32_t lds[L::total];
 	const int lane = threadIdx.x;
 	const int wave = blockIdx.x;
 	const int seg = wave % p.segs;
@@ -250,9 +277,10 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 	// ---- carried history at the start of the segment ---------------------------
 	for (int k = lane; k < L::total; k += 64) lds[k] = 0;
 	__builtin_amdgcn_wave_barrier();
+	if (lane < 17) reinterpret_cast<double *>(lds + L::atan)[lane] = k_atan_nodes[lane];
 	if (from_state && lane == 0) {
 		for (int j = 0; j < 6; j++) lds[L::xh + j] = pack_iq(sin->lp_i_hist[0][j], sin->lp_q_hist[0][j]);
-		auto put_slots = [&](int off, int pass) {  // t[k] = hist[k+1]
+		auto put_slots = [&](int off, int pass) {  // e[-5..-1] = hist[1..5]
 			for (int k = 0; k < 5; k++) lds[off + k] = pack_iq(sin->lp_i_hist[pass][k + 1], sin->lp_q_hist[pass][k + 1]);
 		};
 		auto put_ring = [&](int off, int pass) {  // A[kPre-7+j] = hist[j]
@@ -266,12 +294,13 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 		if (FIR9) {
 			for (int j = 0; j < 9; j++) {
 				uint32_t v = pack_iq(sin->droop_i_hist[j], sin->droop_q_hist[j]);
-				if (L::fz_slots) lds[L::fz + 1 + j] = v; else lds[L::fz + kPre - 9 + j] = v;
+				if (L::fz_slots) lds[L::fz + j] = v; else lds[L::fz + kPre - 9 + j] = v;
 			}
 		}
-		lds[L::zd + 1] = pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j);
+		lds[L::zd] = pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j);
 	}
 	__builtin_amdgcn_wave_barrier();
+	const AtanNodesLds nodes{reinterpret_cast<const double *>(lds + L::atan)};
 
 	const int gt_first = b0 * tpb;
 	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
@@ -280,7 +309,7 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 	const int out_per_tile = 64 * CZ;
 	int16_t *out_base = p.out + (size_t)s * p.out_stride;
 
-	uint4 cur[8], nxt[8];
+	uint4 cur[8];
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)gt_begin * kTileBytes + lane * 128);
 #pragma unroll
@@ -289,61 +318,61 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		const bool more = gt + 1 < gt_end;
-		if (more) {
-			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)(gt + 1) * kTileBytes + lane * 128);
-#pragma unroll
-			for (int k = 0; k < 8; k++) nxt[k] = src[k];
-		}
 		const int tib = gt % tpb;
-		const bool bs = tib == 0;
-		const bool q0 = bs && lane == 0;  // the one place a buffer boundary shows
+		const bool bs = tib == 0;                       // this tile starts a buffer
+		const bool next_bs = ((gt + 1) % tpb) == 0;     // the next one does
+		const bool q0 = bs && lane == 0;
 		const bool emit = gt >= gt_first;
 		const bool last = gt + 1 == gt_end;
+		const bool archive = last && writes_state && lane == 63;
 
 		// ---------------------------------------------------------------- pass 0 ----
-		uint32_t D[32];
-#pragma unroll
-		for (int k = 0; k < 8; k++) { D[4 * k] = cur[k].x; D[4 * k + 1] = cur[k].y; D[4 * k + 2] = cur[k].z; D[4 * k + 3] = cur[k].w; }
 		uint32_t Y0[32];
 		{
-			uint32_t mine[4] = {D[28], D[29], D[30], D[31]}, prev[4];
-			slot_exchange<4>(lds + L::raw, mine, prev, lane);
-			uint32_t sx[35];
-			sx[0] = prev[1] ^ 0x80808080u; sx[1] = prev[2] ^ 0x80808080u; sx[2] = prev[3] ^ 0x80808080u;
+			uint32_t D[32];
+#pragma unroll
+			for (int k = 0; k < 8; k++) { D[4 * k] = cur[k].x; D[4 * k + 1] = cur[k].y; D[4 * k + 2] = cur[k].z; D[4 * k + 3] = cur[k].w; }
+			uint32_t mine[3] = {D[29], D[30], D[31]}, prev[3];
+			hand_off<3>(lds + L::raw, mine, prev, lane);
+			leave_carry<3>(lds + L::raw, mine, lane);
+			uint32_t sx[35];  // S[-3..31]
+			sx[0] = prev[0] ^ 0x80808080u; sx[1] = prev[1] ^ 0x80808080u; sx[2] = prev[2] ^ 0x80808080u;
 #pragma unroll
 			for (int j = 0; j < 32; j++) sx[3 + j] = D[j] ^ 0x80808080u;
+			uint32_t G[34], H[34];  // G[-2..31]
+#pragma unroll
+			for (int k = 0; k < 34; k++) {
+				G[k] = __builtin_amdgcn_perm(sx[k], sx[k + 1], p.taps.selG);
+				H[k] = __builtin_amdgcn_perm(sx[k], sx[k + 1], p.taps.selH);
+			}
 #pragma unroll
 			for (int m = 0; m < 32; m++) {
 				const int par = m & 1;
 				int ai = p.taps.bi[par], aq = p.taps.bq[par];
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					ai = __builtin_amdgcn_sdot4((int)sx[m + k], p.taps.ti[par][k], ai, false);
-					aq = __builtin_amdgcn_sdot4((int)sx[m + k], p.taps.tq[par][k], aq, false);
-				}
+				ai = __builtin_amdgcn_sdot4((int)G[m + 2], p.taps.ti[par][0], ai, false);
+				ai = __builtin_amdgcn_sdot4((int)G[m], p.taps.ti[par][1], ai, false);
+				aq = __builtin_amdgcn_sdot4((int)H[m + 2], p.taps.tq[par][0], aq, false);
+				aq = __builtin_amdgcn_sdot4((int)H[m], p.taps.tq[par][1], aq, false);
 				uint32_t pk = __builtin_amdgcn_perm((uint32_t)aq, (uint32_t)ai, 0x05040100u);
 				Y0[m] = as_u32(as_s2(pk) >> 4);
 			}
-		}
-		if (bs) {
-			// first three outputs of a buffer: history is the archived x' of the
-			// previous buffer (one sample older, previous buffer's rotation phase)
-			uint32_t e[11];
+			if (bs) {
+				// first three outputs of a buffer: history is the archived x' of the
+				// previous buffer (one sample older, previous buffer's rotation phase)
+				uint32_t e[11];
 #pragma unroll
-			for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
-			unpack_rot(D[0], 0, rotate, e[5], e[6]);
-			unpack_rot(D[1], 1, rotate, e[7], e[8]);
-			unpack_rot(D[2], 0, rotate, e[9], e[10]);
-			uint32_t f0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
-			uint32_t f1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
-			uint32_t f2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
-			if (lane == 0) { Y0[0] = f0; Y0[1] = f1; Y0[2] = f2; }
-		}
-		__builtin_amdgcn_wave_barrier();
-		{
-			// archive x'[N-7..N-2] of this tile (lane 63's samples 57..62)
-			const bool need = (((gt + 1) % tpb) == 0);
-			if (need) {
+				for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
+				unpack_rot(D[0], 0, rotate, e[5], e[6]);
+				unpack_rot(D[1], 1, rotate, e[7], e[8]);
+				unpack_rot(D[2], 0, rotate, e[9], e[10]);
+				uint32_t f0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
+				uint32_t f1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
+				uint32_t f2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
+				if (lane == 0) { Y0[0] = f0; Y0[1] = f1; Y0[2] = f2; }
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (next_bs) {
+				// archive x'[N-7..N-2] of the buffer that ends here (lane 63's samples 57..62)
 				uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
 				unpack_rot(D[28], 0, rotate, a0, a1);
 				unpack_rot(D[29], 1, rotate, a2, a3);
@@ -352,18 +381,25 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 				if (lane == 63) {
 					lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
 					lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
-					if (last && writes_state) {
+					if (archive) {
 						uint32_t v[6] = {a1, a2, a3, a4, a5, a6};
 						for (int j = 0; j < 6; j++) { iq16 w = unpack_iq(v[j]); sout->lp_i_hist[0][j] = w.i; sout->lp_q_hist[0][j] = w.q; }
 					}
 				}
 			}
+			__builtin_amdgcn_wave_barrier();
 		}
-		__builtin_amdgcn_wave_barrier();
+		// the raw tile is consumed: fetch the next one into the same registers
+		if (more) {
+			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)(gt + 1) * kTileBytes + lane * 128);
+#pragma unroll
+			for (int k = 0; k < 8; k++) cur[k] = src[k];
+		}
 
-		// helper: archive hist[pass] = Y[c-7..c-2] of lane 63 from registers
-		auto archive_regs = [&](auto &Y, int c, int pass) {
-			if (last && writes_state && lane == 63) {
+		// hist[pass] = Y[c-7..c-2] of lane 63 (registers) / of the ring's prefix
+		auto archive_regs = [&](auto &Y, auto cc, int pass) {
+			constexpr int c = decltype(cc)::value;
+			if (archive) {
 #pragma unroll
 				for (int j = 0; j < 6; j++) {
 					iq16 w = unpack_iq(Y[c - 7 + j]);
@@ -371,9 +407,8 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 				}
 			}
 		};
-		auto archive_ring = [&](int off, int c, int pass) {
-			if (last && writes_state && lane == 63) {
-				// the tail was already moved into the prefix: A[kPre-7+j]
+		auto archive_ring = [&](int off, int pass) {
+			if (archive) {
 				for (int j = 0; j < 6; j++) {
 					iq16 w = unpack_iq(lds[off + kPre - 7 + j]);
 					sout->lp_i_hist[pass][j] = w.i; sout->lp_q_hist[pass][j] = w.q;
@@ -387,39 +422,30 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 #pragma unroll
 			for (int k = 0; k < 32; k++) Z[k] = Y0[k];
 		} else {
-			uint32_t t6[6], h5[5];
+			uint32_t h5[5];
 			uint32_t Y1[16];
-			{
-				uint32_t mine[6] = {Y0[26], Y0[27], Y0[28], Y0[29], Y0[30], Y0[31]};
-				slot_exchange<6>(lds + L::y0, mine, t6, lane);
-				quirk_select(t6, q0, h5);
-				fifth_lane<32, true>(Y0, h5, Y1);
-				archive_regs(Y0, 32, 1);
-			}
+			fifth_history<32>(lds + L::y0, Y0, h5, lane, next_bs);
+			fifth_lane<32, true>(Y0, h5, Y1);
+			archive_regs(Y0, std::integral_constant<int, 32>(), 1);
 			if constexpr (P == 2) {
 #pragma unroll
 				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
 			} else {
 				uint32_t Y2[8];
-				{
-					uint32_t mine[6] = {Y1[10], Y1[11], Y1[12], Y1[13], Y1[14], Y1[15]};
-					slot_exchange<6>(lds + L::y1, mine, t6, lane);
-					quirk_select(t6, q0, h5);
-					fifth_lane<16, true>(Y1, h5, Y2);
-					archive_regs(Y1, 16, 2);
-				}
+				fifth_history<16>(lds + L::y1, Y1, h5, lane, next_bs);
+				fifth_lane<16, true>(Y1, h5, Y2);
+				archive_regs(Y1, std::integral_constant<int, 16>(), 2);
 				if constexpr (P == 3) {
 #pragma unroll
 					for (int k = 0; k < 8; k++) Z[k] = Y2[k];
 				} else {
 					uint32_t Y3[4];
-					{
-						uint32_t mine[6] = {Y2[2], Y2[3], Y2[4], Y2[5], Y2[6], Y2[7]};
-						slot_exchange<6>(lds + L::y2, mine, t6, lane);
-						quirk_select(t6, q0, h5);
-						fifth_lane<8, false>(Y2, h5, Y3);
-						archive_regs(Y2, 8, 3);
-					}
+					fifth_history<8>(lds + L::y2, Y2, h5, lane, next_bs);
+					// with rotation |x| <= 1023 here, so the 16-bit form cannot overflow;
+					// without it an all-255 input reaches exactly 2^15
+					if (rotate) fifth_lane<8, true>(Y2, h5, Y3);
+					else fifth_lane<8, false>(Y2, h5, Y3);
+					archive_regs(Y2, std::integral_constant<int, 8>(), 3);
 					if constexpr (P == 4) {
 #pragma unroll
 						for (int k = 0; k < 4; k++) Z[k] = Y3[k];
@@ -427,14 +453,14 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 						uint32_t Y4[2];
 						ring_exchange<4, 5, true>(lds + L::y3, Y3, h5, lane, bs);
 						fifth_lane<4, false>(Y3, h5, Y4);
-						archive_ring(L::y3, 4, 4);
+						archive_ring(L::y3, 4);
 						if constexpr (P == 5) {
 							Z[0] = Y4[0]; Z[1] = Y4[1];
 						} else {
 							uint32_t Y5[1];
 							ring_exchange<2, 5, true>(lds + L::y4, Y4, h5, lane, bs);
 							fifth_lane<2, false>(Y4, h5, Y5);
-							archive_ring(L::y4, 2, 5);
+							archive_ring(L::y4, 5);
 							Z[0] = Y5[0];
 						}
 					}
@@ -447,19 +473,18 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 		if constexpr (FIR9) {
 			uint32_t h9[9];
 			if constexpr (L::fz_slots) {
-				uint32_t mine[10], prev[10];
+				uint32_t mine[9];
 #pragma unroll
-				for (int k = 0; k < 10; k++) mine[k] = Z[CZ - 10 + k];
-				slot_exchange<10>(lds + L::fz, mine, prev, lane);
+				for (int k = 0; k < 9; k++) mine[k] = Z[CZ - 9 + k];
+				hand_off<9>(lds + L::fz, mine, h9, lane);
+				leave_carry<9>(lds + L::fz, mine, lane);
+				if (archive) {
 #pragma unroll
-				for (int k = 0; k < 9; k++) h9[k] = prev[1 + k];
-				if (last && writes_state && lane == 63) {
-#pragma unroll
-					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(Z[CZ - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
+					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(mine[j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
 			} else {
 				ring_exchange<CZ, 9, false>(lds + L::fz, Z, h9, lane, false);
-				if (last && writes_state && lane == 63) {
+				if (archive) {
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(lds[L::fz + kPre - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
 			}
@@ -482,10 +507,11 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 		// ------------------------------------------------------------ fm_demod ----
 		uint32_t pv;
 		{
-			uint32_t mine[2] = {0u, V[CZ - 1]}, prev[2];
-			slot_exchange<2>(lds + L::zd, mine, prev, lane);
-			pv = prev[1];
-			if (last && writes_state && lane == 63) {
+			uint32_t mine[1] = {V[CZ - 1]}, prev[1];
+			hand_off<1>(lds + L::zd, mine, prev, lane);
+			leave_carry<1>(lds + L::zd, mine, lane);
+			pv = prev[0];
+			if (archive) {
 				iq16 w = unpack_iq(V[CZ - 1]);
 				sout->pre_r = w.i; sout->pre_j = w.q;
 			}
@@ -493,25 +519,31 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 		int16_t pcm[CZ];
 #pragma unroll
 		for (int n = 0; n < CZ; n++) {
-			iq16 c = unpack_iq(V[n]);
-			iq16 b = unpack_iq(n == 0 ? pv : V[n > 0 ? n - 1 : 0]);
+			const uint32_t c = V[n];
+			const uint32_t b = n == 0 ? pv : V[n > 0 ? n - 1 : 0];
+			// multiply(a, conj(b)) (src/rtl_fm.c:836-840): |values| <= 3*8192 here, so
+			// the int16 negation and the 32-bit dot products are exact
+			const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);                      // (bq, bi)
+			const uint32_t bx = as_u32(as_s2(bsw) * short2_t{(short)-1, (short)1});          // (-bq, bi)
+			const int cr = __builtin_amdgcn_sdot2(as_s2(c), as_s2(b), 0, false);
+			const int cj = __builtin_amdgcn_sdot2(as_s2(c), as_s2(bx), 0, false);
 			int v;
 			if (p.variant == RTLFM_ATAN_STD) {
-				v = disc_std(c.i, c.q, b.i, b.q);
+				v = atan2_q14(cj, cr, nodes);
 			} else {
-				// first output of a buffer is always polar_discriminant (:935-937)
-				const bool first = (n == 0) && q0;
-				if (p.variant == RTLFM_ATAN_FAST) v = disc_fast(c.i, c.q, b.i, b.q);
-				else v = disc_lut(c.i, c.q, b.i, b.q, p.lut);
+				if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
+				else v = lut_atan2_q14(cj, cr, p.lut);
 				if (n == 0 && bs) {
-					int vs = disc_std(c.i, c.q, b.i, b.q);
-					if (first) v = vs;
+					// first output of a buffer is always polar_discriminant (:935-937)
+					int vs = atan2_q14(cj, cr, nodes);
+					if (lane == 0) v = vs;
 				}
 			}
 			pcm[n] = (int16_t)v;
 		}
+		(void)q0;
 		if (emit) {
-			int16_t *dst = out_base + (size_t)(gt - 0) * out_per_tile + lane * CZ;
+			int16_t *dst = out_base + (size_t)gt * out_per_tile + lane * CZ;
 			if constexpr (CZ >= 8) {
 				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
@@ -529,8 +561,6 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 				dst[0] = pcm[0];
 			}
 		}
-#pragma unroll
-		for (int k = 0; k < 8; k++) cur[k] = nxt[k];
 	}
 }
 

@@ -733,6 +733,34 @@ extern "C" int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, 
 	return 0;
 }
 
+__global__ void k_selftest_atan2(const int32_t *yx, int n, int32_t *a, int32_t *b)
+{
+	RTLFM_GRID_STRIDE(i, n) {
+		int y = yx[2 * i], x = yx[2 * i + 1];
+		if (a) a[i] = atan2_q14(y, x, AtanNodesConst());
+		if (b) b[i] = atan2_q14_libm(y, x);
+	}
+}
+
+extern "C" int rtlfm_gpu_selftest_atan2(int device, const int32_t *yx, int n, int32_t *q14, int32_t *q14_libm)
+{
+	if (!yx || n < 1) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	int32_t *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+	HIP_TRY(hipMalloc(&d_in, (size_t)n * 8));
+	HIP_TRY(hipMalloc(&d_a, (size_t)n * 4));
+	HIP_TRY(hipMalloc(&d_b, (size_t)n * 4));
+	HIP_TRY(hipMemcpy(d_in, yx, (size_t)n * 8, hipMemcpyHostToDevice));
+	k_selftest_atan2<<<grid_for((size_t)n), 256>>>(d_in, n, q14 ? d_a : nullptr, q14_libm ? d_b : nullptr);
+	HIP_TRY(hipDeviceSynchronize());
+	if (q14) HIP_TRY(hipMemcpy(q14, d_a, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (q14_libm) HIP_TRY(hipMemcpy(q14_libm, d_b, (size_t)n * 4, hipMemcpyDeviceToHost));
+	hipFree(d_in); hipFree(d_a); hipFree(d_b);
+	return 0;
+}
+
 extern "C" const char *rtlfm_gpu_strerror(int err)
 {
 	switch (err) {

@@ -222,3 +222,32 @@ def test_fused_fullscale_random_bytes(oracle_lib):
         assert used == 2
         for s in range(ns):
             assert np.array_equal(outs[s], want[s, :want_len[s]]), (passes, fir9, s)
+
+
+def test_atan2_q14_against_libm_and_oracle(oracle_lib):
+    """The kernels' 45-instruction atan2->Q14 against the device libm chain and
+    the host (glibc) chain of polar_discriminant, on 6e6 pairs incl. every
+    special case: all must give the same integer."""
+    lib = capi.load()
+    rng = np.random.default_rng(2024)
+    parts = []
+    # products of realistic decimated samples (|z| up to ~8192) and full int32 range
+    for scale in (64, 1024, 1 << 14, 1 << 20, 1 << 26, (1 << 31) - 1):
+        parts.append(rng.integers(-scale, scale + 1, size=(1_000_000, 2), dtype=np.int64))
+    sp = [-(1 << 31) + 1, -(1 << 30), -65536, -2, -1, 0, 1, 2, 3, 65535, 1 << 30, (1 << 31) - 1]
+    parts.append(np.array([(a, b) for a in sp for b in sp], dtype=np.int64))
+    # near node boundaries i/16 +- 1/32 and octant edges
+    base = rng.integers(1, 1 << 20, size=200_000)
+    for num, den in ((1, 32), (3, 32), (15, 32), (31, 32), (1, 1), (33, 32), (2, 1), (32, 1)):
+        y = base * num // den
+        for sy in (1, -1):
+            for sx in (1, -1):
+                parts.append(np.stack([sy * y, sx * base], axis=1))
+                parts.append(np.stack([sy * (y + 1), sx * base], axis=1))
+    yx = np.ascontiguousarray(np.concatenate(parts).astype(np.int32))
+    n = yx.shape[0]
+    a = np.empty(n, dtype=np.int32); b = np.empty(n, dtype=np.int32)
+    assert lib.rtlfm_gpu_selftest_atan2(0, yx.ctypes.data, n, a.ctypes.data, b.ctypes.data) == 0
+    host = np.trunc(np.arctan2(yx[:, 0].astype(np.float64), yx[:, 1].astype(np.float64)) / 3.14159 * 16384.0).astype(np.int32)
+    assert int((a != b).sum()) == 0, f"atan2_q14 vs device libm: {(a != b).sum()} of {n} differ"
+    assert int((a != host).sum()) == 0, f"atan2_q14 vs glibc chain: {(a != host).sum()} of {n} differ"
