@@ -28,11 +28,11 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> None:
-    """Compile the checker (and oracle/_ref when /root/reference exists)."""
-    if force or not (os.path.exists(ORACLE_SO) and os.path.exists(LOADER_SO)):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
-    else:
-        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    """Compile the checker (and oracle/_ref when /root/reference exists).
+    Everything make prints goes to stderr: bench.py's stdout is one JSON line."""
+    import sys
+    cmd = ["make", "-C", _HERE, "-s", "all"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=sys.stderr, stderr=sys.stderr)
 
 
 _oracle = None

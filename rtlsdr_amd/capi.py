@@ -166,7 +166,7 @@ def load(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RTLFM_HIP_LIB") or LIB_PATH  # env override: A/B builds
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

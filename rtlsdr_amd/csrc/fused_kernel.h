@@ -53,6 +53,12 @@ constexpr int kTileBytes = 2 * kTileSamples;     // 8192
 constexpr int kPre = 16;                         // prefix entries of a linear ring
 constexpr int kMaxP = 6;
 
+#ifdef RTLFM_FUSED_MARKS  // analysis builds only: section markers in the .s
+#define RTLFM_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RTLFM_MARK(name) do { } while (0)
+#endif
+
 typedef short short2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ short2_t as_s2(uint32_t v) { return __builtin_bit_cast(short2_t, v); }
@@ -78,11 +84,13 @@ __device__ __forceinline__ uint32_t tap_i32(uint32_t a, uint32_t b, uint32_t c, 
 	return pack_iq((int16_t)yi, (int16_t)yq);
 }
 
-// Pass 0 constants.  S_j = raw dword j (I_2j, Q_2j, I_2j+1, Q_2j+1) XOR 0x80808080
-// (bytes become u-128, so x-127 = s+1 and the tap sum goes into the bias).
+// Pass 0 constants.  S_j = raw dword j (I_2j, Q_2j, I_2j+1, Q_2j+1) XOR 0x7f7f7f7f:
+// as int8 every byte is then exactly -(u - 127), the NEGATED converted sample
+// of src/rtl_fm.c:1326-1328 (u = 0 -> +127, u = 255 -> -128), so the taps below
+// are the negated filter taps and no bias term is left.
 //   G_j = perm(S_j-1, S_j, selG), H_j = perm(S_j-1, S_j, selH)
-//   I'[m] = bias_i + dot4(G_m, ti[par][0]) + dot4(G_m-2, ti[par][1])      (par = m & 1)
-//   Q'[m] = bias_q + dot4(H_m, tq[par][0]) + dot4(H_m-2, tq[par][1])
+//   I'[m] = dot4(G_m, ti[par][0]) + dot4(G_m-2, ti[par][1])      (par = m & 1)
+//   Q'[m] = dot4(H_m, tq[par][0]) + dot4(H_m-2, tq[par][1])
 // With rotation, sample n of a buffer is multiplied by (-j)^n:
 //   I'(n) = +I,+Q,-I,-Q and Q'(n) = +Q,-I,-Q,+I for n%4 = 0..3,
 // so G gathers (I_2j, Q_2j+1) and H gathers (Q_2j, I_2j+1) and the signs sit in
@@ -90,7 +98,6 @@ __device__ __forceinline__ uint32_t tap_i32(uint32_t a, uint32_t b, uint32_t c, 
 struct Pass0Taps {
 	uint32_t selG, selH;
 	int32_t ti[2][2], tq[2][2];
-	int32_t bi[2], bq[2];
 };
 
 inline Pass0Taps make_taps(bool rotate)
@@ -98,20 +105,36 @@ inline Pass0Taps make_taps(bool rotate)
 	Pass0Taps t{};
 	if (rotate) {
 		t.selG = 0x07040300u; t.selH = 0x06050201u;
-		t.ti[0][0] = (int32_t)0xFBF60001; t.ti[0][1] = (int32_t)0xFF000A05;  // (1,0,-10,-5) (5,10,0,-1)
-		t.ti[1][0] = 0x050A00FF; t.ti[1][1] = 0x0100F6FB;                    // negated
-		t.tq[0][0] = 0x05F60001; t.tq[0][1] = 0x0100F605;                    // (1,0,-10,5) (5,-10,0,1)
-		t.tq[1][0] = (int32_t)0xFB0A00FF; t.tq[1][1] = (int32_t)0xFF000AFB;  // negated
-		t.bi[0] = 0; t.bi[1] = 0; t.bq[0] = -8; t.bq[1] = 8;
+		// filter taps for even m: I (1,0,-10,-5) (5,10,0,-1); Q (1,0,-10,5) (5,-10,0,1);
+		// odd m: the negatives.  Stored negated (see above).
+		t.ti[0][0] = 0x050A00FF; t.ti[0][1] = 0x0100F6FB;
+		t.ti[1][0] = (int32_t)0xFBF60001; t.ti[1][1] = (int32_t)0xFF000A05;
+		t.tq[0][0] = (int32_t)0xFB0A00FF; t.tq[0][1] = (int32_t)0xFF000AFB;
+		t.tq[1][0] = 0x05F60001; t.tq[1][1] = 0x0100F605;
 	} else {
 		t.selG = 0x06040200u; t.selH = 0x07050301u;
 		for (int p = 0; p < 2; p++) {
-			t.ti[p][0] = 0x050A0001; t.ti[p][1] = 0x01000A05;  // (1,0,10,5) (5,10,0,1)
-			t.tq[p][0] = 0x050A0001; t.tq[p][1] = 0x01000A05;
-			t.bi[p] = 32; t.bq[p] = 32;
+			// filter taps (1,0,10,5) (5,10,0,1), negated
+			t.ti[p][0] = (int32_t)0xFBF600FF; t.ti[p][1] = (int32_t)0xFF00F6FB;
+			t.tq[p][0] = (int32_t)0xFBF600FF; t.tq[p][1] = (int32_t)0xFF00F6FB;
 		}
 	}
 	return t;
+}
+
+// dot4 / dot2 with a zero accumulator in the VOP3 form (inline constant 0):
+// hipcc otherwise emits v_mov 0 + the accumulate-in-place VOP2 form.
+__device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
+{
+	int r;
+	asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(taps));
+	return r;
+}
+__device__ __forceinline__ int dot2_first(uint32_t a, uint32_t b)
+{
+	int r;
+	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+	return r;
 }
 
 struct Params {
@@ -126,6 +149,8 @@ struct Params {
 	const int32_t *lut;
 	int variant, rotate;
 	int segs, blocks_per_seg;
+	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 1 = do not reload tiles, 2 = clock stamps
+	unsigned long long *stamps;  // [waves][4] when debug & 2
 	Pass0Taps taps;
 };
 
@@ -252,8 +277,17 @@ struct AtanNodesLds {
 	__device__ __forceinline__ double operator()(int i) const { return t[i]; }
 };
 
-template <int P, bool FIR9>
-__global__ void __launch_bounds__(64) k_fused(const Params p)
+#ifndef RTLFM_FUSED_WAVES_PER_SIMD
+#define RTLFM_FUSED_WAVES_PER_SIMD 4
+#endif
+#ifndef RTLFM_FUSED_EARLY_RELOAD
+#define RTLFM_FUSED_EARLY_RELOAD 0
+#endif
+// STD: the discriminator is known to be polar_discriminant at compile time (the
+// common case and the one the roofline is quoted on); otherwise p.variant picks
+// fast / lut at run time.
+template <int P, bool FIR9, bool STD>
+__global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const Params p)
 {
 	using L = Lds<P, FIR9>;
 	constexpr int CZ = L::cz;
@@ -274,6 +308,8 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 	state_t *sout = p.sout + s;
 	const int rotate = p.rotate;
 
+	unsigned long long st_clk = 0, st_rt = 0;
+	if (p.debug & 2) { st_clk = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
 	// ---- carried history at the start of the segment ---------------------------
 	for (int k = lane; k < L::total; k += 64) lds[k] = 0;
 	__builtin_amdgcn_wave_barrier();
@@ -326,19 +362,31 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 		const bool last = gt + 1 == gt_end;
 		const bool archive = last && writes_state && lane == 63;
 
+		RTLFM_MARK("tile_begin");
 		// ---------------------------------------------------------------- pass 0 ----
 		uint32_t Y0[32];
 		{
-			uint32_t D[32];
-#pragma unroll
-			for (int k = 0; k < 8; k++) { D[4 * k] = cur[k].x; D[4 * k + 1] = cur[k].y; D[4 * k + 2] = cur[k].z; D[4 * k + 3] = cur[k].w; }
-			uint32_t mine[3] = {D[29], D[30], D[31]}, prev[3];
-			hand_off<3>(lds + L::raw, mine, prev, lane);
-			leave_carry<3>(lds + L::raw, mine, lane);
+			// S = raw ^ 0x80808080 is the only form of the tile the math needs, so the
+			// raw registers are free again after 35 XORs: the next tile's loads go out
+			// here and have the whole tile's arithmetic to land.
 			uint32_t sx[35];  // S[-3..31]
-			sx[0] = prev[0] ^ 0x80808080u; sx[1] = prev[1] ^ 0x80808080u; sx[2] = prev[2] ^ 0x80808080u;
+			{
+				uint32_t mine[3] = {cur[7].y, cur[7].z, cur[7].w}, prev[3];
+				hand_off<3>(lds + L::raw, mine, prev, lane);
+				leave_carry<3>(lds + L::raw, mine, lane);
+				sx[0] = prev[0] ^ 0x7f7f7f7fu; sx[1] = prev[1] ^ 0x7f7f7f7fu; sx[2] = prev[2] ^ 0x7f7f7f7fu;
+			}
 #pragma unroll
-			for (int j = 0; j < 32; j++) sx[3 + j] = D[j] ^ 0x80808080u;
+			for (int k = 0; k < 8; k++) {
+				sx[3 + 4 * k] = cur[k].x ^ 0x7f7f7f7fu; sx[4 + 4 * k] = cur[k].y ^ 0x7f7f7f7fu;
+				sx[5 + 4 * k] = cur[k].z ^ 0x7f7f7f7fu; sx[6 + 4 * k] = cur[k].w ^ 0x7f7f7f7fu;
+			}
+			if (RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) {
+				const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes + lane * 128);
+#pragma unroll
+				for (int k = 0; k < 8; k++) cur[k] = src[k];
+			}
+			RTLFM_MARK("xor_done");
 			uint32_t G[34], H[34];  // G[-2..31]
 #pragma unroll
 			for (int k = 0; k < 34; k++) {
@@ -348,23 +396,23 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 #pragma unroll
 			for (int m = 0; m < 32; m++) {
 				const int par = m & 1;
-				int ai = p.taps.bi[par], aq = p.taps.bq[par];
-				ai = __builtin_amdgcn_sdot4((int)G[m + 2], p.taps.ti[par][0], ai, false);
+				int ai = dot4_first(G[m + 2], p.taps.ti[par][0]);
 				ai = __builtin_amdgcn_sdot4((int)G[m], p.taps.ti[par][1], ai, false);
-				aq = __builtin_amdgcn_sdot4((int)H[m + 2], p.taps.tq[par][0], aq, false);
+				int aq = dot4_first(H[m + 2], p.taps.tq[par][0]);
 				aq = __builtin_amdgcn_sdot4((int)H[m], p.taps.tq[par][1], aq, false);
 				uint32_t pk = __builtin_amdgcn_perm((uint32_t)aq, (uint32_t)ai, 0x05040100u);
 				Y0[m] = as_u32(as_s2(pk) >> 4);
 			}
+			RTLFM_MARK("pass0_done");
 			if (bs) {
 				// first three outputs of a buffer: history is the archived x' of the
 				// previous buffer (one sample older, previous buffer's rotation phase)
 				uint32_t e[11];
 #pragma unroll
 				for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
-				unpack_rot(D[0], 0, rotate, e[5], e[6]);
-				unpack_rot(D[1], 1, rotate, e[7], e[8]);
-				unpack_rot(D[2], 0, rotate, e[9], e[10]);
+				unpack_rot(sx[3] ^ 0x7f7f7f7fu, 0, rotate, e[5], e[6]);
+				unpack_rot(sx[4] ^ 0x7f7f7f7fu, 1, rotate, e[7], e[8]);
+				unpack_rot(sx[5] ^ 0x7f7f7f7fu, 0, rotate, e[9], e[10]);
 				uint32_t f0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
 				uint32_t f1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
 				uint32_t f2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
@@ -374,10 +422,10 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			if (next_bs) {
 				// archive x'[N-7..N-2] of the buffer that ends here (lane 63's samples 57..62)
 				uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
-				unpack_rot(D[28], 0, rotate, a0, a1);
-				unpack_rot(D[29], 1, rotate, a2, a3);
-				unpack_rot(D[30], 0, rotate, a4, a5);
-				unpack_rot(D[31], 1, rotate, a6, a7);
+				unpack_rot(sx[31] ^ 0x7f7f7f7fu, 0, rotate, a0, a1);
+				unpack_rot(sx[32] ^ 0x7f7f7f7fu, 1, rotate, a2, a3);
+				unpack_rot(sx[33] ^ 0x7f7f7f7fu, 0, rotate, a4, a5);
+				unpack_rot(sx[34] ^ 0x7f7f7f7fu, 1, rotate, a6, a7);
 				if (lane == 63) {
 					lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
 					lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
@@ -389,13 +437,12 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
-		// the raw tile is consumed: fetch the next one into the same registers
-		if (more) {
-			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)(gt + 1) * kTileBytes + lane * 128);
+
+		if (!RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) {
+			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes + lane * 128);
 #pragma unroll
 			for (int k = 0; k < 8; k++) cur[k] = src[k];
 		}
-
 		// hist[pass] = Y[c-7..c-2] of lane 63 (registers) / of the ring's prefix
 		auto archive_regs = [&](auto &Y, auto cc, int pass) {
 			constexpr int c = decltype(cc)::value;
@@ -416,6 +463,7 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			}
 		};
 
+		RTLFM_MARK("pass0_special_done");
 		// ------------------------------------------------------------ passes 1.. ----
 		uint32_t Z[CZ];  // output of the last pass
 		if constexpr (P == 1) {
@@ -468,6 +516,7 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			}
 		}
 
+		RTLFM_MARK("passes_done");
 		// --------------------------------------------------------- generic_fir ----
 		uint32_t V[CZ];  // what fm_demod sees
 		if constexpr (FIR9) {
@@ -504,6 +553,7 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			for (int k = 0; k < CZ; k++) V[k] = Z[k];
 		}
 
+		RTLFM_MARK("fir_done");
 		// ------------------------------------------------------------ fm_demod ----
 		uint32_t pv;
 		{
@@ -525,10 +575,10 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			// the int16 negation and the 32-bit dot products are exact
 			const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);                      // (bq, bi)
 			const uint32_t bx = as_u32(as_s2(bsw) * short2_t{(short)-1, (short)1});          // (-bq, bi)
-			const int cr = __builtin_amdgcn_sdot2(as_s2(c), as_s2(b), 0, false);
-			const int cj = __builtin_amdgcn_sdot2(as_s2(c), as_s2(bx), 0, false);
+			const int cr = dot2_first(c, b);
+			const int cj = dot2_first(c, bx);
 			int v;
-			if (p.variant == RTLFM_ATAN_STD) {
+			if (STD) {
 				v = atan2_q14(cj, cr, nodes);
 			} else {
 				if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
@@ -542,6 +592,7 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			pcm[n] = (int16_t)v;
 		}
 		(void)q0;
+		RTLFM_MARK("demod_done");
 		if (emit) {
 			int16_t *dst = out_base + (size_t)gt * out_per_tile + lane * CZ;
 			if constexpr (CZ >= 8) {
@@ -562,10 +613,17 @@ __global__ void __launch_bounds__(64) k_fused(const Params p)
 			}
 		}
 	}
+	if ((p.debug & 2) && lane == 0) {
+		unsigned long long e_clk = __builtin_amdgcn_s_memtime(), e_rt = __builtin_amdgcn_s_memrealtime();
+		p.stamps[(size_t)wave * 4 + 0] = st_clk; p.stamps[(size_t)wave * 4 + 1] = e_clk;
+		p.stamps[(size_t)wave * 4 + 2] = st_rt; p.stamps[(size_t)wave * 4 + 3] = e_rt;
+	}
 }
 
 struct Workspace {
-	void release() {}
+	unsigned long long *stamps = nullptr;
+	int stamp_waves = 0;
+	void release() { if (stamps) hipFree(stamps); stamps = nullptr; }
 };
 
 inline bool supported(const rtlfm_cfg &c, int nblocks)
@@ -581,11 +639,14 @@ inline bool supported(const rtlfm_cfg &c, int nblocks)
 template <int P, bool FIR9>
 static int launch_one(const Params &p, int waves, hipStream_t q)
 {
-	hipLaunchKernelGGL((k_fused<P, FIR9>), dim3(waves), dim3(64), 0, q, p);
+	if (p.variant == RTLFM_ATAN_STD)
+		hipLaunchKernelGGL((k_fused<P, FIR9, true>), dim3(waves), dim3(64), 0, q, p);
+	else
+		hipLaunchKernelGGL((k_fused<P, FIR9, false>), dim3(waves), dim3(64), 0, q, p);
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 
-inline int launch(Workspace &, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
+inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, const state_t *sin, state_t *sout,
                   const int32_t *lut, hipStream_t q)
 {
@@ -598,7 +659,9 @@ inline int launch(Workspace &, const rtlfm_cfg &c, int nstreams, const uint8_t *
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.taps = make_taps(p.rotate != 0);
 	// enough waves to fill 256 CUs several times over; a segment is a run of whole buffers
-	const int target_waves = 8192;
+	if (const char *e = getenv("RTLFM_FUSED_DEBUG")) p.debug = atoi(e);
+	int target_waves = 8192;
+	if (const char *e = getenv("RTLFM_FUSED_WAVES")) target_waves = atoi(e);
 	int segs = (target_waves + nstreams - 1) / nstreams;
 	if (segs > nblocks) segs = nblocks;
 	if (segs < 1) segs = 1;
@@ -606,6 +669,10 @@ inline int launch(Workspace &, const rtlfm_cfg &c, int nstreams, const uint8_t *
 	segs = (nblocks + bps - 1) / bps;
 	p.segs = segs; p.blocks_per_seg = bps;
 	const int waves = nstreams * segs;
+	if (p.debug & 2) {
+		if (ws.stamp_waves < waves) { ws.release(); if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
+		p.stamps = ws.stamps;
+	}
 	const bool fir = c.comp_fir_size == 9;
 	switch (c.downsample_passes * 2 + (fir ? 1 : 0)) {
 	case 2: return launch_one<1, false>(p, waves, q);

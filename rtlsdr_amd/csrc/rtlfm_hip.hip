@@ -622,6 +622,20 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
+	if (h->fws.stamps && getenv("RTLFM_FUSED_DEBUG") && (atoi(getenv("RTLFM_FUSED_DEBUG")) & 2)) {
+		// diagnostic: shader clock held during the launch (s_memtime vs the 100 MHz s_memrealtime)
+		HIP_TRY(hipStreamSynchronize(q));
+		std::vector<unsigned long long> st((size_t)h->fws.stamp_waves * 4);
+		HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+		double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+		for (int w = 0; w < h->fws.stamp_waves; w++) {
+			double dc = (double)(st[w * 4 + 1] - st[w * 4]), dr = (double)(st[w * 4 + 3] - st[w * 4 + 2]);
+			if (dr > 0) { sum += dc / dr * 100.0; n++; }
+			if (st[w * 4 + 2] < t0) t0 = st[w * 4 + 2];
+			if (st[w * 4 + 3] > t1) t1 = st[w * 4 + 3];
+		}
+		fprintf(stderr, "rtlfm_hip[debug]: mean shader clock %.0f MHz over %d waves, kernel span %.3f ms\n", sum / n, n, (t1 - t0) / 1e5);
+	}
 	const int T = nblocks * (int)((c.block_len / 2) >> c.downsample_passes);
 	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
 }
