@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=64, help="callback buffers per stream per step")
     ap.add_argument("--block-len", type=int, default=262144)
@@ -49,34 +49,76 @@ def parse():
 
 
 def cpu_baseline(cfg, iq_host_sample, seconds):
-    """The oracle (a scalar C port pinned bit-exact to the reference) on the host
-    cores, bounded to roughly `seconds` of wall time."""
-    import numpy as np
+    """CPU baseline on the GPU box's host cores, bounded to roughly `seconds`.
+
+    kind "reference": the reference's own rtlsdr_callback() + full_demod(), compiled
+    in place from /root/reference into oracle/_ref/libref_rtlfm.so (prebuilt file
+    travels with the repo snapshot); one private copy of the library per thread
+    because the reference keeps a single stream in globals.
+    kind "port": the oracle's C restatement (pinned bit-exact to the reference),
+    pthreads over streams — used when oracle/_ref is absent.
+    """
+    import ctypes as C
 
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
     ns, nbytes = iq_host_sample.shape
     L = int(cfg.block_len)
     nb = nbytes // L
-    # calibrate on one block per stream
+    threads = min(cores, ns)
+    if po.have_reference():
+        ld = C.CDLL(po.LOADER_SO)
+        ld.ref_bench_mt.restype = C.c_double
+        ld.ref_bench_mt.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                    C.c_int, C.c_int, C.c_int]
+
+        def run(nt, reps):
+            return ld.ref_bench_mt(po.REF_FM_SO.encode(), C.byref(cfg), iq_host_sample.ctypes.data,
+                                   iq_host_sample.strides[0], L, nb, nt, reps)
+        t1 = run(1, 2)  # one thread, for the per-core figure
+        tc = run(threads, 1)
+        if t1 > 0 and tc > 0:
+            reps = max(1, int(seconds / tc))
+            dt = run(threads, reps)
+            if dt > 0:
+                samples = reps * threads * nb * (L // 2)
+                return {
+                    "value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "cores": threads,
+                    "kind": "reference",
+                    "sample": f"reference rtl_fm.c (gcc -O3) rtlsdr_callback+full_demod: {threads} threads x 1 stream "
+                              f"x {nb} buffers x {L} B x {reps} reps ({samples / 1e6:.0f} Msamples in {dt:.1f} s); "
+                              f"one thread alone: {2 * nb * (L // 2) / t1 / 1e6:.1f} Msamples/s",
+                }
+    # fallback: the port
     t0 = time.perf_counter()
-    po.run_batch(cfg, iq_host_sample[:, :L].copy(), nthreads=cores)
+    po.run_batch(cfg, iq_host_sample[:, :L].copy(), nthreads=threads)
     t_one = max(time.perf_counter() - t0, 1e-4)
     reps = max(1, int(seconds / (t_one * nb)))
     t0 = time.perf_counter()
     states = None
     for _ in range(reps):
-        _, _, states = po.run_batch(cfg, iq_host_sample, states=states, nthreads=cores)
+        _, _, states = po.run_batch(cfg, iq_host_sample, states=states, nthreads=threads)
     dt = time.perf_counter() - t0
     samples = reps * ns * nb * (L // 2)
     return {
-        "value": round(samples / dt / 1e6, 2),
-        "unit": "Msamples/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{ns} streams x {nb} buffers x {L} B x {reps} reps of the same workload "
-                  f"({samples / 1e6:.0f} Msamples, {dt:.1f} s, {cores} pthreads)",
+        "value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"oracle port: {ns} streams x {nb} buffers x {L} B x {reps} reps "
+                  f"({samples / 1e6:.0f} Msamples, {dt:.1f} s, {threads} pthreads)",
     }
+
+
+def measured_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (profiles/pmc_latest.json: FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950, + WRITE_SIZE), when they were taken on this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)
+        if d.get("workload_key") == workload_key:
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -200,14 +242,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": None,
+                "traffic": measured_traffic(f"S{S}_NB{NB}_L{L}_P{a.passes}_F{a.fir9}_{a.atan}"),
                 "kernel": "decimating front end (convert+rotate+fifth_order[+fir9+discriminant])",
                 "launch_ms": round(launch_ms, 4),
                 "algorithmic_bytes_per_sample": alg_bytes_per_sample,
             },
         }
         if not a.no_cpu_baseline and world == 1:
-            cs = min(S, 4 * (os.cpu_count() or 1))
+            cs = min(S, os.cpu_count() or 1)
             sample = iq[:cs, :min(NB, 2) * L].contiguous().cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(cfg, sample, a.cpu_seconds)
         else:
