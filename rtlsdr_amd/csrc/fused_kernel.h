@@ -352,6 +352,34 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 		for (int k = 0; k < 8; k++) cur[k] = src[k];
 	}
 
+	// The PCM of tile t is stored just before tile t+2's loads are issued, never
+	// after them: loads and stores share the in-order vmcnt counter on gfx9-family
+	// parts, so a store younger than the loads would put the whole HBM write latency
+	// into the wait that precedes pass 0 of the next tile.
+	int16_t held[CZ];
+	int16_t *held_dst = nullptr;
+	auto flush_held = [&]() {
+		if (held_dst) {
+			int16_t *dst = held_dst;
+			if constexpr (CZ >= 8) {
+				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+				for (int k = 0; k < CZ / 8; k++) {
+					uint4 w;
+					w.x = pack_iq(held[8 * k], held[8 * k + 1]); w.y = pack_iq(held[8 * k + 2], held[8 * k + 3]);
+					w.z = pack_iq(held[8 * k + 4], held[8 * k + 5]); w.w = pack_iq(held[8 * k + 6], held[8 * k + 7]);
+					d4[k] = w;
+				}
+			} else if constexpr (CZ == 4) {
+				*reinterpret_cast<uint2 *>(dst) = make_uint2(pack_iq(held[0], held[1]), pack_iq(held[2], held[3]));
+			} else if constexpr (CZ == 2) {
+				*reinterpret_cast<uint32_t *>(dst) = pack_iq(held[0], held[1]);
+			} else {
+				dst[0] = held[0];
+			}
+		}
+	};
+
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		const bool more = gt + 1 < gt_end;
 		const int tib = gt % tpb;
@@ -438,6 +466,8 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 			__builtin_amdgcn_wave_barrier();
 		}
 
+		flush_held();
+		held_dst = nullptr;
 		if (!RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) {
 			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes + lane * 128);
 #pragma unroll
@@ -594,25 +624,12 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 		(void)q0;
 		RTLFM_MARK("demod_done");
 		if (emit) {
-			int16_t *dst = out_base + (size_t)gt * out_per_tile + lane * CZ;
-			if constexpr (CZ >= 8) {
-				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+			held_dst = out_base + (size_t)gt * out_per_tile + lane * CZ;
 #pragma unroll
-				for (int k = 0; k < CZ / 8; k++) {
-					uint4 w;
-					w.x = pack_iq(pcm[8 * k], pcm[8 * k + 1]); w.y = pack_iq(pcm[8 * k + 2], pcm[8 * k + 3]);
-					w.z = pack_iq(pcm[8 * k + 4], pcm[8 * k + 5]); w.w = pack_iq(pcm[8 * k + 6], pcm[8 * k + 7]);
-					d4[k] = w;
-				}
-			} else if constexpr (CZ == 4) {
-				*reinterpret_cast<uint2 *>(dst) = make_uint2(pack_iq(pcm[0], pcm[1]), pack_iq(pcm[2], pcm[3]));
-			} else if constexpr (CZ == 2) {
-				*reinterpret_cast<uint32_t *>(dst) = pack_iq(pcm[0], pcm[1]);
-			} else {
-				dst[0] = pcm[0];
-			}
+			for (int k = 0; k < CZ; k++) held[k] = pcm[k];
 		}
 	}
+	flush_held();
 	if ((p.debug & 2) && lane == 0) {
 		unsigned long long e_clk = __builtin_amdgcn_s_memtime(), e_rt = __builtin_amdgcn_s_memrealtime();
 		p.stamps[(size_t)wave * 4 + 0] = st_clk; p.stamps[(size_t)wave * 4 + 1] = e_clk;
