@@ -1,0 +1,110 @@
+"""Parity at BASELINE.json's full sizes, through size-independent properties:
+the oracle cannot process gigabytes in a test, so at full size the fused
+kernel is compared with (a) the staged kernels on every sample, (b) the oracle
+on a sample of streams end to end (all buffers, so carried state is exercised
+through the whole run), (c) itself under run splitting and stream permutation."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from cases import make_cfg
+from rtlsdr_amd import synth
+from rtlsdr_amd.capi import RESAMPLE_ARBITRARY, RtlfmCfg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _run(cfg, iq, path, splits=None):
+    from rtlsdr_amd.demod import GpuDemod
+    ns = iq.shape[0]
+    L = int(cfg.block_len)
+    nb = iq.shape[1] // L
+    outs, lens = [], []
+    with GpuDemod(cfg, ns, 0) as g:
+        g.set_path(path)
+        for (b0, b1) in (splits or [(0, nb)]):
+            o, n = g.run_torch(iq[:, b0 * L:b1 * L] if (b0, b1) != (0, nb) else iq)
+            g.sync()
+            outs.append(o); lens.append(n)
+        states = {s: g.state_get(s) for s in (0, ns // 2, ns - 1)}
+        used = g.last_path
+    return outs, lens, states, used
+
+
+def _concat(outs, lens):
+    n0 = [int(l[0]) for l in lens]
+    return torch.cat([o[:, :n] for o, n in zip(outs, n0)], dim=1)
+
+
+def test_c2_full_size_256_streams(oracle_lib):
+    """configs[1]: 256 streams x 64 buffers x 262144 B, 4 passes + polar_discriminant (4 GiB of IQ)."""
+    S, NB, L = 256, 64, 262144
+    cfg = RtlfmCfg.default(downsample=16, downsample_passes=4, rate_out=150000, block_len=L, max_blocks=NB)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0))
+    fo, fl, fst, used = _run(cfg, iq, 2)
+    assert used == 2
+    so, sl, sst, used1 = _run(cfg, iq, 1)
+    assert used1 == 1
+    n = int(fl[0][0])
+    assert n == NB * (L // 2 // 16) and torch.equal(fl[0], sl[0])
+    assert torch.equal(fo[0][:, :n], so[0][:, :n]), "fused != staged at full size"
+    del so
+    # oracle end to end on sampled streams (all 64 buffers => carried state through the run)
+    for s in (0, 101, 255):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        got = fo[0][s, :n].cpu().numpy()
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()), int((d != 0).sum()))
+        if s in fst:
+            assert gu.state_dict(fst[s], False) == gu.state_dict(st, False)
+    # splitting the run leaves every sample and the state unchanged
+    po_, pl_, pst, _ = _run(cfg, iq, 2, splits=[(0, 16), (16, 17), (17, 64)])
+    assert torch.equal(_concat(po_, pl_), fo[0][:, :n])
+    for s in fst:
+        assert gu.state_dict(pst[s], False) == gu.state_dict(fst[s], False)
+    # streams are independent: permuting them permutes the output
+    perm = torch.randperm(S, device=iq.device)
+    qo, ql, _, _ = _run(cfg, iq[perm].contiguous(), 2)
+    assert torch.equal(qo[0][:, :n], fo[0][perm, :n])
+
+
+def test_c3_full_size_4096_nbfm_streams(oracle_lib):
+    """configs[2] / one GPU's share of configs[4]: 4096 NBFM streams at 1.024 MS/s, /64 + FIR9 +
+    deemph + arbitrary_resample 16k -> 22.05k, one 262144-B buffer each (1 GiB), two launches."""
+    S, NB, L = 4096, 2, 262144
+    cfg = RtlfmCfg.default(downsample=64, downsample_passes=6, comp_fir_size=9, deemph=1, deemph_a=2,
+                           rate_out=16000, rate_out2=22050, resampler=RESAMPLE_ARBITRARY,
+                           block_len=L, max_blocks=1)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0), fs=1.024e6, dev_hz=2.5e3)
+    fo, fl, fst, used = _run(cfg, iq, 2, splits=[(0, 1), (1, 2)])
+    assert used == 2
+    so, sl, sst, _ = _run(cfg, iq, 1, splits=[(0, 1), (1, 2)])
+    per = 2048 * 22050 // 16000
+    assert int(fl[0][0]) == per == 2822
+    f = _concat(fo, fl); s_ = _concat(so, sl)
+    assert torch.equal(f, s_), "fused+tail != staged at full size"
+    for s in (0, 1, 2047, 4095):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        got = f[s].cpu().numpy()
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()))
+    for s in fst:
+        assert gu.state_dict(fst[s], False) == gu.state_dict(sst[s], False)
+
+
+def test_default_buffer_size_many_buffers(oracle_lib):
+    """rtl_fm's default 16384-B buffers (every 2nd tile starts a buffer): 64 streams x 512 buffers."""
+    S, NB, L = 64, 512, 16384
+    cfg = RtlfmCfg.default(downsample=16, downsample_passes=4, comp_fir_size=9, rate_out=150000,
+                           block_len=L, max_blocks=NB)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0))
+    fo, fl, fst, used = _run(cfg, iq, 2)
+    so, sl, _, _ = _run(cfg, iq, 1)
+    n = int(fl[0][0])
+    assert used == 2 and torch.equal(fo[0][:, :n], so[0][:, :n])
+    want, st = oracle_lib.run_stream(cfg, iq[S - 1].cpu().numpy())
+    got = fo[0][S - 1, :n].cpu().numpy()
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-4
+    assert gu.state_dict(fst[S - 1], False) == gu.state_dict(st, False)
