@@ -1,0 +1,86 @@
+/*
+ * rtlpower_hip.h — C ABI of the MI355X (gfx950) form of rtl_power's FFT loop.
+ *
+ * Replaces the body of scanner() (reference src/rtl_power.c:642-720) from the
+ * u8 -> int16 conversion after rtlsdr_read_sync() (:657, :666-668) to the
+ * accumulation into tuning_state.avg[] / .samples (:708-717):
+ *
+ *   rms_power()            src/rtl_power.c:410-436   (bin_e == 0)
+ *   u8 -> int16 (-127)     src/rtl_power.c:666-668
+ *   boxcar | downsample_iq src/rtl_power.c:671-681 | 628-634 (fifth_order :554-579)
+ *   generic_fir            src/rtl_power.c:598-626
+ *   remove_dc              src/rtl_power.c:581-596
+ *   window multiply        src/rtl_power.c:697-706 (window_coefs :983-988, windows :329-408)
+ *   fix_fft                src/rtl_power.c:271-327 (sine_table :247-261, FIX_MPY :263-269)
+ *   integrate / peak hold  src/rtl_power.c:708-716
+ *
+ * One "stream" here is one tuning_state (one hop of the frequency plan, or
+ * one dongle); a "read" is one rtlsdr_read_sync() buffer of buf_len bytes.
+ * Same conventions as rtlfm_hip.h: int return, 0 or negative errno.
+ */
+#ifndef RTLPOWER_HIP_H
+#define RTLPOWER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* -w option, src/rtl_power.c:843-862 */
+enum rtlpower_window {
+	RTLPOWER_WIN_RECTANGLE = 0,
+	RTLPOWER_WIN_HAMMING = 1,
+	RTLPOWER_WIN_BLACKMAN = 2,
+	RTLPOWER_WIN_BLACKMAN_HARRIS = 3,
+	RTLPOWER_WIN_HANN_POISSON = 4,
+	RTLPOWER_WIN_YOUSSEF = 5,
+	RTLPOWER_WIN_KAISER = 6,   /* a 1.0 stub in the reference, :392-396 */
+	RTLPOWER_WIN_BARTLETT = 7
+};
+
+/* The tuning_state / global fields scanner() reads (src/rtl_power.c:86-120). */
+typedef struct rtlpower_cfg {
+	int32_t bin_e;              /* log2 of the FFT length; 0 selects rms_power() */
+	int32_t window;             /* enum rtlpower_window */
+	int32_t downsample;         /* ts->downsample */
+	int32_t downsample_passes;  /* ts->downsample_passes (used when boxcar == 0) */
+	int32_t boxcar;             /* global boxcar, default 1 (:118) */
+	int32_t comp_fir_size;      /* 0 or 9 (:119) */
+	int32_t peak_hold;          /* :120 */
+	uint32_t buf_len;           /* bytes per read */
+} rtlpower_cfg;
+
+typedef struct rtlpower_gpu rtlpower_gpu;
+
+/* window_coefs[i] = (int)(256 * window_fn(i, length)) (src/rtl_power.c:985-988); host only */
+int rtlpower_window_coefs(int window, int length, int32_t *out);
+
+int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int device, rtlpower_gpu **out);
+int rtlpower_gpu_destroy(rtlpower_gpu *h);
+
+/*
+ * scanner()'s work for `nreads` consecutive reads of every stream, input
+ * resident in device memory: stream s, read r at d_iq + s*stream_stride +
+ * r*buf_len.  Accumulates into the handle's avg[] / samples (asynchronous).
+ */
+int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nreads);
+
+/* The same for one host buffer of one stream (what rtlsdr_read_sync() filled). */
+int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf, uint32_t len);
+
+/* tuning_state.avg[0 .. 2^bin_e) and .samples of one stream (what csv_dbm() reads, :722-765). */
+int rtlpower_gpu_fetch(rtlpower_gpu *h, int stream, int64_t *avg, int32_t *samples);
+/* csv_dbm() zeroes avg[] and samples after reporting (:761-764). */
+int rtlpower_gpu_clear(rtlpower_gpu *h);
+int rtlpower_gpu_sync(rtlpower_gpu *h);
+int rtlpower_gpu_set_stream(rtlpower_gpu *h, void *hip_stream);
+/* HIP-event timing of the FFT kernel, as rtlfm_gpu_timing_*. */
+int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on);
+int rtlpower_gpu_timing_read(rtlpower_gpu *h, double *ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

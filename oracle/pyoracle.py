@@ -13,7 +13,7 @@ import subprocess
 
 import numpy as np
 
-from rtlsdr_amd.capi import RtlfmCfg, RtlfmStreamState
+from rtlsdr_amd.capi import RtlfmCfg, RtlfmStreamState, RtlpowerCfg
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
@@ -221,3 +221,101 @@ class Reference:
                                       mode, offset_tuning, o)
         return dict(downsample=int(o[0]), downsample_passes=int(o[1]), output_scale=int(o[2]),
                     capture_freq=int(np.uint32(o[3])), capture_rate=int(np.uint32(o[4])))
+
+
+# --------------------------------------------------------------------------- #
+# rtl_power
+# --------------------------------------------------------------------------- #
+
+def _power_lib():
+    lib = oracle()
+    if not hasattr(lib, "_power_ready"):
+        lib.orcp_scan_batch.argtypes = [_P(RtlpowerCfg), C.c_int, C.c_void_p, C.c_size_t, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+        lib.orcp_scan_batch.restype = C.c_int
+        lib.orcp_window_coefs.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        lib.orcp_fix_fft.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        lib.orcp_fix_fft.restype = C.c_int
+        lib.orcp_sine_table.argtypes = [C.c_int]
+        lib.orcp_sine_table.restype = C.c_void_p
+        lib.orcp_fifth_order.argtypes = [C.c_void_p, C.c_int]
+        lib.orcp_generic_fir.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.orcp_remove_dc.argtypes = [C.c_void_p, C.c_int]
+        lib._power_ready = True
+    return lib
+
+
+def power_scan_batch(cfg: RtlpowerCfg, iq: np.ndarray, avg=None, samples=None, nthreads: int = 1):
+    """iq: uint8 [nstreams, nreads*buf_len]; accumulates like scanner() does.
+    Returns (avg int64 [nstreams, 2^bin_e], samples int32 [nstreams])."""
+    lib = _power_lib()
+    iq = np.ascontiguousarray(iq, dtype=np.uint8)
+    ns = iq.shape[0]
+    nreads = iq.shape[1] // int(cfg.buf_len)
+    bins = 1 << cfg.bin_e
+    if avg is None:
+        avg = np.zeros((ns, bins), dtype=np.int64)
+        samples = np.zeros(ns, dtype=np.int32)
+    lib.orcp_scan_batch(C.byref(cfg), ns, iq.ctypes.data, iq.strides[0], nreads, avg.ctypes.data,
+                        samples.ctypes.data, nthreads)
+    return avg, samples
+
+
+def power_window_coefs(window: int, length: int) -> np.ndarray:
+    out = np.zeros(length, dtype=np.int32)
+    _power_lib().orcp_window_coefs(window, length, out.ctypes.data)
+    return out
+
+
+def have_power_reference() -> bool:
+    return os.path.exists(REF_POWER_SO) and os.path.exists(LOADER_SO)
+
+
+class PowerReference:
+    """A private copy of the reference's rtl_power DSP (oracle/_ref/libref_rtlpower.so)."""
+
+    def __init__(self):
+        import shutil
+        import tempfile
+        self._loader = C.CDLL(LOADER_SO)
+        self._loader.ref_loader_open.restype = C.c_void_p
+        self._loader.ref_loader_open.argtypes = [C.c_char_p]
+        self._loader.ref_loader_close.argtypes = [C.c_void_p]
+        self._tmp = tempfile.NamedTemporaryFile(prefix=f"refp{os.getpid()}_", suffix=".so", delete=False)
+        self._tmp.close()
+        shutil.copyfile(REF_POWER_SO, self._tmp.name)
+        self._handle = self._loader.ref_loader_open(self._tmp.name.encode())
+        if not self._handle:
+            raise OSError("cannot open " + REF_POWER_SO)
+        self.lib = C.CDLL(self._tmp.name, handle=self._handle)
+        self.lib.ref_power_setup.argtypes = [_P(RtlpowerCfg)]
+        self.lib.ref_power_scan.argtypes = [C.c_void_p]
+        self.lib.ref_power_get.argtypes = [C.c_void_p, _P(C.c_int32)]
+        self.lib.ref_window_coefs.restype = _P(C.c_int)
+        self.lib.ref_sinewave.restype = _P(C.c_int16)
+        self.lib.fix_fft.argtypes = [C.c_void_p, C.c_int]
+        self.lib.fifth_order.argtypes = [C.c_void_p, C.c_int]
+        self.lib.remove_dc.argtypes = [C.c_void_p, C.c_int]
+        self.lib.generic_fir.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._loader.ref_loader_close(self._handle)
+            self._handle = None
+            try:
+                os.unlink(self._tmp.name)
+            except OSError:
+                pass
+
+    def scan_stream(self, cfg: RtlpowerCfg, iq: np.ndarray):
+        """All reads of ONE stream; returns (avg int64 [2^bin_e], samples)."""
+        self.lib.ref_power_setup(C.byref(cfg))
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+        L = int(cfg.buf_len)
+        for r in range(iq.size // L):
+            part = np.ascontiguousarray(iq[r * L:(r + 1) * L])
+            self.lib.ref_power_scan(part.ctypes.data)
+        avg = np.zeros(1 << cfg.bin_e, dtype=np.int64)
+        n = C.c_int32()
+        self.lib.ref_power_get(avg.ctypes.data, C.byref(n))
+        return avg, n.value

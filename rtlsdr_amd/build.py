@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "librtlfm_hip.so")
-SOURCES = ["rtlfm_hip.hip"]
+SOURCES = ["rtlfm_hip.hip", "rtlpower_hip.hip"]
 HEADERS = ["dsp_device.h", "staged_kernels.h", "fused_kernel.h",
            os.path.join("..", "..", "include", "rtlfm_hip.h")]
 ARCH = "gfx950"

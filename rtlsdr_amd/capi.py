@@ -119,6 +119,38 @@ class RtlfmStreamState(C.Structure):
         return d
 
 
+WIN_RECTANGLE, WIN_HAMMING, WIN_BLACKMAN, WIN_BLACKMAN_HARRIS, WIN_HANN_POISSON, WIN_YOUSSEF, WIN_KAISER, \
+    WIN_BARTLETT = range(8)
+
+
+class RtlpowerCfg(C.Structure):
+    """``rtlpower_cfg`` — what scanner() reads (reference src/rtl_power.c:86-120)."""
+
+    _fields_ = [
+        ("bin_e", C.c_int32),
+        ("window", C.c_int32),
+        ("downsample", C.c_int32),
+        ("downsample_passes", C.c_int32),
+        ("boxcar", C.c_int32),
+        ("comp_fir_size", C.c_int32),
+        ("peak_hold", C.c_int32),
+        ("buf_len", C.c_uint32),
+    ]
+
+    @classmethod
+    def default(cls, **kw) -> "RtlpowerCfg":
+        c = cls(bin_e=10, window=WIN_RECTANGLE, downsample=1, downsample_passes=0, boxcar=1,
+                comp_fir_size=0, peak_hold=0, buf_len=16384)
+        for k, v in kw.items():
+            if not hasattr(c, k):
+                raise AttributeError(k)
+            setattr(c, k, v)
+        return c
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # Every symbol include/rtlfm_hip.h declares: (name, restype, argtypes)
 _P = C.POINTER
 _SIGNATURES = [
@@ -150,7 +182,25 @@ _SIGNATURES = [
     ("rtlfm_gpu_version", C.c_int, []),
 ]
 
+# ... and include/rtlpower_hip.h
+_POWER_SIGNATURES = [
+    ("rtlpower_window_coefs", C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    ("rtlpower_gpu_create", C.c_int, [_P(RtlpowerCfg), C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("rtlpower_gpu_destroy", C.c_int, [C.c_void_p]),
+    ("rtlpower_gpu_scan_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    ("rtlpower_gpu_scan", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]),
+    ("rtlpower_gpu_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _P(C.c_int32)]),
+    ("rtlpower_gpu_clear", C.c_int, [C.c_void_p]),
+    ("rtlpower_gpu_sync", C.c_int, [C.c_void_p]),
+    ("rtlpower_gpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rtlpower_gpu_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("rtlpower_gpu_timing_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int)]),
+]
+_SIGNATURES = _SIGNATURES + _POWER_SIGNATURES
+
 DECLARED_SYMBOLS = [s[0] for s in _SIGNATURES]
+DECLARED_FM_SYMBOLS = [s[0] for s in _SIGNATURES if s[0].startswith("rtlfm_")]
+DECLARED_POWER_SYMBOLS = [s[0] for s in _POWER_SIGNATURES]
 
 _lib = None
 

@@ -1,0 +1,296 @@
+// power_kernels.h — rtl_power's scanner() DSP (reference src/rtl_power.c:642-720)
+// on gfx950.
+//
+// One workgroup of 1024 threads owns one stream (one tuning_state) and walks
+// its reads in order.  Per read, the whole decimated buffer (<= 16384 complex
+// samples, packed int16 I,Q per dword = 64 KiB) lives in LDS next to the
+// 3N/4-entry sine table (<= 24 KiB):
+//   A. sums of I and Q for remove_dc (:581-596; the sum over N/2 values is divided
+//      by N — only half of the DC goes, reproduced as is);
+//   B. u8 -> int16 (-127) (:666-668), DC subtract, window multiply with int16 wrap
+//      (:697-706), each point stored at its BIT-REVERSED index inside its FFT
+//      chunk, which is fix_fft's reordering pass (:282-297) for free;
+//   C. fix_fft's log2(N) radix-2 DIT stages (:298-326) — all chunks of the read at
+//      once, one __syncthreads per stage, every int16 wrap and the FIX_MPY
+//      rounding (:263-269) reproduced bit for bit;
+//   D. |X|^2 into int64 accumulators held in registers across all reads
+//      (thread t owns points t, t+1024, ...), flushed with one 64-bit atomic per
+//      accumulator at the end (add, or max for peak hold, :708-716).
+// This path is VALU/LDS bound, not HBM bound: ~250 integer ops per input sample.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtlpower_hip.h"
+#include "dsp_device.h"
+
+namespace rtlpower {
+
+using rtlfm::iq16;
+using rtlfm::pack_iq;
+using rtlfm::unpack_iq;
+
+constexpr int kThreads = 1024;
+constexpr int kMaxPoints = 16384;
+
+struct ScanParams {
+	const uint8_t *iq8;      // raw reads (used when dec == nullptr)
+	size_t stride8;          // bytes between streams
+	const int16_t *dec;      // decimated int16 elements [stream][read][dec_elems], or nullptr
+	size_t dec_stream_stride, dec_read_stride;  // in elements
+	int dec_elems;           // valid elements per read in `dec` (beyond: zeros)
+	int nreads;
+	int buf_len;             // bytes per raw read
+	int len_dec;             // buf_len / ds: what remove_dc and the chunk loop see
+	int bin_e, chunks;       // FFT size exponent, chunks per read
+	int ds, peak_hold;
+	const int32_t *window;   // [N]
+	const int16_t *sine;     // [3N/4]
+	long long *avg;          // [stream][N]
+	int32_t *samples;        // [stream]
+};
+
+// FIX_MPY, src/rtl_power.c:263-269
+__device__ __forceinline__ int fix_mpy(int a, int b)
+{
+	int c = (a * b) >> 14;
+	return (int)(int16_t)((c >> 1) + (c & 1));
+}
+
+__device__ __forceinline__ int element_at(const ScanParams &p, const uint8_t *raw, const int16_t *dec, int e)
+{
+	if (dec) return e < p.dec_elems ? (int)dec[e] : 0;
+	return e < p.buf_len ? (int)raw[e] - 127 : 0;
+}
+
+__global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+	const int N = 1 << p.bin_e;
+	const int M = p.chunks * N;
+	uint32_t *pts = sm;                                     // [M]
+	int16_t *sine = reinterpret_cast<int16_t *>(sm + M);    // [3N/4]
+	__shared__ long long red[2][kThreads / 64];
+	__shared__ int ave[2];
+	const int t = threadIdx.x;
+	const size_t s = blockIdx.x;
+	for (int k = t; k < N * 3 / 4; k += kThreads) sine[k] = p.sine[k];
+	const int A = N >= kThreads ? N / kThreads : 1;  // accumulators per thread
+	long long acc[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) acc[k] = 0;
+
+	for (int r = 0; r < p.nreads; r++) {
+		const uint8_t *raw = p.iq8 ? p.iq8 + s * p.stride8 + (size_t)r * p.buf_len : nullptr;
+		const int16_t *dec = p.dec ? p.dec + s * p.dec_stream_stride + (size_t)r * p.dec_read_stride : nullptr;
+		// ---- A: remove_dc sums over the elements below len_dec --------------------
+		long long si = 0, sq = 0;
+		for (int pnt = t; 2 * pnt < p.len_dec; pnt += kThreads) {
+			si += element_at(p, raw, dec, 2 * pnt);
+			if (2 * pnt + 1 < p.len_dec) sq += element_at(p, raw, dec, 2 * pnt + 1);
+		}
+		for (int off = 32; off > 0; off >>= 1) {
+			si += __shfl_down(si, off);
+			sq += __shfl_down(sq, off);
+		}
+		__syncthreads();  // previous read's phase D is done with pts / red
+		if ((t & 63) == 0) { red[0][t >> 6] = si; red[1][t >> 6] = sq; }
+		__syncthreads();
+		if (t == 0) {
+			long long a = 0, b = 0;
+			for (int k = 0; k < kThreads / 64; k++) { a += red[0][k]; b += red[1][k]; }
+			ave[0] = (int)(int16_t)(a / (long long)p.len_dec);
+			ave[1] = p.len_dec > 1 ? (int)(int16_t)(b / (long long)(p.len_dec - 1)) : 0;
+		}
+		__syncthreads();
+		const int ai = ave[0], aq = ave[1];
+		// ---- B: convert, DC, window, bit-reversed placement -----------------------
+		for (int pnt = t; pnt < M; pnt += kThreads) {
+			const int c = pnt >> p.bin_e, j = pnt & (N - 1);
+			int vi = element_at(p, raw, dec, 2 * pnt), vq = element_at(p, raw, dec, 2 * pnt + 1);
+			if (2 * pnt < p.len_dec) vi = (int16_t)(vi - ai);
+			if (2 * pnt + 1 < p.len_dec) vq = (int16_t)(vq - aq);
+			const int w = p.window[j];
+			vi = (int16_t)(vi * w);
+			vq = (int16_t)(vq * w);
+			const int rj = (int)(__brev((unsigned)j) >> (32 - p.bin_e));
+			pts[(c << p.bin_e) + rj] = pack_iq(vi, vq);
+		}
+		__syncthreads();
+		// ---- C: radix-2 DIT stages -------------------------------------------------
+		for (int st = 0; st < p.bin_e; st++) {
+			const int half = 1 << st;
+			const int k = p.bin_e - 1 - st;
+			for (int q = t; q < M / 2; q += kThreads) {
+				const int c = q >> (p.bin_e - 1), qq = q & (N / 2 - 1);
+				const int m = qq & (half - 1), grp = qq >> st;
+				const int i = (c << p.bin_e) + (grp << (st + 1)) + m;
+				const int pp = i + half;
+				const int j = m << k;
+				const int wr = (int)sine[j + N / 4] >> 1;
+				const int wi = (int)(int16_t)(-(int)sine[j]) >> 1;
+				const iq16 b = unpack_iq(pts[pp]);
+				const iq16 a = unpack_iq(pts[i]);
+				const int tr = (int16_t)(fix_mpy(wr, b.i) - fix_mpy(wi, b.q));
+				const int ti = (int16_t)(fix_mpy(wr, b.q) + fix_mpy(wi, b.i));
+				const int qr = (int)a.i >> 1, qi = (int)a.q >> 1;
+				pts[pp] = pack_iq((int16_t)(qr - tr), (int16_t)(qi - ti));
+				pts[i] = pack_iq((int16_t)(qr + tr), (int16_t)(qi + ti));
+			}
+			__syncthreads();
+		}
+		// ---- D: integrate / peak hold ------------------------------------------------
+		auto fold = [&](long long &a, int pnt) {
+			const iq16 v = unpack_iq(pts[pnt]);
+			const long long pw = (long long)v.i * v.i + (long long)v.q * v.q;
+			a = p.peak_hold ? (pw > a ? pw : a) : a + pw;
+		};
+		if (N >= kThreads) {
+			// accumulator a of thread t is bin t + 1024*a of every chunk
+#pragma unroll
+			for (int a = 0; a < 16; a++)
+				if (a < A)
+					for (int c = 0; c < p.chunks; c++) fold(acc[a], (c << p.bin_e) + t + kThreads * a);
+		} else {
+			// N divides 1024: every point of this thread is bin t mod N
+			for (int pnt = t; pnt < M; pnt += kThreads) fold(acc[0], pnt);
+		}
+	}
+	// flush with one 64-bit atomic per accumulator (threads t, t+N, ... share a bin when N < 1024)
+	if (t < M) {
+#pragma unroll
+		for (int a = 0; a < 16; a++) {
+			if (a < A) {
+				const int bin = (t + kThreads * a) & (N - 1);
+				if (p.peak_hold) atomicMax(p.avg + s * N + bin, acc[a]);
+				else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + bin), (unsigned long long)acc[a]);
+			}
+		}
+	}
+	if (t == 0) p.samples[s] += p.ds * p.chunks * p.nreads;  // :717
+}
+
+// rms_power(), src/rtl_power.c:410-436 (bin_e == 0): one workgroup per stream
+__global__ void __launch_bounds__(256) k_power_rms(const uint8_t *iq8, size_t stride8, int nreads, int buf_len,
+                                                   int peak_hold, long long *avg, int32_t *samples)
+{
+	__shared__ long long rp[256], rt[256];
+	const size_t s = blockIdx.x;
+	for (int r = 0; r < nreads; r++) {
+		const uint8_t *raw = iq8 + s * stride8 + (size_t)r * buf_len;
+		long long p = 0, t = 0;
+		for (int i = threadIdx.x; i < buf_len; i += 256) {
+			int v = (int)raw[i] - 127;
+			t += v;
+			p += v * v;
+		}
+		rp[threadIdx.x] = p; rt[threadIdx.x] = t;
+		__syncthreads();
+		for (int off = 128; off > 0; off >>= 1) {
+			if ((int)threadIdx.x < off) { rp[threadIdx.x] += rp[threadIdx.x + off]; rt[threadIdx.x] += rt[threadIdx.x + off]; }
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) {
+			p = rp[0]; t = rt[0];
+			double dc = (double)t / (double)buf_len;
+			double err = (double)(t * 2) * dc - dc * dc * buf_len;
+			p -= (long long)round(err);
+			long long *a = avg + s;
+			if (!peak_hold) *a += p;
+			else if (p > *a) *a = p;
+			samples[s] += 1;
+		}
+		__syncthreads();
+	}
+}
+
+// ---- decimation ahead of the FFT (only when ds > 1) -----------------------------
+// boxcar, src/rtl_power.c:671-681: int16-wrapping sums of ds complex samples
+__global__ void __launch_bounds__(256) k_power_boxcar(const uint8_t *iq8, size_t stride8, int nreads, int buf_len,
+                                                      int ds, int nstreams, int16_t *dec, size_t dec_stream_stride,
+                                                      size_t dec_read_stride, int out_cplx)
+{
+	const int n = buf_len / 2;
+	const size_t total = (size_t)nstreams * nreads * out_cplx;
+	for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+		int k = (int)(g % out_cplx);
+		size_t sr = g / out_cplx;
+		int r = (int)(sr % nreads);
+		size_t s = sr / nreads;
+		const uint8_t *raw = iq8 + s * stride8 + (size_t)r * buf_len;
+		int si = 0, sq = 0;
+		for (int x = k * ds; x < (k + 1) * ds && x < n; x++) {
+			si += (int)raw[2 * x] - 127;
+			sq += (int)raw[2 * x + 1] - 127;
+		}
+		int16_t *d = dec + s * dec_stream_stride + (size_t)r * dec_read_stride;
+		d[2 * k] = (int16_t)si;
+		d[2 * k + 1] = (int16_t)sq;
+	}
+}
+
+// One component value of the input of a fifth_order pass
+struct ElemSrc {
+	const uint8_t *raw;   // pass 0: u8
+	const int16_t *i16;   // later passes
+	__device__ __forceinline__ int at(int e) const { return raw ? (int)raw[e] - 127 : (int)i16[e]; }
+};
+
+// stateless fifth_order on I and Q (downsample_iq, src/rtl_power.c:554-579, 628-634):
+// one thread per complex output; see the oracle for the ease-in / x5-twice pattern
+__global__ void __launch_bounds__(256) k_power_fifth(const uint8_t *iq8, size_t stride8, const int16_t *in,
+                                                     size_t in_stream_stride, size_t in_read_stride, int nreads,
+                                                     int buf_len, int length /* elements going in */, int nstreams,
+                                                     int16_t *out, size_t out_stream_stride, size_t out_read_stride)
+{
+	const int outs = length / 4;  // complex outputs
+	const size_t total = (size_t)nstreams * nreads * outs;
+	for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+		int m = (int)(g % outs);
+		size_t sr = g / outs;
+		int r = (int)(sr % nreads);
+		size_t s = sr / nreads;
+		ElemSrc src;
+		src.raw = iq8 ? iq8 + s * stride8 + (size_t)r * buf_len : nullptr;
+		src.i16 = in ? in + s * in_stream_stride + (size_t)r * in_read_stride : nullptr;
+		int y[2];
+		for (int comp = 0; comp < 2; comp++) {
+			auto x = [&](int k) { return src.at(2 * k + comp); };
+			int v;
+			if (m == 0) v = ((x(0) + x(1)) * 10 + (x(2) + x(3)) * 5 + x(3) + x(5)) >> 4;
+			else if (m == 1) v = ((x(1) + x(2)) * 10 + (x(0) + x(3)) * 5 + x(4) + x(5)) >> 4;
+			else if (m == 2) v = (x(0) + (x(1) + x(4)) * 5 + (x(2) + x(3)) * 10 + x(5)) >> 4;
+			else if (m == 3) v = (x(2) + (x(3) + x(5)) * 5 + (x(4) + x(5)) * 10 + x(6)) >> 4;
+			else if (m == 4) v = (x(4) + (x(5) + x(7)) * 5 + (x(5) + x(6)) * 10 + x(8)) >> 4;
+			else v = (x(2 * m - 5) + (x(2 * m - 4) + x(2 * m - 1)) * 5 + (x(2 * m - 3) + x(2 * m - 2)) * 10 + x(2 * m)) >> 4;
+			y[comp] = (int16_t)v;
+		}
+		int16_t *d = out + s * out_stream_stride + (size_t)r * out_read_stride;
+		d[2 * m] = (int16_t)y[0];
+		d[2 * m + 1] = (int16_t)y[1];
+	}
+}
+
+// stateless generic_fir, src/rtl_power.c:598-626: the first nine samples pass
+__global__ void __launch_bounds__(256) k_power_fir9(const int16_t *in, int16_t *out, size_t stream_stride,
+                                                    size_t read_stride, int nreads, int cplx, int nstreams, int passes)
+{
+	const size_t total = (size_t)nstreams * nreads * cplx;
+	for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+		int n = (int)(g % cplx);
+		size_t sr = g / cplx;
+		int r = (int)(sr % nreads);
+		size_t s = sr / nreads;
+		const int16_t *x = in + s * stream_stride + (size_t)r * read_stride;
+		int16_t *y = out + s * stream_stride + (size_t)r * read_stride;
+		if (n < 9) { y[2 * n] = x[2 * n]; y[2 * n + 1] = x[2 * n + 1]; continue; }
+		int hi[9], hq[9];
+#pragma unroll
+		for (int k = 0; k < 9; k++) { hi[k] = x[2 * (n - 9 + k)]; hq[k] = x[2 * (n - 9 + k) + 1]; }
+		y[2 * n] = (int16_t)rtlfm::fir9_tap(hi, rtlfm::k_cic9[passes]);
+		y[2 * n + 1] = (int16_t)rtlfm::fir9_tap(hq, rtlfm::k_cic9[passes]);
+	}
+}
+
+}  // namespace rtlpower

@@ -1,0 +1,321 @@
+// rtlpower_hip.hip — the C ABI of include/rtlpower_hip.h on HIP / gfx950.
+// Host side of rtl_power's scanner() (reference src/rtl_power.c:642-720).
+// No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rtlpower_hip.h"
+#include "power_kernels.h"
+
+using namespace rtlpower;
+
+#define HIP_TRY(expr)                                                                         \
+	do {                                                                                      \
+		hipError_t e_ = (expr);                                                               \
+		if (e_ != hipSuccess) {                                                               \
+			fprintf(stderr, "rtlpower_hip: %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+			        __FILE__, __LINE__);                                                      \
+			return e_ == hipErrorOutOfMemory ? -ENOMEM : -EIO;                                \
+		}                                                                                     \
+	} while (0)
+
+struct rtlpower_gpu {
+	rtlpower_cfg cfg;
+	int nstreams = 0, device = 0;
+	hipStream_t own_stream = nullptr, stream = nullptr;
+	int N = 1, len_dec = 0, chunks = 0, dec_elems = 0;
+	bool decimates = false;
+	int32_t *d_window = nullptr;
+	int16_t *d_sine = nullptr;
+	long long *d_avg = nullptr;
+	int32_t *d_samples = nullptr;
+	int16_t *d_decA = nullptr, *d_decB = nullptr;
+	size_t dec_cap_reads = 0;
+	uint8_t *d_one = nullptr;  // landing zone of rtlpower_gpu_scan()
+	bool timing = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
+};
+
+// the window functions, src/rtl_power.c:329-408
+static double window_fn(int window, int i, int length)
+{
+	const double n1 = (double)(length - 1);
+	switch (window) {
+	case RTLPOWER_WIN_HAMMING:
+		return 25.0 / 46.0 - 21.0 / 46.0 * cos(2 * i * M_PI / n1);
+	case RTLPOWER_WIN_BLACKMAN:
+		return 7938.0 / 18608.0 - 9240.0 / 18608.0 * cos(2 * i * M_PI / n1) +
+		       1430.0 / 18608.0 * cos(4 * i * M_PI / n1);
+	case RTLPOWER_WIN_BLACKMAN_HARRIS:
+		return 0.35875 - 0.48829 * cos(2 * i * M_PI / n1) + 0.14128 * cos(4 * i * M_PI / n1) -
+		       0.01168 * cos(6 * i * M_PI / n1);
+	case RTLPOWER_WIN_HANN_POISSON:
+		return 0.5 * (1 - cos(2 * M_PI * i / n1)) * pow(M_E, (-2.0 * (double)abs((int)(n1 - 1 - 2 * i))) / n1);
+	case RTLPOWER_WIN_YOUSSEF: {
+		double w = 0.35875 - 0.48829 * cos(2 * i * M_PI / n1) + 0.14128 * cos(4 * i * M_PI / n1) -
+		           0.01168 * cos(6 * i * M_PI / n1);
+		return w * pow(M_E, (-0.0025 * (double)abs((int)(n1 - 1 - 2 * i))) / n1);
+	}
+	case RTLPOWER_WIN_BARTLETT: {
+		double l = (double)length, w = (i - n1 / 2) / (l / 2);
+		if (w < 0) w = -w;
+		return 1 - w;
+	}
+	default:
+		return 1.0;  // rectangle, and kaiser (a stub in the reference, :392-396)
+	}
+}
+
+extern "C" int rtlpower_window_coefs(int window, int length, int32_t *out)
+{
+	if (!out || length < 1 || window < 0 || window > RTLPOWER_WIN_BARTLETT) return -EINVAL;
+	for (int i = 0; i < length; i++)
+		out[i] = (int32_t)(256 * window_fn(window, i, length));  // src/rtl_power.c:985-988
+	return 0;
+}
+
+static int validate(const rtlpower_cfg *c)
+{
+	if (c->bin_e < 0 || c->bin_e > 14) return c->bin_e > 14 && c->bin_e <= 21 ? -ENOTSUP : -EINVAL;
+	if (c->window < 0 || c->window > RTLPOWER_WIN_BARTLETT) return -EINVAL;
+	if (c->buf_len < 16 || c->buf_len % 4 || c->buf_len > (1u << 24)) return -EINVAL;
+	if (c->downsample < 1) return -EINVAL;
+	if (c->comp_fir_size != 0 && c->comp_fir_size != 9) return -EINVAL;
+	if (!c->boxcar && c->downsample_passes) {
+		if (c->downsample_passes < 1 || c->downsample_passes > 10) return -EINVAL;
+		if (c->downsample != (1 << c->downsample_passes)) return -EINVAL;
+		if (c->buf_len % (4u << c->downsample_passes)) return -EINVAL;
+		if ((c->buf_len >> c->downsample_passes) < 48) return -EINVAL;  // ease-in reads x[0..8], fir 9 more
+	}
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int device, rtlpower_gpu **out)
+{
+	if (!cfg || !out || nstreams < 1) return -EINVAL;
+	int v = validate(cfg);
+	if (v < 0) return v;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+		fprintf(stderr, "rtlpower_hip: no usable HIP device (count=%d); there is no CPU fallback\n", ndev);
+		return -ENODEV;
+	}
+	HIP_TRY(hipSetDevice(device));
+	rtlpower_gpu *h = new rtlpower_gpu();
+	h->cfg = *cfg;
+	h->nstreams = nstreams;
+	h->device = device;
+	h->N = 1 << cfg->bin_e;
+	const int ds = cfg->downsample;
+	h->decimates = (cfg->boxcar && ds > 1) || (!cfg->boxcar && cfg->downsample_passes > 0);
+	h->len_dec = (int)cfg->buf_len / ds;  // what remove_dc() and the chunk loop are given (:692-696)
+	if (cfg->bin_e > 0) {
+		h->chunks = (h->len_dec + 2 * h->N - 1) / (2 * h->N);
+		if ((long long)h->chunks * h->N > kMaxPoints) { delete h; return -ENOTSUP; }
+		if (cfg->boxcar && ds > 1) h->dec_elems = 2 * (((int)cfg->buf_len / 2 + ds - 1) / ds);
+		else if (h->decimates) h->dec_elems = (int)cfg->buf_len >> cfg->downsample_passes;
+	}
+	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+	h->stream = h->own_stream;
+	const size_t S = (size_t)nstreams;
+	HIP_TRY(hipMalloc(&h->d_avg, S * h->N * sizeof(long long)));
+	HIP_TRY(hipMalloc(&h->d_samples, S * sizeof(int32_t)));
+	if (cfg->bin_e > 0) {
+		std::vector<int32_t> w((size_t)h->N);
+		rtlpower_window_coefs(cfg->window, h->N, w.data());
+		HIP_TRY(hipMalloc(&h->d_window, w.size() * sizeof(int32_t)));
+		HIP_TRY(hipMemcpy(h->d_window, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		// sine_table(), src/rtl_power.c:247-261
+		std::vector<int16_t> sine((size_t)h->N * 3 / 4 + 1);
+		for (int i = 0; i < h->N * 3 / 4; i++)
+			sine[i] = (int16_t)(int)round(32767 * sin((double)i * 2.0 * M_PI / h->N));
+		HIP_TRY(hipMalloc(&h->d_sine, sine.size() * sizeof(int16_t)));
+		HIP_TRY(hipMemcpy(h->d_sine, sine.data(), sine.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+	}
+	*out = h;
+	return rtlpower_gpu_clear(h);
+}
+
+extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
+{
+	if (!h) return -EINVAL;
+	(void)hipSetDevice(h->device);
+	(void)hipStreamSynchronize(h->stream);
+	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+	void *ptrs[] = {h->d_window, h->d_sine, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+	delete h;
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_clear(rtlpower_gpu *h)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipMemsetAsync(h->d_avg, 0, (size_t)h->nstreams * h->N * sizeof(long long), h->stream));
+	HIP_TRY(hipMemsetAsync(h->d_samples, 0, (size_t)h->nstreams * sizeof(int32_t), h->stream));
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_sync(rtlpower_gpu *h)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_set_stream(rtlpower_gpu *h, void *s)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	h->stream = s ? (hipStream_t)s : h->own_stream;
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on)
+{
+	if (!h) return -EINVAL;
+	h->timing = on != 0;
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_timing_read(rtlpower_gpu *h, double *ms, int *launches)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	double total = 0;
+	int n = 0;
+	for (auto &p : h->ev_pending) {
+		float t = 0;
+		HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
+		total += t; n++;
+		h->ev_free.push_back(p);
+	}
+	h->ev_pending.clear();
+	if (ms) *ms = total;
+	if (launches) *launches = n;
+	return 0;
+}
+
+static inline int grid_for(size_t work, int block = 256, int cap = 256 * 16)
+{
+	size_t g = (work + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > (size_t)cap) g = cap;
+	return (int)g;
+}
+
+extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nreads)
+{
+	if (!h || !d_iq || nreads < 1) return -EINVAL;
+	if (stream_stride < (size_t)nreads * h->cfg.buf_len) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	const rtlpower_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	hipStream_t q = h->stream;
+	if (c.bin_e == 0) {
+		k_power_rms<<<S, 256, 0, q>>>(d_iq, stream_stride, nreads, (int)c.buf_len, c.peak_hold, h->d_avg, h->d_samples);
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
+	const int16_t *dec = nullptr;
+	size_t dss = 0, drs = 0;
+	if (h->decimates) {
+		drs = (size_t)c.buf_len;  // elements reserved per read
+		dss = drs * nreads;
+		if (h->dec_cap_reads < (size_t)nreads) {
+			if (h->d_decA) { (void)hipFree(h->d_decA); (void)hipFree(h->d_decB); h->d_decA = h->d_decB = nullptr; }
+			HIP_TRY(hipMalloc(&h->d_decA, (size_t)S * dss * sizeof(int16_t)));
+			HIP_TRY(hipMalloc(&h->d_decB, (size_t)S * dss * sizeof(int16_t)));
+			h->dec_cap_reads = nreads;
+		}
+		int16_t *cur = h->d_decA, *oth = h->d_decB;
+		if (c.boxcar) {
+			const int out_cplx = h->dec_elems / 2;
+			k_power_boxcar<<<grid_for((size_t)S * nreads * out_cplx), 256, 0, q>>>(
+			    d_iq, stream_stride, nreads, (int)c.buf_len, c.downsample, S, cur, dss, drs, out_cplx);
+		} else {
+			for (int j = 0; j < c.downsample_passes; j++) {
+				const int length = (int)c.buf_len >> j;
+				k_power_fifth<<<grid_for((size_t)S * nreads * (length / 4)), 256, 0, q>>>(
+				    j == 0 ? d_iq : nullptr, stream_stride, j == 0 ? nullptr : cur, dss, drs, nreads, (int)c.buf_len,
+				    length, S, j == 0 ? cur : oth, dss, drs);
+				if (j > 0) std::swap(cur, oth);
+			}
+			if (c.comp_fir_size == 9) {
+				const int cplx = ((int)c.buf_len >> c.downsample_passes) / 2;
+				k_power_fir9<<<grid_for((size_t)S * nreads * cplx), 256, 0, q>>>(cur, oth, dss, drs, nreads, cplx, S,
+				                                                               c.downsample_passes);
+				std::swap(cur, oth);
+			}
+		}
+		dec = cur;
+	}
+	ScanParams p{};
+	p.iq8 = dec ? nullptr : d_iq; p.stride8 = stream_stride;
+	p.dec = dec; p.dec_stream_stride = dss; p.dec_read_stride = drs; p.dec_elems = h->dec_elems;
+	p.nreads = nreads; p.buf_len = (int)c.buf_len; p.len_dec = h->len_dec;
+	p.bin_e = c.bin_e; p.chunks = h->chunks; p.ds = c.downsample; p.peak_hold = c.peak_hold;
+	p.window = h->d_window; p.sine = h->d_sine; p.avg = h->d_avg; p.samples = h->d_samples;
+	const size_t lds = (size_t)h->chunks * h->N * 4 + (size_t)h->N * 3 / 4 * 2 + 16;
+	static bool attr_set = false;
+	if (!attr_set) {
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan),
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		attr_set = true;
+	}
+	std::pair<hipEvent_t, hipEvent_t> ev;
+	if (h->timing) {
+		if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+		else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+		HIP_TRY(hipEventRecord(ev.first, q));
+	}
+	hipLaunchKernelGGL(k_power_scan, dim3(S), dim3(kThreads), lds, q, p);
+	HIP_TRY(hipGetLastError());
+	if (h->timing) {
+		HIP_TRY(hipEventRecord(ev.second, q));
+		h->ev_pending.push_back(ev);
+	}
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf, uint32_t len)
+{
+	// one tuning_state, one rtlsdr_read_sync() buffer (src/rtl_power.c:657): run it
+	// through a one-stream view of the handle
+	if (!h || !buf || stream < 0 || stream >= h->nstreams || len != h->cfg.buf_len) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	if (!h->d_one) HIP_TRY(hipMalloc(&h->d_one, h->cfg.buf_len));
+	HIP_TRY(hipMemcpyAsync(h->d_one, buf, len, hipMemcpyHostToDevice, h->stream));
+	rtlpower_gpu view = *h;  // shallow: same device buffers, shifted to this stream
+	view.nstreams = 1;
+	view.d_avg = h->d_avg + (size_t)stream * h->N;
+	view.d_samples = h->d_samples + stream;
+	view.d_decA = view.d_decB = nullptr; view.dec_cap_reads = 0;
+	view.ev_pending.clear(); view.ev_free.clear(); view.timing = false;
+	int r = rtlpower_gpu_scan_device(&view, h->d_one, h->cfg.buf_len, 1);
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }
+	return r;
+}
+
+extern "C" int rtlpower_gpu_fetch(rtlpower_gpu *h, int stream, int64_t *avg, int32_t *samples)
+{
+	if (!h || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	if (avg) HIP_TRY(hipMemcpy(avg, h->d_avg + (size_t)stream * h->N, (size_t)h->N * sizeof(long long), hipMemcpyDeviceToHost));
+	if (samples) HIP_TRY(hipMemcpy(samples, h->d_samples + stream, sizeof(int32_t), hipMemcpyDeviceToHost));
+	return 0;
+}

@@ -1,0 +1,81 @@
+"""Host-side mirror of rtl_power's scanner() over the C ABI (include/rtlpower_hip.h).
+
+One ``GpuPower`` handle holds ``nstreams`` tuning states (reference
+``struct tuning_state``, src/rtl_power.c:86-108): ``scanner`` feeds reads,
+``avg``/``samples`` are what ``csv_dbm`` (:722-765) reads."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import RtlpowerCfg, check
+
+
+class GpuPower:
+    def __init__(self, cfg: RtlpowerCfg, nstreams: int = 1, device: int = 0):
+        self.lib = capi.load()
+        self.cfg = cfg
+        self.nstreams = nstreams
+        h = C.c_void_p()
+        check(self.lib.rtlpower_gpu_create(C.byref(cfg), nstreams, device, C.byref(h)), "rtlpower_gpu_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.rtlpower_gpu_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scanner(self, buf, stream: int = 0):
+        """One rtlsdr_read_sync() buffer of one tuning state."""
+        a = np.ascontiguousarray(buf, dtype=np.uint8)
+        check(self.lib.rtlpower_gpu_scan(self._h, stream, a.ctypes.data, a.size), "rtlpower_gpu_scan")
+
+    def scan_device(self, d_iq_ptr: int, stream_stride: int, nreads: int):
+        check(self.lib.rtlpower_gpu_scan_device(self._h, d_iq_ptr, stream_stride, nreads),
+              "rtlpower_gpu_scan_device")
+
+    def scan_torch(self, iq):
+        """iq: torch uint8 [nstreams, nreads*buf_len] on the device."""
+        nreads = iq.shape[1] // int(self.cfg.buf_len)
+        self.scan_device(iq.data_ptr(), iq.stride(0), nreads)
+
+    def fetch(self, stream: int = 0):
+        n = 1 << self.cfg.bin_e
+        avg = np.zeros(n, dtype=np.int64)
+        samples = C.c_int32()
+        check(self.lib.rtlpower_gpu_fetch(self._h, stream, avg.ctypes.data, C.byref(samples)), "rtlpower_gpu_fetch")
+        return avg, samples.value
+
+    def clear(self):
+        check(self.lib.rtlpower_gpu_clear(self._h), "rtlpower_gpu_clear")
+
+    def sync(self):
+        check(self.lib.rtlpower_gpu_sync(self._h), "rtlpower_gpu_sync")
+
+    def timing_enable(self, on=True):
+        check(self.lib.rtlpower_gpu_timing_enable(self._h, int(on)), "timing_enable")
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int()
+        check(self.lib.rtlpower_gpu_timing_read(self._h, C.byref(ms), C.byref(n)), "timing_read")
+        return ms.value, n.value
+
+
+def window_coefs(window: int, length: int) -> np.ndarray:
+    out = np.zeros(length, dtype=np.int32)
+    check(capi.load().rtlpower_window_coefs(window, length, out.ctypes.data), "rtlpower_window_coefs")
+    return out

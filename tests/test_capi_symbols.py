@@ -20,14 +20,17 @@ def lib():
 
 
 def header_symbols():
-    text = open(os.path.join(ROOT, "include", "rtlfm_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rtlfm_[a-z_0-9]+)\s*\(", text)))
+    out = []
+    for hdr, prefix in (("rtlfm_hip.h", "rtlfm_"), ("rtlpower_hip.h", "rtlpower_")):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out += re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, text)
+    return sorted(set(out))
 
 
 def test_every_declared_symbol_is_exported(lib):
     declared = header_symbols()
-    assert len(declared) >= 20
+    assert len(declared) >= 30
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rtlfm_hip.h but not exported"
     assert sorted(capi.DECLARED_SYMBOLS) == declared
@@ -37,15 +40,17 @@ def test_struct_sizes_match_header(lib):
     # sizeof() as the C compiler lays them out
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "rtlfm_hip.h"\nint main(){printf("%zu %zu\\n", sizeof(rtlfm_cfg), sizeof(rtlfm_stream_state));return 0;}\n'
+    src = ('#include <stdio.h>\n#include "rtlfm_hip.h"\n#include "rtlpower_hip.h"\n'
+           'int main(){printf("%zu %zu %zu\\n", sizeof(rtlfm_cfg), sizeof(rtlfm_stream_state), sizeof(rtlpower_cfg));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "s.c")
         open(p, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
-        a, b = map(int, subprocess.check_output([exe]).split())
+        a, b, c = map(int, subprocess.check_output([exe]).split())
     assert a == C.sizeof(capi.RtlfmCfg)
     assert b == C.sizeof(capi.RtlfmStreamState)
+    assert c == C.sizeof(capi.RtlpowerCfg)
 
 
 def test_cfg_default_is_demod_init(lib):

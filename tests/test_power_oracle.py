@@ -1,0 +1,81 @@
+"""rtl_power: the CPU oracle against the reference's own golden output and
+(where oracle/_ref exists) against the live compiled reference, function by
+function."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from rtlsdr_amd.capi import RtlpowerCfg
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def power_fixtures():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "power_*.npz")))
+
+
+def load_power(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return RtlpowerCfg.from_buffer_copy(z["cfg"].tobytes()), z["iq"], z["avg"], int(z["samples"])
+
+
+@pytest.mark.parametrize("name", power_fixtures())
+def test_power_oracle_matches_golden(oracle_lib, name):
+    cfg, iq, want, n = load_power(name)
+    avg, samples = oracle_lib.power_scan_batch(cfg, iq[None, :])
+    assert samples[0] == n
+    assert np.array_equal(avg[0], want)  # int64, bit-exact
+
+
+def test_power_functions_against_live_reference(oracle_lib):
+    if not oracle_lib.have_power_reference():
+        pytest.skip("oracle/_ref not built here")
+    lib = oracle_lib._power_lib()
+    ref = oracle_lib.PowerReference()
+    rng = np.random.default_rng(9)
+    try:
+        for be in (3, 8, 12):
+            cfg = RtlpowerCfg.default(bin_e=be, window=1, buf_len=max(16384, 2 << be))
+            ref.lib.ref_power_setup(C.byref(cfg))
+            n = 1 << be
+            # sine table and window coefficients
+            sw = np.ctypeslib.as_array(ref.lib.ref_sinewave(), shape=(n * 3 // 4,)).copy()
+            mine = np.ctypeslib.as_array(C.cast(lib.orcp_sine_table(be), C.POINTER(C.c_int16)), shape=(n * 3 // 4,))
+            assert np.array_equal(sw, mine)
+            wc = np.ctypeslib.as_array(ref.lib.ref_window_coefs(), shape=(n,)).copy()
+            assert np.array_equal(wc, oracle_lib.power_window_coefs(1, n))
+            # fix_fft on full-scale data
+            x = rng.integers(-32768, 32768, size=2 * n).astype(np.int16)
+            a, b = x.copy(), x.copy()
+            ref.lib.fix_fft(a.ctypes.data, be)
+            lib.orcp_fix_fft(b.ctypes.data, be, mine.ctypes.data, be)
+            assert np.array_equal(a, b)
+        for length in (64, 1024, 4096):
+            x = rng.integers(-3000, 3000, size=length).astype(np.int16)
+            a, b = x.copy(), x.copy()
+            ref.lib.fifth_order(a.ctypes.data, length); lib.orcp_fifth_order(b.ctypes.data, length)
+            assert np.array_equal(a, b)
+            a, b = x.copy(), x.copy()
+            ref.lib.remove_dc(a.ctypes.data, length); lib.orcp_remove_dc(b.ctypes.data, length)
+            assert np.array_equal(a, b)
+    finally:
+        ref.close()
+
+
+def test_remove_dc_removes_only_half(oracle_lib):
+    """p2 quirk: the sum over N/2 samples is divided by N."""
+    lib = oracle_lib._power_lib()
+    x = np.zeros(256, dtype=np.int16); x[0::2] = 100
+    lib.orcp_remove_dc(x.ctypes.data, 256)
+    assert set(x[0::2]) == {50}
+
+
+def test_window_multiply_wraps(oracle_lib):
+    """p3: +128 * 256 wraps to -32768 (rectangle window, full-scale input)."""
+    cfg = RtlpowerCfg.default(bin_e=4, window=0, buf_len=16384)
+    iq = np.full(16384, 255, dtype=np.uint8)  # 255-127 = 128 everywhere
+    avg, n = oracle_lib.power_scan_batch(cfg, iq[None, :])
+    assert n[0] == 16384 // 32 and avg[0].sum() > 0
