@@ -112,16 +112,18 @@ __device__ __forceinline__ int atan2_q14(int y, int x, Nodes nodes)
 	const double fx = (double)x, fy = (double)y;
 	const double ax = fabs(fx), ay = fabs(fy);
 	const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-	// node index from an fp32 estimate of mn/mx (mx == 0 gives NaN -> 0)
+	// node index from an fp32 estimate of mn/mx: q <= 1 + 2^-22, so i <= 16;
+	// mx == 0 gives NaN -> i = 0 and, further down, NaN -> result 0 (v_cvt_i32_f64)
 	const float q = (float)mn * __builtin_amdgcn_rcpf((float)mx);
-	int i = (int)__builtin_fmaf(q, 16.0f, 0.5f);
-	i = i > 16 ? 16 : i;
+	const int i = (int)__builtin_fmaf(q, 16.0f, 0.5f);
 	const double c = (double)i * 0.0625;
 	const double num = __builtin_fma(-c, mx, mn);  // exact
 	const double den = __builtin_fma(c, mn, mx);   // exact
 	double r = __builtin_amdgcn_rcp(den);
 	r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+#if !defined(RTLFM_ATAN_ONE_NEWTON)
 	r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+#endif
 	const double t = num * r;
 	const double t2 = t * t;
 	double p = __builtin_fma(t2, RTLFM_ATAN_K7, RTLFM_ATAN_K5);
@@ -132,9 +134,8 @@ __device__ __forceinline__ int atan2_q14(int y, int x, Nodes nodes)
 	// x>=0: swap ? H - w : w ;  x<0: swap ? H + w : PIK - w
 	const double base = neg ? (swap ? RTLFM_ATAN_H : RTLFM_ATAN_PIK) : (swap ? RTLFM_ATAN_H : 0.0);
 	const double v = (neg != swap) ? base - w : base + w;
-	int n = (int)v;
-	n = (mx == 0.0) ? 0 : n;
-	return y < 0 ? -n : n;
+	// trunc toward zero is odd-symmetric: give v the sign of y, then convert
+	return (int)__builtin_copysign(v, fy);
 }
 
 // The library path, kept for A/B checks of atan2_q14 (rtlfm_gpu_selftest_atan2).
