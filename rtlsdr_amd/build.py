@@ -44,5 +44,35 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
     return OUT
 
 
+HOST = os.path.join(CSRC, "host")
+SHIM_OUT = os.path.join(HOST, "librtlsdr_file.so")
+CLI_OUT = os.path.join(HOST, "rtl_fm_hip")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> tuple[str, str]:
+    """The file-backed librtlsdr device layer (26 rtlsdr_* symbols) and the rtl_fm-shaped
+    CLI that sits on it and on librtlfm_hip.so.  Plain gcc/g++."""
+    def stale(out, srcs):
+        return force or not os.path.exists(out) or any(os.path.getmtime(x) > os.path.getmtime(out) for x in srcs)
+    inc = os.path.join(CSRC, "..", "..", "include")
+    shim_src = os.path.join(HOST, "rtlsdr_file.c")
+    if stale(SHIM_OUT, [shim_src, os.path.join(inc, "rtlsdr_file.h")]):
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", SHIM_OUT, shim_src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    cli_src = os.path.join(HOST, "rtl_fm_hip.cpp")
+    if stale(CLI_OUT, [cli_src, SHIM_OUT, OUT, os.path.join(inc, "rtlfm_hip.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI_OUT, cli_src,
+               "-L" + HOST, "-L" + CSRC, "-lrtlsdr_file", "-lrtlfm_hip", "-lpthread",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib",
+               "-Wl,--allow-shlib-undefined"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return SHIM_OUT, CLI_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

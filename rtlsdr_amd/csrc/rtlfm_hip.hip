@@ -687,16 +687,14 @@ extern "C" int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint3
 {
 	if (!h || !iq || stream < 0 || stream >= h->nstreams) return -EINVAL;
 	if (len != h->cfg.block_len) return -EINVAL;
-	int slot;
-	{
-		std::lock_guard<std::mutex> g(h->push_mu);
-		int r = ensure_push_buffers(h);
-		if (r < 0) return r;
-		if (h->pushed[stream] >= h->cap_blocks) return -ENOSPC;
-		slot = h->pushed[stream]++;
-	}
-	// the caller's buffer goes back to the USB queue the moment we return
-	// (src/librtlsdr.c:2705-2707): copy now
+	// The copy happens under the lock: rtlfm_gpu_run() on another thread must see
+	// either the whole buffer or none of it.  The caller's buffer goes back to the
+	// USB queue the moment we return (src/librtlsdr.c:2705-2707).
+	std::lock_guard<std::mutex> g(h->push_mu);
+	int r = ensure_push_buffers(h);
+	if (r < 0) return r;
+	if (h->pushed[stream] >= h->cap_blocks) return -ENOSPC;
+	const int slot = h->pushed[stream]++;
 	memcpy(h->h_stage + ((size_t)stream * h->cap_blocks + slot) * len, iq, len);
 	return 0;
 }
@@ -705,7 +703,10 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 {
 	if (!h) return -EINVAL;
 	int nb;
+	const size_t stride = (size_t)h->cap_blocks * h->cfg.block_len;
 	{
+		// take the queued buffers: the staging ring is copied to HBM before the lock
+		// is released, so callbacks may refill it while the kernels run
 		std::lock_guard<std::mutex> g(h->push_mu);
 		int r = ensure_push_buffers(h);
 		if (r < 0) return r;
@@ -713,22 +714,18 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 		for (int v : h->pushed)
 			if (v != nb) return -EAGAIN;
 		if (nb == 0) return -EAGAIN;
+		HIP_TRY(hipSetDevice(h->device));
+		if (nb == h->cap_blocks) {
+			HIP_TRY(hipMemcpyAsync(h->d_in, h->h_stage, stride * h->nstreams, hipMemcpyHostToDevice, h->stream));
+		} else {
+			HIP_TRY(hipMemcpy2DAsync(h->d_in, stride, h->h_stage, stride, (size_t)nb * h->cfg.block_len,
+			                         h->nstreams, hipMemcpyHostToDevice, h->stream));
+		}
+		HIP_TRY(hipStreamSynchronize(h->stream));
 		std::fill(h->pushed.begin(), h->pushed.end(), 0);
 	}
-	HIP_TRY(hipSetDevice(h->device));
-	const size_t stride = (size_t)h->cap_blocks * h->cfg.block_len;
-	if (nb == h->cap_blocks) {
-		HIP_TRY(hipMemcpyAsync(h->d_in, h->h_stage, stride * h->nstreams, hipMemcpyHostToDevice, h->stream));
-	} else {
-		HIP_TRY(hipMemcpy2DAsync(h->d_in, stride, h->h_stage, stride, (size_t)nb * h->cfg.block_len,
-		                         h->nstreams, hipMemcpyHostToDevice, h->stream));
-	}
 	h->last_run_blocks = nb;
-	int r = rtlfm_gpu_run_device(h, h->d_in, stride, nb, h->d_result, h->rstride, h->d_result_len);
-	if (r < 0) return r;
-	// the staging ring may be refilled once the H2D copy has been consumed
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	return 0;
+	return rtlfm_gpu_run_device(h, h->d_in, stride, nb, h->d_result, h->rstride, h->d_result_len);
 }
 
 extern "C" int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n)

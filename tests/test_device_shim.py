@@ -1,0 +1,109 @@
+"""The file-backed rtlsdr_* device layer (SURVEY.md §8b "device shim"): exports the
+26 symbols rtl_fm / rtl_power / convenience link against, and behaves like the
+reference's reader where a tool can observe it (src/librtlsdr.c:2826-2952)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rtlsdr_amd import build as hipbuild
+
+SYMS = """rtlsdr_cancel_async rtlsdr_close rtlsdr_get_center_freq rtlsdr_get_device_count rtlsdr_get_device_name
+rtlsdr_get_device_usb_strings rtlsdr_get_tuner_gains rtlsdr_get_ver_id rtlsdr_get_version rtlsdr_open
+rtlsdr_read_async rtlsdr_read_sync rtlsdr_reset_buffer rtlsdr_set_agc_mode rtlsdr_set_and_get_tuner_bandwidth
+rtlsdr_set_bias_tee rtlsdr_set_center_freq rtlsdr_set_direct_sampling rtlsdr_set_ds_mode
+rtlsdr_set_freq_correction_ppb rtlsdr_set_offset_tuning rtlsdr_set_opt_string rtlsdr_set_sample_rate
+rtlsdr_set_tuner_bandwidth rtlsdr_set_tuner_gain rtlsdr_set_tuner_gain_mode""".split()
+
+CB = C.CFUNCTYPE(None, C.POINTER(C.c_ubyte), C.c_uint32, C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so, _ = hipbuild.build_host()
+    lib = C.CDLL(so)
+    lib.rtlsdr_open.argtypes = [C.POINTER(C.c_void_p), C.c_uint32]
+    lib.rtlsdr_close.argtypes = [C.c_void_p]
+    lib.rtlsdr_read_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.rtlsdr_read_async.argtypes = [C.c_void_p, CB, C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.rtlsdr_cancel_async.argtypes = [C.c_void_p]
+    lib.rtlsdr_set_center_freq.argtypes = [C.c_void_p, C.c_uint32]
+    lib.rtlsdr_get_center_freq.argtypes = [C.c_void_p]
+    lib.rtlsdr_get_center_freq.restype = C.c_uint32
+    lib.rtlsdr_set_sample_rate.argtypes = [C.c_void_p, C.c_uint32]
+    lib.rtlsdr_get_tuner_gains.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rtlsdr_get_device_name.restype = C.c_char_p
+    lib.rtlsdr_get_device_name.argtypes = [C.c_uint32]
+    return lib, so
+
+
+def test_exports_exactly_the_26_symbols(shim):
+    _, so = shim
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    have = sorted(l.split()[-1] for l in out.splitlines() if " T rtlsdr_" in l)
+    assert have == sorted(SYMS) and len(have) == 26
+
+
+def test_no_file_means_no_device(shim, monkeypatch):
+    lib, _ = shim
+    monkeypatch.delenv("RTLSDR_FILE", raising=False)
+    assert lib.rtlsdr_get_device_count() == 0
+    h = C.c_void_p()
+    assert lib.rtlsdr_open(C.byref(h), 0) < 0
+    assert lib.rtlsdr_read_async(None, CB(lambda *a: None), None, 0, 0) == -1  # NULL device
+
+
+def test_sync_and_async_reads(shim, tmp_path, monkeypatch):
+    lib, _ = shim
+    data = np.random.default_rng(1).integers(0, 256, size=16384 * 5 + 1000, dtype=np.uint8)
+    f = tmp_path / "iq.bin"
+    data.tofile(f)
+    monkeypatch.setenv("RTLSDR_FILE", str(f))
+    assert lib.rtlsdr_get_device_count() == 1 and b"file" in lib.rtlsdr_get_device_name(0)
+    h = C.c_void_p()
+    assert lib.rtlsdr_open(C.byref(h), 0) == 0
+    assert lib.rtlsdr_set_center_freq(h, 99400000) == 0 and lib.rtlsdr_get_center_freq(h) == 99400000
+    assert lib.rtlsdr_set_sample_rate(h, 2400000) == 0
+    assert lib.rtlsdr_set_sample_rate(h, 500000) < 0  # the RTL2832's invalid window (src/librtlsdr.c:1633-1637)
+    gains = (C.c_int * 64)()
+    assert lib.rtlsdr_get_tuner_gains(h, gains) > 10
+    buf = (C.c_ubyte * 4096)(); n = C.c_int()
+    assert lib.rtlsdr_read_sync(h, buf, 4096, C.byref(n)) == 0 and n.value == 4096
+    assert bytes(buf) == data[:4096].tobytes()
+    got = []
+
+    def cb(p, ln, ctx):
+        got.append(bytes(C.cast(p, C.POINTER(C.c_ubyte * ln)).contents))
+    assert lib.rtlsdr_read_async(h, CB(cb), None, 0, 16384) == 0  # returns at end of file
+    assert b"".join(got) == data[4096:].tobytes()
+    assert [len(g) for g in got[:-1]] == [16384] * (len(got) - 1) and len(got[-1]) < 16384
+    assert lib.rtlsdr_cancel_async(h) == -2  # nothing running
+    lib.rtlsdr_close(h)
+
+
+def test_cancel_from_callback_and_wav_header(shim, tmp_path, monkeypatch):
+    lib, _ = shim
+    payload = np.arange(65536, dtype=np.uint32).astype(np.uint8)
+    hdr = b"RIFF" + (36 + payload.size).to_bytes(4, "little") + b"WAVE" + b"fmt " + (16).to_bytes(4, "little") + \
+        (1).to_bytes(2, "little") + (2).to_bytes(2, "little") + (2400000).to_bytes(4, "little") + \
+        (4800000).to_bytes(4, "little") + (2).to_bytes(2, "little") + (8).to_bytes(2, "little") + \
+        b"data" + payload.size.to_bytes(4, "little")
+    f = tmp_path / "iq.wav"
+    f.write_bytes(hdr + payload.tobytes())
+    monkeypatch.setenv("RTLSDR_FILE", str(f))
+    monkeypatch.setenv("RTLSDR_FILE_LOOP", "1")
+    h = C.c_void_p()
+    assert lib.rtlsdr_open(C.byref(h), 0) == 0
+    seen = []
+
+    def cb(p, ln, ctx):
+        seen.append(bytes(C.cast(p, C.POINTER(C.c_ubyte * ln)).contents))
+        if len(seen) == 7:
+            lib.rtlsdr_cancel_async(h)
+    # buf_len not a multiple of 512 falls back to 16*32*512 (src/librtlsdr.c:2853-2855)
+    assert lib.rtlsdr_read_async(h, CB(cb), None, 3, 1000) == 0
+    assert len(seen) == 7 and all(len(s) == 262144 for s in seen)
+    assert seen[0][:16] == payload[:16].tobytes()  # header skipped; loops over the 64 KiB payload
+    lib.rtlsdr_close(h)
