@@ -31,6 +31,7 @@
 
 #include "../../../include/rtlfm_hip.h"
 #include "../../../include/rtlsdr_file.h"
+#include "wavhdr.h"
 
 namespace {
 
@@ -65,6 +66,7 @@ struct App {
 	rtlsdr_dev_t *dev = nullptr;
 	Plumbing p;
 	FILE *file = nullptr;
+	rtlamd_wave wave{};
 	int verbosity = 0;
 	uint64_t blocks_in = 0, samples_out = 0;
 };
@@ -152,6 +154,7 @@ void output_thread(App *a)
 			a->p.out_q.pop_front();
 		}
 		fwrite(pcm.data(), 2, pcm.size(), a->file);  // src/rtl_fm.c:1400
+		a->wave.data_size += 2 * (uint32_t)pcm.size();  // waveDataSize, :1401
 		a->samples_out += pcm.size();
 	}
 	fflush(a->file);
@@ -172,6 +175,7 @@ void usage()
 	        "\t[-c de-emphasis_time_constant in us: us (75), eu (50) or a number]\n"
 	        "\t[-o oversampling (default: 1)]  [-l squelch_level]  [-q rdc_block_const]\n"
 	        "\t[-W length of one buffer in units of 512 bytes (default: 32 = 16384 B)]\n"
+	        "\t[-H write a wave header with the auxi chunk SDR programs read the frequency from]\n"
 	        "\t[-d device_index] [-g gain] [-p ppm]  accepted and passed to the device layer\n"
 	        "\tfilename ('-' means stdout)\n");
 	exit(1);
@@ -187,11 +191,11 @@ int main(int argc, char **argv)
 	int rate_in = 24000, min_capture = 1000000, time_constant = 75;
 	int fifth = 0, edge = 0, dev_index = 0, gain = -100, ppm = 0;
 	uint32_t freq = 0;
-	bool have_freq = false;
+	bool have_freq = false, write_wav = false;
 	c.rate_out = 24000;
 	c.max_blocks = 8;
 	int opt;
-	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:r:p:E:F:A:M:hm:q:c:W:v")) != -1) {
+	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:r:p:E:F:A:M:hm:q:c:W:Hv")) != -1) {
 		switch (opt) {
 		case 'd': dev_index = atoi(optarg); break;
 		case 'f': freq = (uint32_t)atofs(optarg); have_freq = true; break;
@@ -242,6 +246,7 @@ int main(int argc, char **argv)
 			c.block_len = (uint32_t)v;
 			break;
 		}
+		case 'H': write_wav = true; break;
 		case 'v': a.verbosity++; break;
 		default: usage();
 		}
@@ -272,13 +277,19 @@ int main(int argc, char **argv)
 	if (r < 0) { fprintf(stderr, "rtlfm_gpu_create: %s\n", rtlfm_gpu_strerror(r)); return 2; }
 	a.file = !strcmp(filename, "-") ? stdout : fopen(filename, "wb");
 	if (!a.file) { fprintf(stderr, "Failed to open %s\n", filename); return 1; }
+	if (write_wav && a.file != stdout)  // src/rtl_fm.c:1990-1995
+		rtlamd_wave_write_header(&a.wave, (unsigned)(c.rate_out2 > 0 ? c.rate_out2 : c.rate_out), freq, 16,
+		                         c.mode == RTLFM_MODE_RAW ? 2 : 1, a.file);
 	rtlsdr_reset_buffer(a.dev);
 
 	std::thread t_out(output_thread, &a), t_demod(demod_thread, &a), t_dongle(dongle_thread, &a);
 	t_dongle.join();
 	t_demod.join();
 	t_out.join();
-	if (a.file != stdout) fclose(a.file);
+	if (a.file != stdout) {
+		if (write_wav) rtlamd_wave_finalize(&a.wave, a.file);  // src/rtl_fm.c:2041-2045
+		fclose(a.file);
+	}
 	fprintf(stderr, "%llu buffers in, %llu samples out%s\n", (unsigned long long)a.blocks_in,
 	        (unsigned long long)a.samples_out, a.p.failed ? " (FAILED)" : "");
 	rtlfm_gpu_destroy(a.gpu);

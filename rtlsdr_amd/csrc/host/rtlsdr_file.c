@@ -181,3 +181,13 @@ int rtlsdr_cancel_async(rtlsdr_dev_t *d)
 
 const char *rtlsdr_get_ver_id(void) { return "rtlsdr_amd file device"; }
 uint32_t rtlsdr_get_version(void) { return (0u << 24) | (1u << 16) | (0u << 8) | 0u; }
+
+/* ---- the WAV container helpers, exported for tools and tests (not part of the 26) ---- */
+#include "wavhdr.h"
+static struct rtlamd_wave g_wave;
+void rtlamd_wave_write_header_file(unsigned samplerate, unsigned freq, int bits, int channels, FILE *f)
+{
+	rtlamd_wave_write_header(&g_wave, samplerate, freq, bits, channels, f);
+}
+void rtlamd_wave_add_data(uint32_t nbytes) { g_wave.data_size += nbytes; }
+void rtlamd_wave_finalize_file(FILE *f) { rtlamd_wave_finalize(&g_wave, f); }

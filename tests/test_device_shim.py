@@ -107,3 +107,49 @@ def test_cancel_from_callback_and_wav_header(shim, tmp_path, monkeypatch):
     assert len(seen) == 7 and all(len(s) == 262144 for s in seen)
     assert seen[0][:16] == payload[:16].tobytes()  # header skipped; loops over the 64 KiB payload
     lib.rtlsdr_close(h)
+
+
+def test_wave_header_matches_reference_writer(shim, tmp_path, oracle_lib):
+    """§8f-2: the 120-byte RIFF/fmt/auxi/data header, field for field against the
+    reference's own wavewrite.c (compiled into oracle/_ref/libref_rtlfm.so); the two
+    SYSTEMTIME stamps are wall-clock and only checked for plausibility."""
+    lib, _ = shim
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.fwrite.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.rtlamd_wave_write_header_file.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]
+    lib.rtlamd_wave_finalize_file.argtypes = [C.c_void_p]
+    payload = bytes(range(200)) * 7
+    mine = tmp_path / "mine.wav"
+    f = libc.fopen(str(mine).encode(), b"wb")
+    lib.rtlamd_wave_write_header_file(32000, 99400000, 16, 1, f)
+    libc.fwrite(payload, 1, len(payload), f)
+    lib.rtlamd_wave_add_data(len(payload))
+    lib.rtlamd_wave_finalize_file(f)
+    libc.fclose(f)
+    a = mine.read_bytes()
+    assert len(a) == 120 + len(payload) and a[:4] == b"RIFF" and a[36:40] == b"auxi" and a[112:116] == b"data"
+    assert int.from_bytes(a[4:8], "little") == 112 + len(payload)
+    assert int.from_bytes(a[116:120], "little") == len(payload)
+    assert int.from_bytes(a[76:80], "little") == 99400000 and int.from_bytes(a[32:34], "little") == 1
+    assert 2024 <= int.from_bytes(a[44:46], "little") <= 2100
+    if not oracle_lib.have_reference():
+        return
+    ref = oracle_lib.Reference()
+    try:
+        ref.lib.waveWriteHeader.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]
+        ref.lib.waveFinalizeHeader.argtypes = [C.c_void_p]
+        theirs = tmp_path / "ref.wav"
+        f = libc.fopen(str(theirs).encode(), b"wb")
+        ref.lib.waveWriteHeader(32000, 99400000, 16, 1, f)
+        libc.fwrite(payload, 1, len(payload), f)
+        C.c_uint32.in_dll(ref.lib, "waveDataSize").value = len(payload)
+        ref.lib.waveFinalizeHeader(f)
+        libc.fclose(f)
+        b = theirs.read_bytes()
+    finally:
+        ref.close()
+    assert len(a) == len(b)
+    assert a[:44] == b[:44] and a[76:] == b[76:]  # everything but the two time stamps
