@@ -52,7 +52,40 @@ typedef struct rtlpower_cfg {
 	uint32_t buf_len;           /* bytes per read */
 } rtlpower_cfg;
 
+/*
+ * The hop plan frequency_range() builds into tunes[] (src/rtl_power.c:438-540):
+ * tune i is centred on lower + i*bw_seen + bw_seen/2 and sampled at `rate`.
+ */
+typedef struct rtlpower_plan {
+	int32_t lower, upper, max_size;  /* the three fields of -f lower:upper:bin_size (after atofs) */
+	int32_t tune_count;
+	int32_t bw_seen;                 /* bandwidth kept per hop */
+	int32_t rate;                    /* bw_used: the dongle rate of every hop */
+	int32_t bin_e;
+	int32_t downsample, downsample_passes;
+	int32_t buf_len;
+	double crop;                     /* may be forced to 0 (giant bins) */
+	double bin_size;                 /* reported "FFT bin size" */
+} rtlpower_plan;
+
 typedef struct rtlpower_gpu rtlpower_gpu;
+
+/* frequency_range() (src/rtl_power.c:438-540); `boxcar` is the global of :118 (0 after -F).
+ * Returns 0, or -E2BIG when the plan needs more than MAX_TUNES (3000) hops. */
+int rtlpower_frequency_range(int32_t lower, int32_t upper, int32_t max_size, double crop, int boxcar,
+                             rtlpower_plan *out);
+/* centre frequency of hop i (src/rtl_power.c:509) */
+int32_t rtlpower_tune_freq(const rtlpower_plan *plan, int i);
+/* the rtlpower_cfg one hop of the plan scans with */
+void rtlpower_plan_cfg(const rtlpower_plan *plan, int window, int boxcar, int comp_fir_size, int peak_hold,
+                       rtlpower_cfg *cfg);
+/*
+ * csv_dbm() (src/rtl_power.c:722-765) for hop `tune`: patches the DC bin, swaps the
+ * spectrum halves IN avg[], then formats "Hz low, Hz high, Hz step, samples, dB, dB, ...\n"
+ * (without the date/time prefix main() prints, :997-999) into out.  Returns the string
+ * length, or -ENOBUFS.  The caller clears the accumulators afterwards (rtlpower_gpu_clear).
+ */
+int rtlpower_csv_dbm(const rtlpower_plan *plan, int tune, int64_t *avg, int32_t samples, char *out, size_t cap);
 
 /* window_coefs[i] = (int)(256 * window_fn(i, length)) (src/rtl_power.c:985-988); host only */
 int rtlpower_window_coefs(int window, int length, int32_t *out);

@@ -134,3 +134,41 @@ void ref_power_clear(void)
 
 const int *ref_window_coefs(void) { return window_coefs; }
 const int16_t *ref_sinewave(void) { return Sinewave; }
+
+/* frequency_range() (src/rtl_power.c:438-540) through the reference's own code:
+ * out = {tune_count, bw_seen (from freq spacing), rate, bin_e, downsample, passes, buf_len, freq0, freq1} */
+int ref_frequency_range(const char *arg, double crop_in, int boxcar_flag, int32_t out[10], double *crop_out)
+{
+	char tmp[256];
+	strncpy(tmp, arg, sizeof(tmp) - 1); tmp[sizeof(tmp) - 1] = 0;
+	for (int i = 0; i < tune_count && i < MAX_TUNES; i++) { free(tunes[i].avg); free(tunes[i].buf8); }
+	memset(tunes, 0, sizeof(tunes));
+	tune_count = 0;
+	boxcar = boxcar_flag;
+	frequency_range(tmp, crop_in);
+	out[0] = tune_count; out[1] = tune_count > 1 ? tunes[1].freq - tunes[0].freq : 0;
+	out[2] = tunes[0].rate; out[3] = tunes[0].bin_e; out[4] = tunes[0].downsample;
+	out[5] = tunes[0].downsample_passes; out[6] = tunes[0].buf_len; out[7] = tunes[0].freq;
+	out[8] = tune_count > 1 ? tunes[tune_count - 1].freq : tunes[0].freq;
+	*crop_out = tunes[0].crop;
+	return 0;
+}
+
+/* csv_dbm() (src/rtl_power.c:722-765) on tunes[0] as frequency_range left it, with the given
+ * accumulators; the line is captured from the reference's FILE* `file`. */
+int ref_csv_dbm(int tune, const int64_t *avg, int32_t samples, char *out, size_t cap)
+{
+	struct tuning_state *ts = &tunes[tune];
+	int bins = 1 << ts->bin_e;
+	char *mem = NULL; size_t sz = 0;
+	for (int i = 0; i < bins; i++) ts->avg[i] = (long)avg[i];
+	ts->samples = samples;
+	file = open_memstream(&mem, &sz);
+	csv_dbm(ts);
+	fclose(file);
+	file = NULL;
+	if (sz + 1 > cap) { free(mem); return -1; }
+	memcpy(out, mem, sz + 1);
+	free(mem);
+	return (int)sz;
+}

@@ -47,6 +47,7 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
 HOST = os.path.join(CSRC, "host")
 SHIM_OUT = os.path.join(HOST, "librtlsdr_file.so")
 CLI_OUT = os.path.join(HOST, "rtl_fm_hip")
+POWER_CLI_OUT = os.path.join(HOST, "rtl_power_hip")
 
 
 def build_host(force: bool = False, verbose: bool = False) -> tuple[str, str]:
@@ -65,6 +66,15 @@ def build_host(force: bool = False, verbose: bool = False) -> tuple[str, str]:
     if stale(CLI_OUT, [cli_src, SHIM_OUT, OUT, os.path.join(inc, "rtlfm_hip.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI_OUT, cli_src,
                "-L" + HOST, "-L" + CSRC, "-lrtlsdr_file", "-lrtlfm_hip", "-lpthread",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib",
+               "-Wl,--allow-shlib-undefined"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    pw_src = os.path.join(HOST, "rtl_power_hip.cpp")
+    if stale(POWER_CLI_OUT, [pw_src, SHIM_OUT, OUT, os.path.join(inc, "rtlpower_hip.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", POWER_CLI_OUT, pw_src,
+               "-L" + HOST, "-L" + CSRC, "-lrtlsdr_file", "-lrtlfm_hip", "-lm",
                "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib",
                "-Wl,--allow-shlib-undefined"]
         if verbose:

@@ -182,8 +182,24 @@ _SIGNATURES = [
     ("rtlfm_gpu_version", C.c_int, []),
 ]
 
+class RtlpowerPlan(C.Structure):
+    """``rtlpower_plan`` — frequency_range()'s hop plan (reference src/rtl_power.c:438-540)."""
+
+    _fields_ = [("lower", C.c_int32), ("upper", C.c_int32), ("max_size", C.c_int32), ("tune_count", C.c_int32),
+                ("bw_seen", C.c_int32), ("rate", C.c_int32), ("bin_e", C.c_int32), ("downsample", C.c_int32),
+                ("downsample_passes", C.c_int32), ("buf_len", C.c_int32), ("crop", C.c_double),
+                ("bin_size", C.c_double)]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # ... and include/rtlpower_hip.h
 _POWER_SIGNATURES = [
+    ("rtlpower_frequency_range", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int, _P(RtlpowerPlan)]),
+    ("rtlpower_tune_freq", C.c_int32, [_P(RtlpowerPlan), C.c_int]),
+    ("rtlpower_plan_cfg", None, [_P(RtlpowerPlan), C.c_int, C.c_int, C.c_int, C.c_int, _P(RtlpowerCfg)]),
+    ("rtlpower_csv_dbm", C.c_int, [_P(RtlpowerPlan), C.c_int, C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]),
     ("rtlpower_window_coefs", C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     ("rtlpower_gpu_create", C.c_int, [_P(RtlpowerCfg), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("rtlpower_gpu_destroy", C.c_int, [C.c_void_p]),

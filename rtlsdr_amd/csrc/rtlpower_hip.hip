@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/rtlpower_hip.h"
@@ -78,6 +79,108 @@ extern "C" int rtlpower_window_coefs(int window, int length, int32_t *out)
 	for (int i = 0; i < length; i++)
 		out[i] = (int32_t)(256 * window_fn(window, i, length));  // src/rtl_power.c:985-988
 	return 0;
+}
+
+// ---- planner and CSV emitter (host only) ------------------------------------------
+
+extern "C" int rtlpower_frequency_range(int32_t lower, int32_t upper, int32_t max_size, double crop, int boxcar,
+                                        rtlpower_plan *out)
+{
+	// frequency_range(), src/rtl_power.c:438-540; MAXIMUM_RATE / MINIMUM_RATE :78-79, MAX_TUNES :111
+	const int kMaxRate = 2800000, kMinRate = 1000000, kMaxTunes = 3000, kDefaultBuf = 16384;
+	if (!out) return -EINVAL;
+	int tune_count = 0, bw_seen = 0, bw_used = 0, downsample = 1, passes = 0, bin_e = 0;
+	double bin_size = 0;
+	for (int i = 1; i < 1500; i++) {  // evenly sized hops, as close to the maximum rate as possible
+		bw_seen = (upper - lower) / i;
+		bw_used = (int)((double)bw_seen / (1.0 - crop));
+		if (bw_used > kMaxRate) continue;
+		tune_count = i;
+		break;
+	}
+	if (bw_used < kMinRate) {  // small bandwidth: one hop, decimated
+		tune_count = 1;
+		downsample = kMaxRate / bw_used;
+		bw_used = bw_used * downsample;
+	}
+	if (!boxcar && downsample > 1) {
+		passes = (int)log2((double)downsample);
+		downsample = 1 << passes;
+		bw_used = (int)((double)(bw_seen * downsample) / (1.0 - crop));
+	}
+	for (int i = 1; i <= 21; i++) {  // power-of-two bins no wider than asked
+		bin_e = i;
+		bin_size = (double)bw_used / (double)((1 << i) * downsample);
+		if (bin_size <= (double)max_size) break;
+	}
+	if (max_size >= kMinRate) {  // giant bins: rms_power per hop
+		bw_seen = max_size;
+		bw_used = max_size;
+		tune_count = (upper - lower) / bw_seen;
+		bin_e = 0;
+		crop = 0;
+	}
+	if (tune_count > kMaxTunes) return -E2BIG;
+	int buf_len = 2 * (1 << bin_e) * downsample;
+	if (buf_len < kDefaultBuf) buf_len = kDefaultBuf;
+	out->lower = lower; out->upper = upper; out->max_size = max_size;
+	out->tune_count = tune_count; out->bw_seen = bw_seen; out->rate = bw_used; out->bin_e = bin_e;
+	out->downsample = downsample; out->downsample_passes = passes; out->buf_len = buf_len;
+	out->crop = crop; out->bin_size = bin_size;
+	return 0;
+}
+
+extern "C" int32_t rtlpower_tune_freq(const rtlpower_plan *p, int i)
+{
+	return p->lower + i * p->bw_seen + p->bw_seen / 2;  // src/rtl_power.c:509
+}
+
+extern "C" void rtlpower_plan_cfg(const rtlpower_plan *p, int window, int boxcar, int comp_fir_size, int peak_hold,
+                                  rtlpower_cfg *c)
+{
+	memset(c, 0, sizeof(*c));
+	c->bin_e = p->bin_e; c->window = window; c->downsample = p->downsample;
+	c->downsample_passes = p->downsample_passes; c->boxcar = boxcar; c->comp_fir_size = comp_fir_size;
+	c->peak_hold = peak_hold; c->buf_len = (uint32_t)p->buf_len;
+}
+
+extern "C" int rtlpower_csv_dbm(const rtlpower_plan *p, int tune, int64_t *avg, int32_t samples, char *out, size_t cap)
+{
+	// csv_dbm(), src/rtl_power.c:722-765
+	if (!p || !avg || !out) return -EINVAL;
+	const int len = 1 << p->bin_e, ds = p->downsample;
+	const int freq = rtlpower_tune_freq(p, tune);
+	if (p->bin_e > 0) {
+		avg[0] = avg[1];  // "nuke DC component"
+		for (int i = 0; i < len / 2; i++) {  // the FFT is translated by 180 degrees
+			int64_t t = avg[i]; avg[i] = avg[i + len / 2]; avg[i + len / 2] = t;
+		}
+	}
+	std::string sres;
+	char tmp[96];
+	const int bin_count = (int)((double)len * (1.0 - p->crop));
+	const int bw2 = (int)(((double)p->rate * (double)bin_count) / (len * 2 * ds));
+	snprintf(tmp, sizeof(tmp), "%i, %i, %.2f, %i, ", freq - bw2, freq + bw2, (double)p->rate / (double)(len * ds), samples);
+	sres += tmp;
+	const int i1 = 0 + (int)((double)len * p->crop * 0.5);
+	const int i2 = (len - 1) - (int)((double)len * p->crop * 0.5);
+	double dbm;
+	for (int i = i1; i <= i2; i++) {
+		dbm = (double)avg[i];
+		dbm /= (double)p->rate;
+		dbm /= (double)samples;
+		dbm = 10 * log10(dbm);
+		snprintf(tmp, sizeof(tmp), "%.2f, ", dbm);
+		sres += tmp;
+	}
+	dbm = (double)avg[i2] / ((double)p->rate * (double)samples);
+	if (p->bin_e == 0) dbm = ((double)avg[0] / ((double)p->rate * (double)samples));
+	dbm = 10 * log10(dbm);
+	snprintf(tmp, sizeof(tmp), "%.2f\n", dbm);
+	sres += tmp;
+	if (sres.size() + 1 > cap) return -ENOBUFS;
+	memcpy(out, sres.c_str(), sres.size() + 1);
+	return (int)sres.size();
 }
 
 static int validate(const rtlpower_cfg *c)

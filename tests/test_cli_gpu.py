@@ -50,3 +50,44 @@ def test_cli_output_matches_oracle(oracle_lib, tmp_path, argv, plan, fs):
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     exact_needed = cfg.mode == MODE_FM and cfg.custom_atan != ATAN_STD
     assert d.max() <= (0 if exact_needed else 1) and (d != 0).mean() <= 1e-4, (argv, int(d.max()), int((d != 0).sum()))
+
+
+@pytest.mark.parametrize("argv,passes", [
+    (["-f", "100M:102.048M:125", "-w", "hamming", "-1"], 4),          # BASELINE config 4's command line
+    (["-f", "88M:96M:10k", "-w", "blackman", "-c", "20%", "-1"], 3),  # 3 hops, cropped
+    (["-f", "433M:434M:1k", "-F", "9", "-1"], 2),                      # one hop, fifth_order /2 + FIR9
+    (["-f", "24M:34M:1M", "-1"], 2),                                   # giant bins: rms_power per hop
+])
+def test_rtl_power_cli_matches_oracle(oracle_lib, tmp_path, argv, passes):
+    from rtlsdr_amd import capi
+    lib = capi.load()
+    cli = os.path.join(os.path.dirname(hipbuild.CLI_OUT), "rtl_power_hip")
+    hipbuild.build_host()
+    farg = argv[argv.index("-f") + 1]
+    lo, hi, step = (int(float(t[:-1]) * {"k": 1e3, "M": 1e6}[t[-1]]) if t[-1] in "kM" else int(float(t)) for t in farg.split(":"))
+    crop = 0.2 if "-c" in argv else 0.0
+    boxcar = 0 if "-F" in argv else 1
+    win = {"hamming": 1, "blackman": 2}.get(argv[argv.index("-w") + 1], 0) if "-w" in argv else 0
+    plan = capi.RtlpowerPlan()
+    assert lib.rtlpower_frequency_range(lo, hi, step, crop, boxcar, C.byref(plan)) == 0
+    cfg = capi.RtlpowerCfg()
+    lib.rtlpower_plan_cfg(C.byref(plan), win, boxcar, 9 if "-F" in argv else 0, 0, C.byref(cfg))
+    L, T = plan.buf_len, plan.tune_count
+    iq = synth.fm_iq_u8(1, L // 2 * T * passes, fs=2.048e6, dev_hz=40e3, seed=909)[0]
+    src = tmp_path / "capture.bin"
+    iq.tofile(src)
+    out = tmp_path / "power.csv"
+    env = dict(os.environ, RTLSDR_FILE=str(src), RTLPOWER_PASSES=str(passes))
+    r = subprocess.run([cli] + argv + [str(out)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = out.read_text().splitlines()
+    assert len(lines) == T
+    # the file is read hop after hop, pass after pass
+    reads = iq.reshape(passes, T, L)
+    for i in range(T):
+        avg, n = oracle_lib.power_scan_batch(cfg, np.ascontiguousarray(reads[:, i, :]).reshape(1, -1))
+        buf = C.create_string_buffer(1 << 20)
+        a = avg[0].copy()
+        assert lib.rtlpower_csv_dbm(C.byref(plan), i, a.ctypes.data, int(n[0]), buf, len(buf)) > 0
+        got = lines[i].split(", ", 2)[2]  # drop "date, time, "
+        assert got + "\n" == buf.value.decode(), (i, got[:80], buf.value[:80])

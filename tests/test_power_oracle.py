@@ -79,3 +79,58 @@ def test_window_multiply_wraps(oracle_lib):
     iq = np.full(16384, 255, dtype=np.uint8)  # 255-127 = 128 everywhere
     avg, n = oracle_lib.power_scan_batch(cfg, iq[None, :])
     assert n[0] == 16384 // 32 and avg[0].sum() > 0
+
+
+PLAN_CASES = [
+    # -f lower:upper:bin, crop, boxcar
+    ("100M:102.048M:125", 0.0, 1), ("88M:108M:125k", 0.0, 1), ("88M:108M:1k", 0.25, 1),
+    ("433M:434M:1k", 0.0, 1), ("433M:434M:1k", 0.0, 0), ("144M:146M:500", 0.1, 0),
+    ("24M:1700M:1M", 0.0, 1), ("118M:137M:25k", 0.3, 1), ("100M:100.5M:50", 0.0, 1),
+    ("100M:100.2M:100", 0.0, 0), ("50M:60M:2M", 0.0, 1),
+]
+
+
+def _atofs(t):
+    mul = {"k": 1e3, "M": 1e6, "G": 1e9}.get(t[-1])
+    return float(t[:-1]) * mul if mul else float(t)
+
+
+@pytest.mark.parametrize("arg,crop,boxcar", PLAN_CASES)
+def test_planner_and_csv_match_reference(oracle_lib, arg, crop, boxcar):
+    """§8f-3: rtlpower_frequency_range / rtlpower_csv_dbm (host side of the product library)
+    against the reference's frequency_range() and csv_dbm() compiled in place."""
+    if not oracle_lib.have_power_reference():
+        pytest.skip("oracle/_ref not built here")
+    from rtlsdr_amd import capi
+    from rtlsdr_amd import build as hipbuild
+    hipbuild.build()
+    lib = capi.load()
+    lo, hi, step = (int(_atofs(x)) for x in arg.split(":"))
+    plan = capi.RtlpowerPlan()
+    assert lib.rtlpower_frequency_range(lo, hi, step, crop, boxcar, C.byref(plan)) == 0
+    ref = oracle_lib.PowerReference()
+    try:
+        ref.lib.ref_frequency_range.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        ref.lib.ref_csv_dbm.argtypes = [C.c_int, C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]
+        o = np.zeros(10, dtype=np.int32); rc = C.c_double()
+        ref.lib.ref_frequency_range(arg.encode(), crop, boxcar, o.ctypes.data, C.byref(rc))
+        last = plan.tune_count - 1
+        assert (plan.tune_count, plan.rate, plan.bin_e, plan.downsample, plan.downsample_passes, plan.buf_len,
+                lib.rtlpower_tune_freq(C.byref(plan), 0), lib.rtlpower_tune_freq(C.byref(plan), last), plan.crop) == \
+               (o[0], o[2], o[3], o[4], o[5], o[6], o[7], o[8], rc.value)
+        if plan.tune_count > 1:
+            assert plan.bw_seen == o[1]
+        if plan.bin_e > 14:
+            return
+        # csv line for hop 0 and the last hop, from the same accumulators
+        rng = np.random.default_rng(3)
+        avg = rng.integers(1, 1 << 40, size=1 << plan.bin_e).astype(np.int64)
+        for tune in {0, last}:
+            mine_avg = avg.copy()
+            buf = C.create_string_buffer(1 << 20)
+            n = lib.rtlpower_csv_dbm(C.byref(plan), tune, mine_avg.ctypes.data, 77, buf, len(buf))
+            rbuf = C.create_string_buffer(1 << 20)
+            rn = ref.lib.ref_csv_dbm(tune, avg.ctypes.data, 77, rbuf, len(rbuf))
+            assert n == rn and buf.value == rbuf.value
+    finally:
+        ref.close()
