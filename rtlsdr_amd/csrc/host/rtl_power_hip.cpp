@@ -8,6 +8,7 @@
 // Deterministic replay: RTLPOWER_PASSES=<n> reports after exactly n passes over the
 // hops instead of by wall clock (the file device has no real-time pacing).
 #include <getopt.h>
+#include <cmath>
 
 #include <cerrno>
 #include <cstdio>
