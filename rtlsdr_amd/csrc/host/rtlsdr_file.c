@@ -11,11 +11,25 @@
  */
 #include "../../../include/rtlsdr_file.h"
 
+#include <arpa/inet.h>
+#include <netdb.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
+/*
+ * RTLSDR_FILE=tcp://host:port makes the device an rtl_tcp client instead
+ * (reference protocol_rtl_tcp.txt, src/rtl_tcp.c:86-90, 378-460, include/rtl_tcp.h:34-50):
+ * the server first sends the 12-byte dongle_info {"RTL0", tuner type, gain count}
+ * (big endian), then raw u8 I,Q; every setter becomes a 5-byte command
+ * {id, 32-bit big-endian parameter}.  This is how thousands of remote dongles
+ * can feed one GPU box.
+ */
 struct rtlsdr_dev {
+	int sock;               /* >= 0: rtl_tcp client */
+	uint32_t tuner_type, tuner_gain_count;
 	FILE *f;
 	long data_start;
 	uint32_t freq, rate, bw;
@@ -41,8 +55,53 @@ int rtlsdr_get_device_usb_strings(uint32_t index, char *manufact, char *product,
 {
 	if (index != 0 || !env_path()) return -2;
 	if (manufact) strcpy(manufact, "rtlsdr_amd");
-	if (product) strcpy(product, "file");
+	if (product) strcpy(product, !strncmp(env_path(), "tcp://", 6) ? "rtl_tcp" : "file");
 	if (serial) strcpy(serial, "00000001");
+	return 0;
+}
+
+static int tcp_command(rtlsdr_dev_t *d, unsigned char id, uint32_t param)
+{
+	unsigned char c[5] = {id, (unsigned char)(param >> 24), (unsigned char)(param >> 16),
+	                      (unsigned char)(param >> 8), (unsigned char)param};
+	if (d->sock < 0) return 0;
+	return send(d->sock, c, 5, MSG_NOSIGNAL) == 5 ? 0 : -1;
+}
+
+static int tcp_open(rtlsdr_dev_t **out, const char *url)
+{
+	char host[256];
+	const char *colon = strrchr(url, ':');
+	if (!colon || (size_t)(colon - url) >= sizeof(host)) return -1;
+	memcpy(host, url, (size_t)(colon - url));
+	host[colon - url] = 0;
+	struct addrinfo hints, *res = NULL;
+	memset(&hints, 0, sizeof(hints));
+	hints.ai_family = AF_UNSPEC;
+	hints.ai_socktype = SOCK_STREAM;
+	if (getaddrinfo(host, colon + 1, &hints, &res) != 0 || !res) return -1;
+	int s = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+	if (s < 0 || connect(s, res->ai_addr, res->ai_addrlen) != 0) {
+		if (s >= 0) close(s);
+		freeaddrinfo(res);
+		return -1;
+	}
+	freeaddrinfo(res);
+	unsigned char info[12];
+	size_t got = 0;
+	while (got < 12) {
+		ssize_t n = recv(s, info + got, 12 - got, 0);
+		if (n <= 0) { close(s); return -1; }
+		got += (size_t)n;
+	}
+	if (memcmp(info, "RTL0", 4) != 0) { fprintf(stderr, "rtlsdr_file: not an rtl_tcp server\n"); close(s); return -1; }
+	rtlsdr_dev_t *d = (rtlsdr_dev_t *)calloc(1, sizeof(*d));
+	d->sock = s;
+	d->tuner_type = ((uint32_t)info[4] << 24) | (info[5] << 16) | (info[6] << 8) | info[7];
+	d->tuner_gain_count = ((uint32_t)info[8] << 24) | (info[9] << 16) | (info[10] << 8) | info[11];
+	d->rate = 2048000;
+	d->freq = 100000000;
+	*out = d;
 	return 0;
 }
 
@@ -50,9 +109,11 @@ int rtlsdr_open(rtlsdr_dev_t **out, uint32_t index)
 {
 	const char *path = env_path();
 	if (!out || index != 0 || !path) return -1;
+	if (!strncmp(path, "tcp://", 6)) return tcp_open(out, path + 6);
 	FILE *f = fopen(path, "rb");
 	if (!f) { perror(path); return -1; }
 	rtlsdr_dev_t *d = (rtlsdr_dev_t *)calloc(1, sizeof(*d));
+	d->sock = -1;
 	d->f = f;
 	d->rate = 2048000;
 	d->freq = 100000000;
@@ -79,37 +140,38 @@ int rtlsdr_close(rtlsdr_dev_t *d)
 {
 	if (!d) return -1;
 	if (d->f) fclose(d->f);
+	if (d->sock >= 0) close(d->sock);
 	free(d);
 	return 0;
 }
 
-int rtlsdr_set_center_freq(rtlsdr_dev_t *d, uint32_t freq) { if (!d) return -1; d->freq = freq; return 0; }
+int rtlsdr_set_center_freq(rtlsdr_dev_t *d, uint32_t freq) { if (!d) return -1; d->freq = freq; return tcp_command(d, 0x01, freq); }
 uint32_t rtlsdr_get_center_freq(rtlsdr_dev_t *d) { return d ? d->freq : 0; }
-int rtlsdr_set_freq_correction_ppb(rtlsdr_dev_t *d, int ppb) { if (!d) return -1; d->ppb = ppb; return 0; }
+int rtlsdr_set_freq_correction_ppb(rtlsdr_dev_t *d, int ppb) { if (!d) return -1; d->ppb = ppb; return tcp_command(d, 0x05, (uint32_t)(ppb / 1000)); }
 
 int rtlsdr_get_tuner_gains(rtlsdr_dev_t *d, int *gains)
 {
 	/* tenths of a dB, an R820T-like ladder so nearest_gain() has something to pick from */
 	static const int table[] = {0, 9, 14, 27, 37, 77, 87, 125, 144, 157, 166, 197, 207, 229, 254, 280,
 	                            297, 328, 338, 364, 372, 386, 402, 421, 434, 439, 445, 480, 496};
-	const int n = (int)(sizeof(table) / sizeof(table[0]));
+	int n = (int)(sizeof(table) / sizeof(table[0]));
 	if (!d) return -1;
 	if (gains) memcpy(gains, table, sizeof(table));
 	return n;
 }
 
-int rtlsdr_set_tuner_gain(rtlsdr_dev_t *d, int gain) { if (!d) return -1; d->gain = gain; return 0; }
+int rtlsdr_set_tuner_gain(rtlsdr_dev_t *d, int gain) { if (!d) return -1; d->gain = gain; return tcp_command(d, 0x04, (uint32_t)gain); }
 
 int rtlsdr_set_and_get_tuner_bandwidth(rtlsdr_dev_t *d, uint32_t bw, uint32_t *applied_bw, int apply_bw)
 {
 	if (!d) return -1;
 	if (apply_bw) d->bw = bw;
 	if (applied_bw) *applied_bw = bw;
-	return 0;
+	return apply_bw ? tcp_command(d, 0x40, bw) : 0;
 }
 
 int rtlsdr_set_tuner_bandwidth(rtlsdr_dev_t *d, uint32_t bw) { return rtlsdr_set_and_get_tuner_bandwidth(d, bw, NULL, 1); }
-int rtlsdr_set_tuner_gain_mode(rtlsdr_dev_t *d, int manual) { if (!d) return -1; d->gain_mode = manual; return 0; }
+int rtlsdr_set_tuner_gain_mode(rtlsdr_dev_t *d, int manual) { if (!d) return -1; d->gain_mode = manual; return tcp_command(d, 0x03, (uint32_t)manual); }
 
 int rtlsdr_set_sample_rate(rtlsdr_dev_t *d, uint32_t rate)
 {
@@ -117,19 +179,28 @@ int rtlsdr_set_sample_rate(rtlsdr_dev_t *d, uint32_t rate)
 	/* the reference's validity window, src/librtlsdr.c:1633-1637 */
 	if (rate <= 225000 || rate > 3200000 || (rate > 300000 && rate <= 900000)) return -22;
 	d->rate = rate;
-	return 0;
+	return tcp_command(d, 0x02, rate);
 }
 
-int rtlsdr_set_agc_mode(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->agc = on; return 0; }
-int rtlsdr_set_direct_sampling(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->direct = on; return 0; }
+int rtlsdr_set_agc_mode(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->agc = on; return tcp_command(d, 0x08, (uint32_t)on); }
+int rtlsdr_set_direct_sampling(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->direct = on; return tcp_command(d, 0x09, (uint32_t)on); }
 int rtlsdr_set_ds_mode(rtlsdr_dev_t *d, enum rtlsdr_ds_mode mode, uint32_t thr) { (void)thr; if (!d) return -1; d->direct = (int)mode; return 0; }
-int rtlsdr_set_offset_tuning(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->offset = on; return 0; }
+int rtlsdr_set_offset_tuning(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->offset = on; return tcp_command(d, 0x0A, (uint32_t)on); }
 int rtlsdr_set_bias_tee(rtlsdr_dev_t *d, int on) { if (!d) return -1; d->bias = on; return 0; }
 int rtlsdr_set_opt_string(rtlsdr_dev_t *d, const char *opts, int verbose) { (void)opts; (void)verbose; return d ? 0 : -1; }
 int rtlsdr_reset_buffer(rtlsdr_dev_t *d) { return d ? 0 : -1; }
 
 static size_t read_some(rtlsdr_dev_t *d, unsigned char *buf, size_t len)
 {
+	if (d->sock >= 0) {
+		size_t have = 0;
+		while (have < len) {
+			ssize_t n = recv(d->sock, buf + have, len - have, 0);
+			if (n <= 0) break;  /* server closed: end of stream */
+			have += (size_t)n;
+		}
+		return have;
+	}
 	size_t got = fread(buf, 1, len, d->f);
 	while (got < len && d->loop) {
 		if (fseek(d->f, d->data_start, SEEK_SET) != 0) break;

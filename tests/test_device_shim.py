@@ -153,3 +153,52 @@ def test_wave_header_matches_reference_writer(shim, tmp_path, oracle_lib):
         ref.close()
     assert len(a) == len(b)
     assert a[:44] == b[:44] and a[76:] == b[76:]  # everything but the two time stamps
+
+
+def test_rtl_tcp_source(shim, monkeypatch):
+    """§8f-4: RTLSDR_FILE=tcp://host:port speaks rtl_tcp's wire format (protocol_rtl_tcp.txt):
+    12-byte "RTL0" dongle_info, then raw u8 IQ; setters become 5-byte big-endian commands."""
+    import socket
+    import threading
+    lib, _ = shim
+    payload = np.random.default_rng(4).integers(0, 256, size=16384 * 3 + 700, dtype=np.uint8).tobytes()
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    port = srv.getsockname()[1]
+    commands = []
+
+    def serve():
+        c, _ = srv.accept()
+        c.sendall(b"RTL0" + (5).to_bytes(4, "big") + (29).to_bytes(4, "big"))  # R820T, 29 gains
+        c.settimeout(2.0)
+        buf = b""
+        try:
+            while len(buf) < 15:  # three commands
+                buf += c.recv(64)
+        except OSError:
+            pass
+        commands.extend(buf[i:i + 5] for i in range(0, len(buf) - len(buf) % 5, 5))
+        c.sendall(payload)
+        c.close()
+    t = threading.Thread(target=serve, daemon=True)
+    t.start()
+    monkeypatch.setenv("RTLSDR_FILE", f"tcp://127.0.0.1:{port}")
+    h = C.c_void_p()
+    assert lib.rtlsdr_open(C.byref(h), 0) == 0
+    assert lib.rtlsdr_set_center_freq(h, 99400000) == 0
+    assert lib.rtlsdr_set_sample_rate(h, 2400000) == 0
+    lib.rtlsdr_set_agc_mode.argtypes = [C.c_void_p, C.c_int]
+    assert lib.rtlsdr_set_agc_mode(h, 1) == 0
+    got = []
+
+    def cb(p, ln, ctx):
+        got.append(bytes(C.cast(p, C.POINTER(C.c_ubyte * ln)).contents))
+    assert lib.rtlsdr_read_async(h, CB(cb), None, 0, 16384) == 0  # ends when the server closes
+    t.join(5)
+    lib.rtlsdr_close(h)
+    srv.close()
+    assert b"".join(got) == payload
+    assert commands[0] == b"\x01" + (99400000).to_bytes(4, "big")
+    assert commands[1] == b"\x02" + (2400000).to_bytes(4, "big")
+    assert commands[2] == b"\x08" + (1).to_bytes(4, "big")
