@@ -415,21 +415,25 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 				for (int k = 0; k < 8; k++) cur[k] = src[k];
 			}
 			RTLFM_MARK("xor_done");
-			uint32_t G[34], H[34];  // G[-2..31]
+			// Outputs are produced eight at a time so that only a window of the
+			// gathered registers is live (keeps the kernel at 4 waves per SIMD).
+			{
+				uint32_t g0 = __builtin_amdgcn_perm(sx[0], sx[1], p.taps.selG), g1 = __builtin_amdgcn_perm(sx[1], sx[2], p.taps.selG);
+				uint32_t h0 = __builtin_amdgcn_perm(sx[0], sx[1], p.taps.selH), h1 = __builtin_amdgcn_perm(sx[1], sx[2], p.taps.selH);
 #pragma unroll
-			for (int k = 0; k < 34; k++) {
-				G[k] = __builtin_amdgcn_perm(sx[k], sx[k + 1], p.taps.selG);
-				H[k] = __builtin_amdgcn_perm(sx[k], sx[k + 1], p.taps.selH);
-			}
-#pragma unroll
-			for (int m = 0; m < 32; m++) {
-				const int par = m & 1;
-				int ai = dot4_first(G[m + 2], p.taps.ti[par][0]);
-				ai = __builtin_amdgcn_sdot4((int)G[m], p.taps.ti[par][1], ai, false);
-				int aq = dot4_first(H[m + 2], p.taps.tq[par][0]);
-				aq = __builtin_amdgcn_sdot4((int)H[m], p.taps.tq[par][1], aq, false);
-				uint32_t pk = __builtin_amdgcn_perm((uint32_t)aq, (uint32_t)ai, 0x05040100u);
-				Y0[m] = as_u32(as_s2(pk) >> 4);
+				for (int m = 0; m < 32; m++) {
+					// G[m+2] in the notation above = perm(S[m-1], S[m]) = perm(sx[m+2], sx[m+3])
+					const uint32_t g2 = __builtin_amdgcn_perm(sx[m + 2], sx[m + 3], p.taps.selG);
+					const uint32_t h2 = __builtin_amdgcn_perm(sx[m + 2], sx[m + 3], p.taps.selH);
+					const int par = m & 1;
+					int ai = dot4_first(g2, p.taps.ti[par][0]);
+					ai = __builtin_amdgcn_sdot4((int)g0, p.taps.ti[par][1], ai, false);
+					int aq = dot4_first(h2, p.taps.tq[par][0]);
+					aq = __builtin_amdgcn_sdot4((int)h0, p.taps.tq[par][1], aq, false);
+					uint32_t pk = __builtin_amdgcn_perm((uint32_t)aq, (uint32_t)ai, 0x05040100u);
+					Y0[m] = as_u32(as_s2(pk) >> 4);
+					g0 = g1; g1 = g2; h0 = h1; h1 = h2;
+				}
 			}
 			RTLFM_MARK("pass0_done");
 			if (bs) {
