@@ -46,7 +46,7 @@ struct ScanParams {
 	int bin_e, chunks;       // FFT size exponent, chunks per read
 	int ds, peak_hold;
 	const int32_t *window;   // [N]
-	const int16_t *sine;     // [3N/4]
+	const uint32_t *tw;      // [N] per-stage twiddles, see make_twiddles() in rtlpower_hip.hip
 	long long *avg;          // [stream][N]
 	int32_t *samples;        // [stream]
 };
@@ -64,18 +64,73 @@ __device__ __forceinline__ int element_at(const ScanParams &p, const uint8_t *ra
 	return e < p.buf_len ? (int)raw[e] - 127 : 0;
 }
 
+typedef short pk16_t __attribute__((ext_vector_type(2)));
+
+// One butterfly of fix_fft (src/rtl_power.c:309-321) on packed (re, im) int16 pairs.
+//   FIX_MPY(a, b) = ((a*b >> 14) >> 1) + ((a*b >> 14) & 1) = (a*b + 2^14) >> 15   (exact identity)
+//   tr = FIX_MPY(wr, b.re) - FIX_MPY(wi, b.im), ti = FIX_MPY(wr, b.im) + FIX_MPY(wi, b.re)
+//   q  = a >> 1 (per component);  b' = q - t,  a' = q + t
+// Every int16 store of the reference wraps mod 2^16; so do the packed 16-bit adds here.
+__device__ __forceinline__ void butterfly(uint32_t &a, uint32_t &b, int wr, int wi)
+{
+	const int br = (int)(int16_t)(b & 0xffffu), bi = (int)(int16_t)(b >> 16);
+	const int tr = ((wr * br + 16384) >> 15) - ((wi * bi + 16384) >> 15);
+	const int ti = ((wr * bi + 16384) >> 15) + ((wi * br + 16384) >> 15);
+	const uint32_t tt = __builtin_amdgcn_perm((uint32_t)ti, (uint32_t)tr, 0x05040100u);
+	const pk16_t q = __builtin_bit_cast(pk16_t, a) >> 1;
+	const pk16_t tv = __builtin_bit_cast(pk16_t, tt);
+	b = __builtin_bit_cast(uint32_t, (pk16_t)(q - tv));
+	a = __builtin_bit_cast(uint32_t, (pk16_t)(q + tv));
+}
+
+// LDS holds the points skewed by 8 dwords per 64-dword block: with the natural
+// layout the stride-8 pass (stages 3-5) puts 32 lanes on 8 banks.
+__device__ __forceinline__ int skew(int a) { return a + ((a >> 6) << 3); }
+__host__ __device__ constexpr int skewed_size(int n) { return n + ((n >> 6) << 3) + 8; }
+
+// stages st .. st+R-1 for every group of 2^R points at stride 2^st (st is a multiple
+// of 3).  tw[(1 << stage) - 1 + m] holds the stage's twiddle for butterfly position m
+// as packed int16 (wr, wi), already halved as fix_fft does (src/rtl_power.c:303-308):
+// consecutive lanes read consecutive dwords (or the same one), never a strided table.
+template <int R>
+__device__ __forceinline__ void fft_pass(uint32_t *pts, const uint32_t *tw, int M, int st, int t)
+{
+	constexpr int G = 1 << R;
+	const int h = 1 << st;
+	const int hs = h + ((h >> 6) << 3);  // stride between a group's points in the skewed layout
+	for (int g = t; g < (M >> R); g += kThreads) {
+		const int glo = g & (h - 1), ghi = g >> st;
+		const int base = skew((ghi << (st + R)) | glo);
+		uint32_t x[G];
+#pragma unroll
+		for (int k = 0; k < G; k++) x[k] = pts[base + k * hs];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint32_t *tws = tw + ((1 << (st + r)) - 1) + glo;
+#pragma unroll
+			for (int k = 0; k < G; k++) {
+				if (k & (1 << r)) continue;
+				const uint32_t w = tws[(k & ((1 << r) - 1)) * h];  // position m = glo + (k mod 2^r) * h
+				butterfly(x[k], x[k + (1 << r)], (int)(int16_t)(w & 0xffffu), (int)(int16_t)(w >> 16));
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < G; k++) pts[base + k * hs] = x[k];
+	}
+}
+
 __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
 	const int N = 1 << p.bin_e;
 	const int M = p.chunks * N;
-	uint32_t *pts = sm;                                     // [M]
-	int16_t *sine = reinterpret_cast<int16_t *>(sm + M);    // [3N/4]
+	uint32_t *pts = sm;                       // [skewed_size(M)]
+	uint32_t *tw = sm + skewed_size(M);       // [N]
 	__shared__ long long red[2][kThreads / 64];
 	__shared__ int ave[2];
 	const int t = threadIdx.x;
 	const size_t s = blockIdx.x;
-	for (int k = t; k < N * 3 / 4; k += kThreads) sine[k] = p.sine[k];
+	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
 	const int A = N >= kThreads ? N / kThreads : 1;  // accumulators per thread
 	long long acc[16];
 #pragma unroll
@@ -115,34 +170,23 @@ __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 			vi = (int16_t)(vi * w);
 			vq = (int16_t)(vq * w);
 			const int rj = (int)(__brev((unsigned)j) >> (32 - p.bin_e));
-			pts[(c << p.bin_e) + rj] = pack_iq(vi, vq);
+			pts[skew((c << p.bin_e) + rj)] = pack_iq(vi, vq);
 		}
 		__syncthreads();
-		// ---- C: radix-2 DIT stages -------------------------------------------------
-		for (int st = 0; st < p.bin_e; st++) {
-			const int half = 1 << st;
-			const int k = p.bin_e - 1 - st;
-			for (int q = t; q < M / 2; q += kThreads) {
-				const int c = q >> (p.bin_e - 1), qq = q & (N / 2 - 1);
-				const int m = qq & (half - 1), grp = qq >> st;
-				const int i = (c << p.bin_e) + (grp << (st + 1)) + m;
-				const int pp = i + half;
-				const int j = m << k;
-				const int wr = (int)sine[j + N / 4] >> 1;
-				const int wi = (int)(int16_t)(-(int)sine[j]) >> 1;
-				const iq16 b = unpack_iq(pts[pp]);
-				const iq16 a = unpack_iq(pts[i]);
-				const int tr = (int16_t)(fix_mpy(wr, b.i) - fix_mpy(wi, b.q));
-				const int ti = (int16_t)(fix_mpy(wr, b.q) + fix_mpy(wi, b.i));
-				const int qr = (int)a.i >> 1, qi = (int)a.q >> 1;
-				pts[pp] = pack_iq((int16_t)(qr - tr), (int16_t)(qi - ti));
-				pts[i] = pack_iq((int16_t)(qr + tr), (int16_t)(qi + ti));
-			}
+		// ---- C: radix-2 DIT stages, up to three per LDS round trip ---------------------
+		// A group of 2^R points at stride 2^s stays in registers for stages s..s+R-1;
+		// each butterfly is the reference's, bit for bit (see butterfly()).
+		for (int st = 0; st < p.bin_e;) {
+			const int R = p.bin_e - st >= 3 ? 3 : p.bin_e - st;
+			if (R == 3) fft_pass<3>(pts, tw, M, st, t);
+			else if (R == 2) fft_pass<2>(pts, tw, M, st, t);
+			else fft_pass<1>(pts, tw, M, st, t);
+			st += R;
 			__syncthreads();
 		}
 		// ---- D: integrate / peak hold ------------------------------------------------
 		auto fold = [&](long long &a, int pnt) {
-			const iq16 v = unpack_iq(pts[pnt]);
+			const iq16 v = unpack_iq(pts[skew(pnt)]);
 			const long long pw = (long long)v.i * v.i + (long long)v.q * v.q;
 			a = p.peak_hold ? (pw > a ? pw : a) : a + pw;
 		};
@@ -169,6 +213,114 @@ __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 		}
 	}
 	if (t == 0) p.samples[s] += p.ds * p.chunks * p.nreads;  // :717
+}
+
+// The same scan specialised for the large-FFT, undecimated case (BASELINE config 4:
+// bin_e = 13 or 14, one FFT per read, raw u8 input).  Differences from k_power_scan:
+//  * thread (lane l, wave w) owns the contiguous points j = l<<(E-6) | w<<(E-10) | k:
+//    its bytes arrive with one or two 16-byte loads, stay in registers from the DC sums
+//    (phase A) to the windowing (phase B), and the NEXT read is fetched while this
+//    one is transformed;
+//  * with the lane index in the top bits of j the bit-reversed LDS address has the
+//    lane in its LOW bits: phase B's scattered stores are bank-conflict free (they were
+//    32-way conflicted with the natural mapping).
+template <int E>
+__global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
+{
+	constexpr int N = 1 << E;
+	constexpr int P = N / kThreads;  // points per thread: 8 or 16
+	constexpr int V = P / 8;         // uint4 loads per thread
+	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+	uint32_t *pts = sm;                       // [skewed_size(N)]
+	uint32_t *tw = sm + skewed_size(N);       // [N]
+	__shared__ long long red[2][kThreads / 64];
+	__shared__ int ave[2];
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const size_t s = blockIdx.x;
+	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
+	const int j0 = (lane << (E - 6)) | (wave << (E - 10));
+	int w[P];
+	{
+		const int4 *wp = reinterpret_cast<const int4 *>(p.window + j0);
+#pragma unroll
+		for (int k = 0; k < P / 4; k++) { int4 v = wp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+	}
+	long long acc[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) acc[k] = 0;
+	const uint8_t *base = p.iq8 + s * p.stride8 + 2 * (size_t)j0;
+	uint4 cur[V], nxt[V];
+#pragma unroll
+	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base)[v];
+
+	for (int r = 0; r < p.nreads; r++) {
+		// ---- A: remove_dc sums (all 2N elements are below len_dec here) ------------
+		int si = 0, sq = 0;
+#pragma unroll
+		for (int v = 0; v < V; v++) {
+			const uint32_t d[4] = {cur[v].x, cur[v].y, cur[v].z, cur[v].w};
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				si += (int)(d[q] & 0xff) + (int)((d[q] >> 16) & 0xff) - 254;
+				sq += (int)((d[q] >> 8) & 0xff) + (int)(d[q] >> 24) - 254;
+			}
+		}
+		long long li = si, lq = sq;
+		for (int off = 32; off > 0; off >>= 1) { li += __shfl_down(li, off); lq += __shfl_down(lq, off); }
+		__syncthreads();  // previous read's phase D is done with pts / red
+		if (lane == 0) { red[0][wave] = li; red[1][wave] = lq; }
+		__syncthreads();
+		if (t == 0) {
+			long long a = 0, b = 0;
+			for (int k = 0; k < kThreads / 64; k++) { a += red[0][k]; b += red[1][k]; }
+			ave[0] = (int)(int16_t)(a / (long long)(2 * N));
+			ave[1] = (int)(int16_t)(b / (long long)(2 * N - 1));
+		}
+		__syncthreads();
+		const int ai = ave[0], aq = ave[1];
+		// ---- B: convert, DC, window, bit-reversed placement (conflict-free) ---------
+#pragma unroll
+		for (int k = 0; k < P; k++) {
+			const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
+			const uint32_t pair = (k & 1) ? (d >> 16) : (d & 0xffffu);
+			int vi = (int16_t)((int)(pair & 0xff) - 127 - ai);
+			int vq = (int16_t)((int)(pair >> 8) - 127 - aq);
+			vi = (int16_t)(vi * w[k]);
+			vq = (int16_t)(vq * w[k]);
+			pts[skew((int)(__brev((unsigned)(j0 + k)) >> (32 - E)))] = pack_iq(vi, vq);
+		}
+		// the next read's bytes travel while this one is transformed
+		if (r + 1 < p.nreads) {
+#pragma unroll
+			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
+		}
+		__syncthreads();
+		// ---- C ------------------------------------------------------------------------
+		for (int st = 0; st < E;) {
+			const int R = E - st >= 3 ? 3 : E - st;
+			if (R == 3) fft_pass<3>(pts, tw, N, st, t);
+			else if (R == 2) fft_pass<2>(pts, tw, N, st, t);
+			else fft_pass<1>(pts, tw, N, st, t);
+			st += R;
+			__syncthreads();
+		}
+		// ---- D ------------------------------------------------------------------------
+#pragma unroll
+		for (int a = 0; a < P; a++) {
+			const iq16 v = unpack_iq(pts[skew(t + kThreads * a)]);
+			const long long pw = (long long)v.i * v.i + (long long)v.q * v.q;
+			acc[a] = p.peak_hold ? (pw > acc[a] ? pw : acc[a]) : acc[a] + pw;
+		}
+#pragma unroll
+		for (int v = 0; v < V; v++) cur[v] = nxt[v];
+	}
+#pragma unroll
+	for (int a = 0; a < P; a++) {
+		const int bin = t + kThreads * a;
+		if (p.peak_hold) atomicMax(p.avg + s * N + bin, acc[a]);
+		else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + bin), (unsigned long long)acc[a]);
+	}
+	if (t == 0) p.samples[s] += p.ds * p.nreads;
 }
 
 // rms_power(), src/rtl_power.c:410-436 (bin_e == 0): one workgroup per stream

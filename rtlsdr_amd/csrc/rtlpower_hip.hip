@@ -33,7 +33,7 @@ struct rtlpower_gpu {
 	int N = 1, len_dec = 0, chunks = 0, dec_elems = 0;
 	bool decimates = false;
 	int32_t *d_window = nullptr;
-	int16_t *d_sine = nullptr;
+	uint32_t *d_tw = nullptr;
 	long long *d_avg = nullptr;
 	int32_t *d_samples = nullptr;
 	int16_t *d_decA = nullptr, *d_decB = nullptr;
@@ -234,12 +234,24 @@ extern "C" int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int de
 		rtlpower_window_coefs(cfg->window, h->N, w.data());
 		HIP_TRY(hipMalloc(&h->d_window, w.size() * sizeof(int32_t)));
 		HIP_TRY(hipMemcpy(h->d_window, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-		// sine_table(), src/rtl_power.c:247-261
+		// sine_table(), src/rtl_power.c:247-261, regrouped per FFT stage: stage s uses
+		// wr = Sinewave[j + N/4] >> 1, wi = -Sinewave[j] >> 1 at j = m << (log2N - 1 - s)
+		// for m < 2^s (:303-308); entry (1 << s) - 1 + m holds them packed (wr, wi).
 		std::vector<int16_t> sine((size_t)h->N * 3 / 4 + 1);
 		for (int i = 0; i < h->N * 3 / 4; i++)
 			sine[i] = (int16_t)(int)round(32767 * sin((double)i * 2.0 * M_PI / h->N));
-		HIP_TRY(hipMalloc(&h->d_sine, sine.size() * sizeof(int16_t)));
-		HIP_TRY(hipMemcpy(h->d_sine, sine.data(), sine.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+		std::vector<uint32_t> tw((size_t)h->N, 0u);
+		for (int st = 0; st < cfg->bin_e; st++) {
+			const int k = cfg->bin_e - 1 - st;
+			for (int m = 0; m < (1 << st); m++) {
+				const int j = m << k;
+				int16_t wr = sine[j + h->N / 4], wi = (int16_t)(-sine[j]);
+				wr >>= 1; wi >>= 1;
+				tw[(size_t)(1 << st) - 1 + m] = (uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)wi << 16);
+			}
+		}
+		HIP_TRY(hipMalloc(&h->d_tw, tw.size() * sizeof(uint32_t)));
+		HIP_TRY(hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
 	*out = h;
 	return rtlpower_gpu_clear(h);
@@ -252,7 +264,7 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 	(void)hipStreamSynchronize(h->stream);
 	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_window, h->d_sine, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
+	void *ptrs[] = {h->d_window, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -370,12 +382,12 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 	p.dec = dec; p.dec_stream_stride = dss; p.dec_read_stride = drs; p.dec_elems = h->dec_elems;
 	p.nreads = nreads; p.buf_len = (int)c.buf_len; p.len_dec = h->len_dec;
 	p.bin_e = c.bin_e; p.chunks = h->chunks; p.ds = c.downsample; p.peak_hold = c.peak_hold;
-	p.window = h->d_window; p.sine = h->d_sine; p.avg = h->d_avg; p.samples = h->d_samples;
-	const size_t lds = (size_t)h->chunks * h->N * 4 + (size_t)h->N * 3 / 4 * 2 + 16;
+	p.window = h->d_window; p.tw = h->d_tw; p.avg = h->d_avg; p.samples = h->d_samples;
+	const size_t lds = ((size_t)skewed_size(h->chunks * h->N) + (size_t)h->N) * 4;
 	static bool attr_set = false;
 	if (!attr_set) {
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan),
-		                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
 		attr_set = true;
 	}
 	std::pair<hipEvent_t, hipEvent_t> ev;
@@ -384,7 +396,19 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
 		HIP_TRY(hipEventRecord(ev.first, q));
 	}
-	hipLaunchKernelGGL(k_power_scan, dim3(S), dim3(kThreads), lds, q, p);
+	const bool big = !dec && h->chunks == 1 && h->len_dec == 2 * h->N && (c.bin_e == 13 || c.bin_e == 14) &&
+	                 !(stream_stride & 15) && !((uintptr_t)d_iq & 15) && !(c.buf_len & 15);
+	static bool attr_big = false;
+	if (big && !attr_big) {
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_big<13>),
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_big<14>),
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+		attr_big = true;
+	}
+	if (big && c.bin_e == 14) hipLaunchKernelGGL(k_power_scan_big<14>, dim3(S), dim3(kThreads), lds, q, p);
+	else if (big) hipLaunchKernelGGL(k_power_scan_big<13>, dim3(S), dim3(kThreads), lds, q, p);
+	else hipLaunchKernelGGL(k_power_scan, dim3(S), dim3(kThreads), lds, q, p);
 	HIP_TRY(hipGetLastError());
 	if (h->timing) {
 		HIP_TRY(hipEventRecord(ev.second, q));
