@@ -38,6 +38,8 @@
 //    quantity depends on fewer than 4096 earlier samples for P <= 6.
 #pragma once
 
+#include <string.h>
+
 #include <type_traits>
 
 #include "dsp_device.h"
@@ -122,6 +124,39 @@ inline Pass0Taps make_taps(bool rotate)
 	return t;
 }
 
+// Pass 0 as a Toeplitz product on the int8 matrix pipe (optional engine, see k_fused):
+//   D[16 x 16] = A[16 x 64] * B[64 x 16]   (v_mfma_i32_16x16x64_i8, operand maps verified
+//   with tools/mfma_probe.hip: A[row l&15][k 16(l>>4)+byte], B[k][col l&15], D[row 4(l>>4)+reg][col l&15])
+// Column n of B is a 64-byte window of S (raw ^ 0x7f) starting at dword 8n-4 of a
+// 128-dword segment; row 2o+c of A holds the taps of output o (0..7) of the window,
+// component c (0 = I', 1 = Q'): the four dwords m-3..m of output m = 8n+o sit at window
+// dwords o+1..o+4.  Same taps as the dot4 form (negated for S = -x, sign (-1)^o when
+// rotating), so the 32-bit sums are identical integers.
+inline void make_mfma_taps(bool rotate, uint32_t out[256])
+{
+	static const int TI_rot[4][4] = {{0, 0, 0, -1}, {5, 0, 0, 10}, {-10, 0, 0, -5}, {1, 0, 0, 0}};
+	static const int TQ_rot[4][4] = {{0, 0, 1, 0}, {0, 5, -10, 0}, {0, -10, 5, 0}, {0, 1, 0, 0}};
+	static const int TI_raw[4][4] = {{0, 0, 1, 0}, {5, 0, 10, 0}, {10, 0, 5, 0}, {1, 0, 0, 0}};
+	static const int TQ_raw[4][4] = {{0, 0, 0, 1}, {0, 5, 0, 10}, {0, 10, 0, 5}, {0, 1, 0, 0}};
+	signed char A[16][64];
+	memset(A, 0, sizeof(A));
+	for (int o = 0; o < 8; o++) {
+		const int g = (rotate && (o & 1)) ? -1 : 1;
+		for (int i = 0; i < 4; i++)
+			for (int by = 0; by < 4; by++) {
+				const int k = 4 * (o + 1 + i) + by;
+				A[2 * o][k] = (signed char)(-g * (rotate ? TI_rot : TI_raw)[i][by]);
+				A[2 * o + 1][k] = (signed char)(-g * (rotate ? TQ_rot : TQ_raw)[i][by]);
+			}
+	}
+	for (int l = 0; l < 64; l++)
+		for (int w = 0; w < 4; w++) {
+			uint32_t v = 0;
+			for (int by = 0; by < 4; by++) v |= (uint32_t)(unsigned char)A[l & 15][16 * (l >> 4) + 4 * w + by] << (8 * by);
+			out[4 * l + w] = v;
+		}
+}
+
 // dot4 / dot2 with a zero accumulator in the VOP3 form (inline constant 0):
 // hipcc otherwise emits v_mov 0 + the accumulate-in-place VOP2 form.
 __device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
@@ -149,13 +184,14 @@ struct Params {
 	const int32_t *lut;
 	int variant, rotate;
 	int segs, blocks_per_seg;
+	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 1 = do not reload tiles, 2 = clock stamps
 	unsigned long long *stamps;  // [waves][4] when debug & 2
 	Pass0Taps taps;
 };
 
 // ---- LDS layout of one wave (dword offsets) -----------------------------------
-template <int P, bool FIR9>
+template <int P, bool FIR9, bool MFMA0 = false>
 struct Lds {
 	static constexpr int cz = 64 >> P;  // values per lane of the decimated array Z = Y[P-1]
 	static constexpr int atan = 0;                 // 17 doubles
@@ -170,7 +206,10 @@ struct Lds {
 	static constexpr bool fz_slots = cz >= 9;                     // else ring
 	static constexpr int fz_size = !FIR9 ? 0 : (fz_slots ? 65 * 9 : kPre + 64 * cz);
 	static constexpr int zd = fz + fz_size;        // demod input tails [65]
-	static constexpr int total = zd + 65 + 1;
+	// MFMA engine: the XORed tile as 513 16-byte chunks (chunk -1 = last chunk of the
+	// previous tile), reused in place for pass 0's output in natural order
+	static constexpr int rawbuf = ((zd + 65 + 1 + 31) & ~31) + 28;  // chunk -1; chunk 0 starts 128-byte aligned
+	static constexpr int total = MFMA0 ? rawbuf + 4 * 513 + 4 : zd + 65 + 1;
 };
 
 // Lane l publishes `mine` for lane l+1 and receives lane l-1's; lane 0 receives
@@ -280,18 +319,22 @@ struct AtanNodesLds {
 #ifndef RTLFM_FUSED_WAVES_PER_SIMD
 #define RTLFM_FUSED_WAVES_PER_SIMD 4
 #endif
+#ifndef RTLFM_PASS0_DEFAULT
+#define RTLFM_PASS0_DEFAULT 0  // 0: v_dot4 on the VALU, 1: int8 MFMA (RTLFM_PASS0=valu|mfma overrides)
+#endif
 #ifndef RTLFM_FUSED_EARLY_RELOAD
 #define RTLFM_FUSED_EARLY_RELOAD 0
 #endif
 // STD: the discriminator is known to be polar_discriminant at compile time (the
 // common case and the one the roofline is quoted on); otherwise p.variant picks
 // fast / lut at run time.
-template <int P, bool FIR9, bool STD>
+// MFMA0: pass 0 on the int8 matrix pipe instead of v_dot4 (see make_mfma_taps).
+template <int P, bool FIR9, bool STD, bool MFMA0>
 __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const Params p)
 {
-	using L = Lds<P, FIR9>;
+	using L = Lds<P, FIR9, MFMA0>;
 	constexpr int CZ = L::cz;
-	__shared__ __attribute__((aligned(16))) uint32_t lds[L::total];
+	__shared__ __attribute__((aligned(128))) uint32_t lds[L::total];
 	const int lane = threadIdx.x;
 	const int wave = blockIdx.x;
 	const int seg = wave % p.segs;
@@ -345,11 +388,21 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 	const int out_per_tile = 64 * CZ;
 	int16_t *out_base = p.out + (size_t)s * p.out_stride;
 
+	// dot4 engine: lane l holds the contiguous dwords 32l..32l+31 (cur[k] = dwords 32l+4k..);
+	// MFMA engine: cur[k] = 16-byte chunk 64k + l of the tile (fully coalesced 1 KiB per load)
 	uint4 cur[8];
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)gt_begin * kTileBytes + lane * 128);
+	auto load_tile = [&](int tile) {
+		const uint8_t *tb = stream_base + (size_t)tile * kTileBytes;
 #pragma unroll
-		for (int k = 0; k < 8; k++) cur[k] = src[k];
+		for (int k = 0; k < 8; k++)
+			cur[k] = *reinterpret_cast<const uint4 *>(MFMA0 ? tb + k * 1024 + lane * 16 : tb + lane * 128 + k * 16);
+	};
+	load_tile(gt_begin);
+	typedef int v4i_t __attribute__((ext_vector_type(4)));
+	v4i_t mfma_a = {0, 0, 0, 0};
+	if constexpr (MFMA0) {
+		const uint4 a = reinterpret_cast<const uint4 *>(p.mfma_taps)[lane];
+		mfma_a = v4i_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
 	}
 
 	// The PCM of tile t is stored just before tile t+2's loads are issued, never
@@ -393,6 +446,106 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 		RTLFM_MARK("tile_begin");
 		// ---------------------------------------------------------------- pass 0 ----
 		uint32_t Y0[32];
+		if constexpr (MFMA0) {
+			// The first / last raw dwords of the tile are needed by the two rare paths below;
+			// in this layout they sit in lane 0's cur[0] and lane 63's cur[7].
+			uint32_t fix0 = 0, fix1 = 0, fix2 = 0;
+			if (bs) {
+				uint32_t e[11];
+#pragma unroll
+				for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
+				unpack_rot(cur[0].x, 0, rotate, e[5], e[6]);
+				unpack_rot(cur[0].y, 1, rotate, e[7], e[8]);
+				unpack_rot(cur[0].z, 0, rotate, e[9], e[10]);
+				fix0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
+				fix1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
+				fix2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (next_bs) {
+				uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
+				unpack_rot(cur[7].x, 0, rotate, a0, a1);
+				unpack_rot(cur[7].y, 1, rotate, a2, a3);
+				unpack_rot(cur[7].z, 0, rotate, a4, a5);
+				unpack_rot(cur[7].w, 1, rotate, a6, a7);
+				if (lane == 63) {
+					lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
+					lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
+					if (archive) {
+						uint32_t v[6] = {a1, a2, a3, a4, a5, a6};
+						for (int j = 0; j < 6; j++) { iq16 w = unpack_iq(v[j]); sout->lp_i_hist[0][j] = w.i; sout->lp_q_hist[0][j] = w.q; }
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			// stage S = raw ^ 0x7f7f7f7f as chunks 0..511 (chunk -1 is still the previous tile's 511)
+			uint4 *chunks = reinterpret_cast<uint4 *>(lds + L::rawbuf) + 1;
+			uint4 last;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				uint4 v = cur[k];
+				v.x ^= 0x7f7f7f7fu; v.y ^= 0x7f7f7f7fu; v.z ^= 0x7f7f7f7fu; v.w ^= 0x7f7f7f7fu;
+				chunks[64 * k + lane] = v;
+				if (k == 7) last = v;
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
+			// 16 segments of 128 outputs: lane (n = l&15, q = l>>4) feeds window n's bytes
+			// 16q..16q+15 = chunk 32s + 2n + q - 1 and receives outputs 128s + 8n + 2q + {0,1}
+			const int n = lane & 15, q = lane >> 4;
+			const uint4 *rd = chunks + (2 * n + q - 1);
+			// Outputs go back in place, but the eight 16-byte slots of each lane's later
+			// 128-byte run (run L = m >> 5) are stored XOR-swizzled, slot k at k ^ ((L >> 1) & 7):
+			// the read-back below (lane stride 128 B) is then bank-conflict free instead of
+			// 8-way conflicted.  For this lane L = 4*sgm + (n >> 2), k = (2n + (q >> 1)) & 7, so
+			// the swizzle is ((2*sgm) & 7) | (n >> 3): four distinct store offsets, by sgm & 3.
+			const int yk = ((2 * n + (q >> 1)) & 7) ^ (n >> 3);
+			const int ybase = L::rawbuf + 4 + 32 * (n >> 2) + ((2 * q) & 3);
+			uint2 *wr_sw[4];
+#pragma unroll
+			for (int a = 0; a < 4; a++) wr_sw[a] = reinterpret_cast<uint2 *>(lds + ybase + 4 * (yk ^ (2 * a)));
+			// Two batches of eight segments.  Segment s+1's lane (0,0) needs chunk 32s+31, which
+			// segment s's outputs overwrite in place, so each batch reads all of its operands
+			// (plus the first one of the next batch) before it writes anything; inside a batch
+			// the nine LDS reads, eight MFMAs and eight stores are independent of each other.
+			uint4 bop[9];
+#pragma unroll
+			for (int k = 0; k < 9; k++) bop[k] = rd[32 * k];
+			__builtin_amdgcn_wave_barrier();
+			if (lane == 63) chunks[-1] = last;  // for the next tile; segment 0 has read the old one
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+				uint2 yv[8];
+#pragma unroll
+				for (int k = 0; k < 8; k++) {
+					const v4i_t b = {(int)bop[k].x, (int)bop[k].y, (int)bop[k].z, (int)bop[k].w};
+					const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(mfma_a, b, v4i_t{0, 0, 0, 0}, 0, 0, 0);
+					const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x05040100u);
+					const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x05040100u);
+					yv[k] = make_uint2(as_u32(as_s2(p0) >> 4), as_u32(as_s2(p1) >> 4));
+				}
+				if (half == 0) {
+					bop[0] = bop[8];
+#pragma unroll
+					for (int k = 1; k < 8; k++) bop[k] = rd[32 * (8 + k)];  // chunks >= 287: not touched by batch 0's stores
+					__builtin_amdgcn_wave_barrier();
+				}
+#pragma unroll
+				for (int k = 0; k < 8; k++) wr_sw[k & 3][64 * (8 * half + k)] = yv[k];
+				__builtin_amdgcn_wave_barrier();
+			}
+			// back to the lane-contiguous form the later passes use
+			const uint4 *yl = reinterpret_cast<const uint4 *>(lds + L::rawbuf + 4) + 8 * lane;
+			const int ysw = (lane >> 1) & 7;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const uint4 v = yl[k ^ ysw];
+				Y0[4 * k] = v.x; Y0[4 * k + 1] = v.y; Y0[4 * k + 2] = v.z; Y0[4 * k + 3] = v.w;
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (bs && lane == 0) { Y0[0] = fix0; Y0[1] = fix1; Y0[2] = fix2; }
+		} else
 		{
 			// S = raw ^ 0x80808080 is the only form of the tile the math needs, so the
 			// raw registers are free again after 35 XORs: the next tile's loads go out
@@ -409,11 +562,7 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 				sx[3 + 4 * k] = cur[k].x ^ 0x7f7f7f7fu; sx[4 + 4 * k] = cur[k].y ^ 0x7f7f7f7fu;
 				sx[5 + 4 * k] = cur[k].z ^ 0x7f7f7f7fu; sx[6 + 4 * k] = cur[k].w ^ 0x7f7f7f7fu;
 			}
-			if (RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) {
-				const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes + lane * 128);
-#pragma unroll
-				for (int k = 0; k < 8; k++) cur[k] = src[k];
-			}
+			if (RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
 			RTLFM_MARK("xor_done");
 			// Outputs are produced eight at a time so that only a window of the
 			// gathered registers is live (keeps the kernel at 4 waves per SIMD).
@@ -472,11 +621,7 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 
 		flush_held();
 		held_dst = nullptr;
-		if (!RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) {
-			const uint4 *src = reinterpret_cast<const uint4 *>(stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes + lane * 128);
-#pragma unroll
-			for (int k = 0; k < 8; k++) cur[k] = src[k];
-		}
+		if (!MFMA0 && !RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
 		// hist[pass] = Y[c-7..c-2] of lane 63 (registers) / of the ring's prefix
 		auto archive_regs = [&](auto &Y, auto cc, int pass) {
 			constexpr int c = decltype(cc)::value;
@@ -644,7 +789,14 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 struct Workspace {
 	unsigned long long *stamps = nullptr;
 	int stamp_waves = 0;
-	void release() { if (stamps) hipFree(stamps); stamps = nullptr; }
+	uint32_t *mfma_taps[2] = {nullptr, nullptr};  // [rotate]
+	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = from RTLFM_PASS0
+	void release()
+	{
+		if (stamps) hipFree(stamps);
+		stamps = nullptr;
+		for (auto &t : mfma_taps) { if (t) hipFree(t); t = nullptr; }
+	}
 };
 
 inline bool supported(const rtlfm_cfg &c, int nblocks)
@@ -660,10 +812,13 @@ inline bool supported(const rtlfm_cfg &c, int nblocks)
 template <int P, bool FIR9>
 static int launch_one(const Params &p, int waves, hipStream_t q)
 {
-	if (p.variant == RTLFM_ATAN_STD)
-		hipLaunchKernelGGL((k_fused<P, FIR9, true>), dim3(waves), dim3(64), 0, q, p);
-	else
-		hipLaunchKernelGGL((k_fused<P, FIR9, false>), dim3(waves), dim3(64), 0, q, p);
+	if (p.mfma_taps) {
+		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true>), dim3(waves), dim3(64), 0, q, p);
+		else hipLaunchKernelGGL((k_fused<P, FIR9, false, true>), dim3(waves), dim3(64), 0, q, p);
+	} else {
+		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, false>), dim3(waves), dim3(64), 0, q, p);
+		else hipLaunchKernelGGL((k_fused<P, FIR9, false, false>), dim3(waves), dim3(64), 0, q, p);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 
@@ -679,6 +834,20 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.sin = sin; p.sout = sout; p.lut = lut;
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.taps = make_taps(p.rotate != 0);
+	if (ws.pass0_engine < 0) {
+		const char *e = getenv("RTLFM_PASS0");
+		ws.pass0_engine = (e && !strcmp(e, "mfma")) ? 1 : (e && !strcmp(e, "valu")) ? 0 : RTLFM_PASS0_DEFAULT;
+	}
+	if (ws.pass0_engine == 1) {
+		uint32_t *&t = ws.mfma_taps[p.rotate];
+		if (!t) {
+			uint32_t host[256];
+			make_mfma_taps(p.rotate != 0, host);
+			if (hipMalloc(&t, sizeof(host)) != hipSuccess) return -ENOMEM;
+			if (hipMemcpy(t, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+		}
+		p.mfma_taps = t;
+	}
 	// enough waves to fill 256 CUs several times over; a segment is a run of whole buffers
 	if (const char *e = getenv("RTLFM_FUSED_DEBUG")) p.debug = atoi(e);
 	int target_waves = 8192;
