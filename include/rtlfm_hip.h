@@ -191,7 +191,9 @@ int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *hip_stream);
 
 /* 0 = automatic, 1 = staged reference kernels, 2 = fused streaming kernel
  * (fails with -ENOTSUP at run time when the configuration has no fused
- * form).  For tests and A/B measurement. */
+ * form); 3 / 4 = fused with the first decimation pass forced onto v_dot4 /
+ * onto the int8 MFMA pipe (2 takes the engine from RTLFM_PASS0 or the
+ * compiled default).  For tests and A/B measurement. */
 int rtlfm_gpu_set_path(rtlfm_gpu *h, int path);
 /* Which path the last run took (1 or 2). */
 int rtlfm_gpu_last_path(rtlfm_gpu *h);

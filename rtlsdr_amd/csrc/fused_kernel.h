@@ -131,7 +131,10 @@ inline Pass0Taps make_taps(bool rotate)
 // 128-dword segment; row 2o+c of A holds the taps of output o (0..7) of the window,
 // component c (0 = I', 1 = Q'): the four dwords m-3..m of output m = 8n+o sit at window
 // dwords o+1..o+4.  Same taps as the dot4 form (negated for S = -x, sign (-1)^o when
-// rotating), so the 32-bit sums are identical integers.
+// rotating), so the 32-bit sums are identical integers.  The taps are stored times 8
+// and every segment runs through two chained MFMAs (the second accumulates onto the
+// first), which yields 16*sum: the reference's ">> 4" is then a byte select (one
+// v_perm per output instead of v_perm + v_pk_ashrrev; the matrix pipe has the slack).
 inline void make_mfma_taps(bool rotate, uint32_t out[256])
 {
 	static const int TI_rot[4][4] = {{0, 0, 0, -1}, {5, 0, 0, 10}, {-10, 0, 0, -5}, {1, 0, 0, 0}};
@@ -145,8 +148,8 @@ inline void make_mfma_taps(bool rotate, uint32_t out[256])
 		for (int i = 0; i < 4; i++)
 			for (int by = 0; by < 4; by++) {
 				const int k = 4 * (o + 1 + i) + by;
-				A[2 * o][k] = (signed char)(-g * (rotate ? TI_rot : TI_raw)[i][by]);
-				A[2 * o + 1][k] = (signed char)(-g * (rotate ? TQ_rot : TQ_raw)[i][by]);
+				A[2 * o][k] = (signed char)(-8 * g * (rotate ? TI_rot : TI_raw)[i][by]);
+				A[2 * o + 1][k] = (signed char)(-8 * g * (rotate ? TQ_rot : TQ_raw)[i][by]);
 			}
 	}
 	for (int l = 0; l < 64; l++)
@@ -194,43 +197,55 @@ struct Params {
 template <int P, bool FIR9, bool MFMA0 = false>
 struct Lds {
 	static constexpr int cz = 64 >> P;  // values per lane of the decimated array Z = Y[P-1]
-	static constexpr int atan = 0;                 // 17 doubles
-	static constexpr int raw = atan + 36;          // [65][3]
-	static constexpr int xh = raw + 65 * 3 + 1;    // [8]
-	static constexpr int y0 = xh + 8;              // Y0 tails [65][5]   (P >= 2)
-	static constexpr int y1 = y0 + (P >= 2 ? 65 * 5 : 0);  // Y1 tails (P >= 3)
-	static constexpr int y2 = y1 + (P >= 3 ? 65 * 5 : 0);  // Y2 tails (P >= 4)
-	static constexpr int y3 = y2 + (P >= 4 ? 65 * 5 : 0);  // Y3 ring, c=4 (P >= 5)
+	// 28 small persistent dwords first, so that the MFMA engine's chunk 0 lands on a
+	// 128-byte boundary.  c_*: the predecessor values lane 0 sees in the next tile.
+	static constexpr int xh = 0;        // [8] archived x' of the previous buffer
+	static constexpr int c_y0 = 8;      // [5]
+	static constexpr int c_y1 = 13;     // [5]
+	static constexpr int c_y2 = 18;     // [5]
+	static constexpr int c_zd = 23;     // [1]
+	static constexpr int c_raw = 24;    // [3]
+	// MFMA engine: the XORed tile as 16-byte chunks -1..512 (chunk -1 = last chunk of the
+	// previous tile, chunk 512 = slack), reused in place for pass 0's output
+	static constexpr int rawbuf = 28;
+	static constexpr bool fz_slots = cz >= 9;                     // FIR history by hand-off, else ring
+	static constexpr int tr_w = (FIR9 && fz_slots) ? 9 : 5;
+	// Transient lane-to-lane hand-off slots [65][tr_w], shared by every hand-off of a tile.
+	// With the MFMA engine they live inside the chunk area, which is idle between pass 0's
+	// read-back and the next tile's staging (one wave's LDS queue is in order).
+	static constexpr int tr = MFMA0 ? 32 + 64 : 32;
+	static constexpr int after = MFMA0 ? 32 + 4 * 513 : 32 + 65 * tr_w;
+	static constexpr int atan = (after + 1) & ~1;                 // 17 doubles
+	static constexpr int c_fz = atan + 34;                        // [9]
+	static constexpr int y3 = c_fz + ((FIR9 && fz_slots) ? 9 : 0);  // Y3 ring, c=4 (P >= 5)
 	static constexpr int y4 = y3 + (P >= 5 ? kPre + 64 * 4 : 0);  // Y4 ring, c=2 (P >= 6)
-	static constexpr int fz = y4 + (P >= 6 ? kPre + 64 * 2 : 0);  // FIR input history
-	static constexpr bool fz_slots = cz >= 9;                     // else ring
-	static constexpr int fz_size = !FIR9 ? 0 : (fz_slots ? 65 * 9 : kPre + 64 * cz);
-	static constexpr int zd = fz + fz_size;        // demod input tails [65]
-	// MFMA engine: the XORed tile as 513 16-byte chunks (chunk -1 = last chunk of the
-	// previous tile), reused in place for pass 0's output in natural order
-	static constexpr int rawbuf = ((zd + 65 + 1 + 31) & ~31) + 28;  // chunk -1; chunk 0 starts 128-byte aligned
-	static constexpr int total = MFMA0 ? rawbuf + 4 * 513 + 4 : zd + 65 + 1;
+	static constexpr int fz = y4 + (P >= 6 ? kPre + 64 * 2 : 0);  // FIR input ring (!fz_slots)
+	static constexpr int fz_size = (FIR9 && !fz_slots) ? kPre + 64 * cz : 0;
+	static constexpr int total = fz + fz_size;
 };
 
-// Lane l publishes `mine` for lane l+1 and receives lane l-1's; lane 0 receives
-// what lane 63 left in slot 0 during the previous tile (`carry`, stored after the
-// reads).  Wave-private, no barrier: one wave's LDS queue is in order.
+// Lane l publishes `mine` for lane l+1 in the transient slots and receives lane
+// l-1's; lane 0 receives what lane 63 left in `cr` during the previous tile
+// (leave_carry, stored after the reads).  Wave-private, no barrier: one wave's
+// LDS queue is in order.
 template <int W>
-__device__ __forceinline__ void hand_off(uint32_t *slots, const uint32_t (&mine)[W], uint32_t (&prev)[W], int lane)
+__device__ __forceinline__ void hand_off(uint32_t *slots, const uint32_t *cr, const uint32_t (&mine)[W],
+                                         uint32_t (&prev)[W], int lane)
 {
 #pragma unroll
 	for (int k = 0; k < W; k++) slots[(lane + 1) * W + k] = mine[k];
 	__builtin_amdgcn_wave_barrier();
+	const uint32_t *rp = lane ? slots + lane * W : cr;
 #pragma unroll
-	for (int k = 0; k < W; k++) prev[k] = slots[lane * W + k];
+	for (int k = 0; k < W; k++) prev[k] = rp[k];
 	__builtin_amdgcn_wave_barrier();
 }
 template <int W>
-__device__ __forceinline__ void leave_carry(uint32_t *slots, const uint32_t (&carry)[W], int lane)
+__device__ __forceinline__ void leave_carry(uint32_t *cr, const uint32_t (&carry)[W], int lane)
 {
 	if (lane == 63) {
 #pragma unroll
-		for (int k = 0; k < W; k++) slots[k] = carry[k];
+		for (int k = 0; k < W; k++) cr[k] = carry[k];
 	}
 	__builtin_amdgcn_wave_barrier();
 }
@@ -240,16 +255,16 @@ __device__ __forceinline__ void leave_carry(uint32_t *slots, const uint32_t (&ca
 // a buffer, whose history is one sample older (the archive of
 // src/rtl_fm.c:800-805 never holds the newest input).
 template <int C>
-__device__ __forceinline__ void fifth_history(uint32_t *slots, const uint32_t (&Y)[C], uint32_t (&h)[5], int lane,
-                                              bool drop_newest_next)
+__device__ __forceinline__ void fifth_history(uint32_t *slots, uint32_t *cr, const uint32_t (&Y)[C], uint32_t (&h)[5],
+                                              int lane, bool drop_newest_next)
 {
 	uint32_t mine[5] = {Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2], Y[C - 1]};
-	hand_off<5>(slots, mine, h, lane);
+	hand_off<5>(slots, cr, mine, h, lane);
 	if (drop_newest_next) {
 		uint32_t carry[5] = {Y[C - 6], Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2]};
-		leave_carry<5>(slots, carry, lane);
+		leave_carry<5>(cr, carry, lane);
 	} else {
-		leave_carry<5>(slots, mine, lane);
+		leave_carry<5>(cr, mine, lane);
 	}
 }
 
@@ -320,7 +335,7 @@ struct AtanNodesLds {
 #define RTLFM_FUSED_WAVES_PER_SIMD 4
 #endif
 #ifndef RTLFM_PASS0_DEFAULT
-#define RTLFM_PASS0_DEFAULT 0  // 0: v_dot4 on the VALU, 1: int8 MFMA (RTLFM_PASS0=valu|mfma overrides)
+#define RTLFM_PASS0_DEFAULT 1  // 0: always v_dot4 on the VALU, 1: int8 MFMA where it is faster (RTLFM_PASS0=valu|mfma overrides)
 #endif
 #ifndef RTLFM_FUSED_EARLY_RELOAD
 #define RTLFM_FUSED_EARLY_RELOAD 0
@@ -330,7 +345,7 @@ struct AtanNodesLds {
 // fast / lut at run time.
 // MFMA0: pass 0 on the int8 matrix pipe instead of v_dot4 (see make_mfma_taps).
 template <int P, bool FIR9, bool STD, bool MFMA0>
-__global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const Params p)
+__global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
 {
 	using L = Lds<P, FIR9, MFMA0>;
 	constexpr int CZ = L::cz;
@@ -365,18 +380,18 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 		auto put_ring = [&](int off, int pass) {  // A[kPre-7+j] = hist[j]
 			for (int j = 0; j < 6; j++) lds[off + kPre - 7 + j] = pack_iq(sin->lp_i_hist[pass][j], sin->lp_q_hist[pass][j]);
 		};
-		if (P >= 2) put_slots(L::y0, 1);
-		if (P >= 3) put_slots(L::y1, 2);
-		if (P >= 4) put_slots(L::y2, 3);
+		if (P >= 2) put_slots(L::c_y0, 1);
+		if (P >= 3) put_slots(L::c_y1, 2);
+		if (P >= 4) put_slots(L::c_y2, 3);
 		if (P >= 5) put_ring(L::y3, 4);
 		if (P >= 6) put_ring(L::y4, 5);
 		if (FIR9) {
 			for (int j = 0; j < 9; j++) {
 				uint32_t v = pack_iq(sin->droop_i_hist[j], sin->droop_q_hist[j]);
-				if (L::fz_slots) lds[L::fz + j] = v; else lds[L::fz + kPre - 9 + j] = v;
+				if (L::fz_slots) lds[L::c_fz + j] = v; else lds[L::fz + kPre - 9 + j] = v;
 			}
 		}
-		lds[L::zd] = pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j);
+		lds[L::c_zd] = pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j);
 	}
 	__builtin_amdgcn_wave_barrier();
 	const AtanNodesLds nodes{reinterpret_cast<const double *>(lds + L::atan)};
@@ -479,7 +494,7 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 			}
 			__builtin_amdgcn_wave_barrier();
 			// stage S = raw ^ 0x7f7f7f7f as chunks 0..511 (chunk -1 is still the previous tile's 511)
-			uint4 *chunks = reinterpret_cast<uint4 *>(lds + L::rawbuf) + 1;
+			uint4 *chunks = reinterpret_cast<uint4 *>(lds + L::rawbuf + 4);
 			uint4 last;
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
@@ -489,7 +504,6 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 				if (k == 7) last = v;
 			}
 			__builtin_amdgcn_wave_barrier();
-			if (more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
 			// 16 segments of 128 outputs: lane (n = l&15, q = l>>4) feeds window n's bytes
 			// 16q..16q+15 = chunk 32s + 2n + q - 1 and receives outputs 128s + 8n + 2q + {0,1}
 			const int n = lane & 15, q = lane >> 4;
@@ -518,12 +532,23 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 			for (int half = 0; half < 2; half++) {
 				uint2 yv[8];
 #pragma unroll
-				for (int k = 0; k < 8; k++) {
-					const v4i_t b = {(int)bop[k].x, (int)bop[k].y, (int)bop[k].z, (int)bop[k].w};
-					const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(mfma_a, b, v4i_t{0, 0, 0, 0}, 0, 0, 0);
-					const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x05040100u);
-					const uint32_t p1 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x05040100u);
-					yv[k] = make_uint2(as_u32(as_s2(p0) >> 4), as_u32(as_s2(p1) >> 4));
+				for (int g = 0; g < 8; g += 4) {
+					v4i_t acc[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const uint4 o = bop[g + k];
+						acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mfma_a, v4i_t{(int)o.x, (int)o.y, (int)o.z, (int)o.w},
+						                                                v4i_t{0, 0, 0, 0}, 0, 0, 0);
+					}
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const uint4 o = bop[g + k];
+						const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(mfma_a, v4i_t{(int)o.x, (int)o.y, (int)o.z, (int)o.w},
+						                                                       acc[k], 0, 0, 0);
+						// d = 16*sum: bits 8..23 are (sum >> 4) as int16
+						yv[g + k] = make_uint2(__builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x06050201u),
+						                       __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x06050201u));
+					}
 				}
 				if (half == 0) {
 					bop[0] = bop[8];
@@ -535,6 +560,9 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 				for (int k = 0; k < 8; k++) wr_sw[k & 3][64 * (8 * half + k)] = yv[k];
 				__builtin_amdgcn_wave_barrier();
 			}
+			// the raw registers are free since the staging; the next tile's loads go out once
+			// the MFMA phase no longer needs the register file for operands and accumulators
+			if (more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
 			// back to the lane-contiguous form the later passes use
 			const uint4 *yl = reinterpret_cast<const uint4 *>(lds + L::rawbuf + 4) + 8 * lane;
 			const int ysw = (lane >> 1) & 7;
@@ -553,8 +581,8 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 			uint32_t sx[35];  // S[-3..31]
 			{
 				uint32_t mine[3] = {cur[7].y, cur[7].z, cur[7].w}, prev[3];
-				hand_off<3>(lds + L::raw, mine, prev, lane);
-				leave_carry<3>(lds + L::raw, mine, lane);
+				hand_off<3>(lds + L::tr, lds + L::c_raw, mine, prev, lane);
+				leave_carry<3>(lds + L::c_raw, mine, lane);
 				sx[0] = prev[0] ^ 0x7f7f7f7fu; sx[1] = prev[1] ^ 0x7f7f7f7fu; sx[2] = prev[2] ^ 0x7f7f7f7fu;
 			}
 #pragma unroll
@@ -651,7 +679,7 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 		} else {
 			uint32_t h5[5];
 			uint32_t Y1[16];
-			fifth_history<32>(lds + L::y0, Y0, h5, lane, next_bs);
+			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lane, next_bs);
 			fifth_lane<32, true>(Y0, h5, Y1);
 			archive_regs(Y0, std::integral_constant<int, 32>(), 1);
 			if constexpr (P == 2) {
@@ -659,7 +687,7 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
 			} else {
 				uint32_t Y2[8];
-				fifth_history<16>(lds + L::y1, Y1, h5, lane, next_bs);
+				fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lane, next_bs);
 				fifth_lane<16, true>(Y1, h5, Y2);
 				archive_regs(Y1, std::integral_constant<int, 16>(), 2);
 				if constexpr (P == 3) {
@@ -667,7 +695,7 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 					for (int k = 0; k < 8; k++) Z[k] = Y2[k];
 				} else {
 					uint32_t Y3[4];
-					fifth_history<8>(lds + L::y2, Y2, h5, lane, next_bs);
+					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lane, next_bs);
 					// with rotation |x| <= 1023 here, so the 16-bit form cannot overflow;
 					// without it an all-255 input reaches exactly 2^15
 					if (rotate) fifth_lane<8, true>(Y2, h5, Y3);
@@ -704,8 +732,8 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 				uint32_t mine[9];
 #pragma unroll
 				for (int k = 0; k < 9; k++) mine[k] = Z[CZ - 9 + k];
-				hand_off<9>(lds + L::fz, mine, h9, lane);
-				leave_carry<9>(lds + L::fz, mine, lane);
+				hand_off<9>(lds + L::tr, lds + L::c_fz, mine, h9, lane);
+				leave_carry<9>(lds + L::c_fz, mine, lane);
 				if (archive) {
 #pragma unroll
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(mine[j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
@@ -737,8 +765,8 @@ __global__ void __launch_bounds__(64, RTLFM_FUSED_WAVES_PER_SIMD) k_fused(const 
 		uint32_t pv;
 		{
 			uint32_t mine[1] = {V[CZ - 1]}, prev[1];
-			hand_off<1>(lds + L::zd, mine, prev, lane);
-			leave_carry<1>(lds + L::zd, mine, lane);
+			hand_off<1>(lds + L::tr, lds + L::c_zd, mine, prev, lane);
+			leave_carry<1>(lds + L::c_zd, mine, lane);
 			pv = prev[0];
 			if (archive) {
 				iq16 w = unpack_iq(V[CZ - 1]);
@@ -790,7 +818,7 @@ struct Workspace {
 	unsigned long long *stamps = nullptr;
 	int stamp_waves = 0;
 	uint32_t *mfma_taps[2] = {nullptr, nullptr};  // [rotate]
-	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = from RTLFM_PASS0
+	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = automatic (see launch)
 	void release()
 	{
 		if (stamps) hipFree(stamps);
@@ -834,11 +862,19 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.sin = sin; p.sout = sout; p.lut = lut;
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.taps = make_taps(p.rotate != 0);
-	if (ws.pass0_engine < 0) {
+	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the
+	// faster one for the configuration as measured on MI355X (tools/sweep_engines.sh): the
+	// MFMA form everywhere except 3 passes + FIR, whose LDS footprint would drop it to
+	// three waves per SIMD.
+	int engine = ws.pass0_engine;
+	if (engine < 0) {
 		const char *e = getenv("RTLFM_PASS0");
-		ws.pass0_engine = (e && !strcmp(e, "mfma")) ? 1 : (e && !strcmp(e, "valu")) ? 0 : RTLFM_PASS0_DEFAULT;
+		if (e && !strcmp(e, "mfma")) engine = 1;
+		else if (e && !strcmp(e, "valu")) engine = 0;
+		else if (!RTLFM_PASS0_DEFAULT) engine = 0;
+		else engine = !(c.downsample_passes == 3 && c.comp_fir_size == 9);
 	}
-	if (ws.pass0_engine == 1) {
+	if (engine == 1) {
 		uint32_t *&t = ws.mfma_taps[p.rotate];
 		if (!t) {
 			uint32_t host[256];
@@ -860,7 +896,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.segs = segs; p.blocks_per_seg = bps;
 	const int waves = nstreams * segs;
 	if (p.debug & 2) {
-		if (ws.stamp_waves < waves) { ws.release(); if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
+		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
 		p.stamps = ws.stamps;
 	}
 	const bool fir = c.comp_fir_size == 9;

@@ -337,8 +337,10 @@ extern "C" int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *s)
 
 extern "C" int rtlfm_gpu_set_path(rtlfm_gpu *h, int path)
 {
-	if (!h || path < 0 || path > 2) return -EINVAL;
-	h->path = path;
+	if (!h || path < 0 || path > 4) return -EINVAL;
+	h->path = path > 2 ? 2 : path;
+	if (path == 2) h->fws.pass0_engine = -1;  // RTLFM_PASS0 / compiled default
+	if (path > 2) h->fws.pass0_engine = path - 3;
 	return 0;
 }
 extern "C" int rtlfm_gpu_last_path(rtlfm_gpu *h) { return h ? h->last_path : -EINVAL; }

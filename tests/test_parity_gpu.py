@@ -181,19 +181,24 @@ FUSED_CASES = [
 ]
 
 
+# rtlfm_gpu_set_path: 3 = fused with pass 0 on v_dot4, 4 = fused with pass 0 on the int8 MFMA pipe
+ENGINES = [3, 4]
+
+
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("passes,fir9,atan,offs", FUSED_CASES)
 @pytest.mark.parametrize("L,nb,ns", [(8192, 5, 3), (16384, 4, 40), (262144, 3, 2)])
-def test_fused_kernel_vs_oracle_and_staged(oracle_lib, passes, fir9, atan, offs, L, nb, ns):
-    """The fused streaming kernel (path 2): bit-exact against the oracle and the
-    staged kernels, including runs split into several segments with warm-up tiles
-    (ns small => several segments per stream) and carried state."""
+def test_fused_kernel_vs_oracle_and_staged(oracle_lib, passes, fir9, atan, offs, L, nb, ns, engine):
+    """The fused streaming kernel (both pass-0 engines): bit-exact against the oracle
+    and the staged kernels, including runs split into several segments with warm-up
+    tiles (ns small => several segments per stream) and carried state."""
     ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0,
               custom_atan=atan, offset_tuning=offs, rate_out=int(2.4e6) >> passes)
     cfg = make_cfg(ov, L, nb)
     amp = 30.0 if atan == 1 else 60.0
     iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=1000 + passes, fs=2.4e6, dev_hz=75e3, amplitude=amp)
     want, want_len, wstates = oracle_lib.run_batch(cfg, iq, nthreads=4)
-    fo, fs_, used = gpu_run(cfg, iq, path=2)
+    fo, fs_, used = gpu_run(cfg, iq, path=engine)
     assert used == 2
     so, ss, used1 = gpu_run(cfg, iq, path=1)
     assert used1 == 1
@@ -203,25 +208,54 @@ def test_fused_kernel_vs_oracle_and_staged(oracle_lib, passes, fir9, atan, offs,
         assert gu.state_dict(fs_[s], False) == gu.state_dict(wstates[s], False)
     # same data in two runs: carried state written by the fused kernel is complete
     if nb >= 3:
-        fo2, fs2, _ = gpu_run(cfg, iq, path=2, splits=[(0, 1), (1, nb)])
+        fo2, fs2, _ = gpu_run(cfg, iq, path=engine, splits=[(0, 1), (1, nb)])
         for s in range(ns):
             assert np.array_equal(fo2[s], fo[s])
             assert gu.state_dict(fs2[s], False) == gu.state_dict(fs_[s], False)
 
 
-def test_fused_fullscale_random_bytes(oracle_lib):
-    """Full-scale random bytes: every integer stage of the fused kernel wraps like the reference."""
-    for passes, fir9 in ((4, 0), (6, 1), (3, 1)):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_fused_fullscale_random_bytes(oracle_lib, engine):
+    """Full-scale random bytes (0 and 255 included): every integer stage of the fused
+    kernel, with either pass-0 engine, wraps like the reference."""
+    for passes, fir9 in ((4, 0), (6, 1), (3, 1), (5, 0), (1, 0), (2, 1)):
         ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0,
                   custom_atan=2)  # LUT discriminator: integer only
         L, nb, ns = 16384, 3, 12
         cfg = make_cfg(ov, L, nb)
         iq = synth.random_u8(ns, L * nb, seed=50 + passes)
         want, want_len, _ = oracle_lib.run_batch(cfg, iq, nthreads=4)
-        outs, _, used = gpu_run(cfg, iq, path=2)
+        outs, _, used = gpu_run(cfg, iq, path=engine)
         assert used == 2
         for s in range(ns):
             assert np.array_equal(outs[s], want[s, :want_len[s]]), (passes, fir9, s)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("offs", [0, 1])
+def test_fused_extreme_patterns(oracle_lib, engine, offs):
+    """Byte patterns that drive the decimator sums to their extremes: constant 0 / 255,
+    alternating, and the period-4 pattern whose rotate16_neg90 image is all-positive
+    full scale (largest pass-0 sums: 32*128 per component)."""
+    L, nb = 16384, 3
+    pats = [
+        np.full(8, 255, np.uint8), np.zeros(8, np.uint8), np.array([255, 0] * 4, np.uint8),
+        np.array([0, 255] * 4, np.uint8), np.array([255, 255, 0, 255, 0, 0, 255, 0], np.uint8),
+        np.array([0, 0, 255, 0, 255, 255, 0, 255], np.uint8), np.array([255, 255, 0, 0, 255, 255, 0, 0], np.uint8),
+    ]
+    iq = np.stack([np.tile(p, L * nb // 8) for p in pats])
+    # a buffer of noise in the middle so that histories differ from the steady state
+    iq[:, L:L + 4096] = synth.random_u8(len(pats), 4096, seed=77)
+    for passes, fir9 in ((1, 0), (3, 0), (5, 0), (6, 1)):
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0,
+                  custom_atan=2, offset_tuning=offs)
+        cfg = make_cfg(ov, L, nb)
+        want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+        outs, sts, used = gpu_run(cfg, iq, path=engine)
+        assert used == 2
+        for s in range(len(pats)):
+            assert np.array_equal(outs[s], want[s, :want_len[s]]), (passes, fir9, s)
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
 
 
 def test_atan2_q14_against_libm_and_oracle(oracle_lib):
