@@ -188,7 +188,7 @@ struct Params {
 	int variant, rotate;
 	int segs, blocks_per_seg;
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
-	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 1 = do not reload tiles, 2 = clock stamps
+	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps, 4 = reload one (cached) tile
 	unsigned long long *stamps;  // [waves][4] when debug & 2
 	Pass0Taps taps;
 };
@@ -240,9 +240,21 @@ __device__ __forceinline__ void hand_off(uint32_t *slots, const uint32_t *cr, co
 	for (int k = 0; k < W; k++) prev[k] = rp[k];
 	__builtin_amdgcn_wave_barrier();
 }
+#if RTLFM_ABLATE & 8
+#define hand_off hand_off_ablated
+template <int W>
+__device__ __forceinline__ void hand_off_ablated(uint32_t *, const uint32_t *, const uint32_t (&mine)[W], uint32_t (&prev)[W], int)
+{
+#pragma unroll
+	for (int k = 0; k < W; k++) prev[k] = mine[k] ^ 1u;
+}
+#endif
 template <int W>
 __device__ __forceinline__ void leave_carry(uint32_t *cr, const uint32_t (&carry)[W], int lane)
 {
+#if RTLFM_ABLATE & 8
+	return;
+#endif
 	if (lane == 63) {
 #pragma unroll
 		for (int k = 0; k < W; k++) cr[k] = carry[k];
@@ -277,6 +289,11 @@ template <int C, int H, bool QUIRK>
 __device__ __forceinline__ void ring_exchange(uint32_t *ring, const uint32_t (&mine)[C], uint32_t (&hist)[H],
                                               int lane, bool buffer_start)
 {
+#if RTLFM_ABLATE & 8
+#pragma unroll
+	for (int k = 0; k < H; k++) hist[k] = mine[k % C] ^ (uint32_t)k;
+	return;
+#endif
 #pragma unroll
 	for (int k = 0; k < C; k++) ring[kPre + lane * C + k] = mine[k];
 	__builtin_amdgcn_wave_barrier();
@@ -336,6 +353,17 @@ struct AtanNodesLds {
 #endif
 #ifndef RTLFM_PASS0_DEFAULT
 #define RTLFM_PASS0_DEFAULT 1  // 0: always v_dot4 on the VALU, 1: int8 MFMA where it is faster (RTLFM_PASS0=valu|mfma overrides)
+#endif
+// Analysis builds only (tools/ablate.sh): leave parts of the tile out to see what they cost
+// under the real power/clock conditions.  1 = no atan2, 2 = no passes 1.., 4 = no MFMA
+// phase (MFMA engine), 8 = hand-offs return zeros.  Results are wrong by construction.
+#ifndef RTLFM_ABLATE
+#define RTLFM_ABLATE 0
+#endif
+// Where the MFMA variant issues the next tile's loads: 0 = after the MFMA phase, 1 = after
+// pass 0's read-back and the deferred PCM store, 2 = after pass 1 (P >= 2 only).
+#ifndef RTLFM_MFMA_RELOAD_AT
+#define RTLFM_MFMA_RELOAD_AT 1
 #endif
 #ifndef RTLFM_FUSED_EARLY_RELOAD
 #define RTLFM_FUSED_EARLY_RELOAD 0
@@ -413,6 +441,11 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			cur[k] = *reinterpret_cast<const uint4 *>(MFMA0 ? tb + k * 1024 + lane * 16 : tb + lane * 128 + k * 16);
 	};
 	load_tile(gt_begin);
+	// The reload is unconditional: were it skipped for the last tile of a segment, the
+	// loop-carried registers would be a merge of "kept" and "loaded" values and the register
+	// allocator would copy loaded registers right after the loads, i.e. wait for them
+	// (tools/check_prefetch.py).  The last tile re-reads itself instead, an L2 hit.
+	auto reload = [&](int gt, bool more) { load_tile((p.debug & 4) ? gt_begin : more ? gt + 1 : gt); };
 	typedef int v4i_t __attribute__((ext_vector_type(4)));
 	v4i_t mfma_a = {0, 0, 0, 0};
 	if constexpr (MFMA0) {
@@ -493,6 +526,14 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
+#if RTLFM_ABLATE & 4
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				Y0[4 * k] = cur[k].x ^ 0x7f7f7f7fu; Y0[4 * k + 1] = cur[k].y ^ 0x7f7f7f7fu;
+				Y0[4 * k + 2] = cur[k].z ^ 0x7f7f7f7fu; Y0[4 * k + 3] = cur[k].w ^ 0x7f7f7f7fu;
+			}
+			reload(gt, more);
+#else
 			// stage S = raw ^ 0x7f7f7f7f as chunks 0..511 (chunk -1 is still the previous tile's 511)
 			uint4 *chunks = reinterpret_cast<uint4 *>(lds + L::rawbuf + 4);
 			uint4 last;
@@ -513,11 +554,12 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			// the read-back below (lane stride 128 B) is then bank-conflict free instead of
 			// 8-way conflicted.  For this lane L = 4*sgm + (n >> 2), k = (2n + (q >> 1)) & 7, so
 			// the swizzle is ((2*sgm) & 7) | (n >> 3): four distinct store offsets, by sgm & 3.
+			// The chunk area starts 128-byte aligned, so the slot index is bits 4..6 of the byte
+			// address and the four offsets are wr0 ^ 32a: one v_xor each, no address registers held.
 			const int yk = ((2 * n + (q >> 1)) & 7) ^ (n >> 3);
-			const int ybase = L::rawbuf + 4 + 32 * (n >> 2) + ((2 * q) & 3);
-			uint2 *wr_sw[4];
-#pragma unroll
-			for (int a = 0; a < 4; a++) wr_sw[a] = reinterpret_cast<uint2 *>(lds + ybase + 4 * (yk ^ (2 * a)));
+			char *const lds_b = reinterpret_cast<char *>(lds);
+			const uint32_t wr0 = 4u * (uint32_t)(L::rawbuf + 4 + 32 * (n >> 2) + ((2 * q) & 3) + 4 * yk);
+			auto wr_sw = [&](int a) { return reinterpret_cast<uint2 *>(lds_b + (wr0 ^ (32u * (uint32_t)a))); };
 			// Two batches of eight segments.  Segment s+1's lane (0,0) needs chunk 32s+31, which
 			// segment s's outputs overwrite in place, so each batch reads all of its operands
 			// (plus the first one of the next batch) before it writes anything; inside a batch
@@ -557,21 +599,21 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					__builtin_amdgcn_wave_barrier();
 				}
 #pragma unroll
-				for (int k = 0; k < 8; k++) wr_sw[k & 3][64 * (8 * half + k)] = yv[k];
+				for (int k = 0; k < 8; k++) wr_sw(k & 3)[64 * (8 * half + k)] = yv[k];
 				__builtin_amdgcn_wave_barrier();
 			}
 			// the raw registers are free since the staging; the next tile's loads go out once
 			// the MFMA phase no longer needs the register file for operands and accumulators
-			if (more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
+			if (RTLFM_MFMA_RELOAD_AT == 0) reload(gt, more);
 			// back to the lane-contiguous form the later passes use
-			const uint4 *yl = reinterpret_cast<const uint4 *>(lds + L::rawbuf + 4) + 8 * lane;
-			const int ysw = (lane >> 1) & 7;
+			const uint32_t yl0 = 4u * (uint32_t)(L::rawbuf + 4) + 128u * lane + 16u * ((lane >> 1) & 7);
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
-				const uint4 v = yl[k ^ ysw];
+				const uint4 v = *reinterpret_cast<const uint4 *>(lds_b + (yl0 ^ (16u * k)));
 				Y0[4 * k] = v.x; Y0[4 * k + 1] = v.y; Y0[4 * k + 2] = v.z; Y0[4 * k + 3] = v.w;
 			}
 			__builtin_amdgcn_wave_barrier();
+#endif
 			if (bs && lane == 0) { Y0[0] = fix0; Y0[1] = fix1; Y0[2] = fix2; }
 		} else
 		{
@@ -590,7 +632,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				sx[3 + 4 * k] = cur[k].x ^ 0x7f7f7f7fu; sx[4 + 4 * k] = cur[k].y ^ 0x7f7f7f7fu;
 				sx[5 + 4 * k] = cur[k].z ^ 0x7f7f7f7fu; sx[6 + 4 * k] = cur[k].w ^ 0x7f7f7f7fu;
 			}
-			if (RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
+			if (RTLFM_FUSED_EARLY_RELOAD) reload(gt, more);
 			RTLFM_MARK("xor_done");
 			// Outputs are produced eight at a time so that only a window of the
 			// gathered registers is live (keeps the kernel at 4 waves per SIMD).
@@ -649,7 +691,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 
 		flush_held();
 		held_dst = nullptr;
-		if (!MFMA0 && !RTLFM_FUSED_EARLY_RELOAD && more && !(p.debug & 1)) load_tile((p.debug & 4) ? gt_begin : gt + 1);
+		if (!MFMA0 ? !RTLFM_FUSED_EARLY_RELOAD : RTLFM_MFMA_RELOAD_AT == 1) reload(gt, more);
 		// hist[pass] = Y[c-7..c-2] of lane 63 (registers) / of the ring's prefix
 		auto archive_regs = [&](auto &Y, auto cc, int pass) {
 			constexpr int c = decltype(cc)::value;
@@ -673,7 +715,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		RTLFM_MARK("pass0_special_done");
 		// ------------------------------------------------------------ passes 1.. ----
 		uint32_t Z[CZ];  // output of the last pass
-		if constexpr (P == 1) {
+		if constexpr ((RTLFM_ABLATE & 2) != 0) {
+			uint32_t x = 0;
+#pragma unroll
+			for (int k = CZ; k < 32; k++) x ^= Y0[k];
+#pragma unroll
+			for (int k = 0; k < CZ; k++) Z[k] = Y0[k] ^ x;
+		} else if constexpr (P == 1) {
 #pragma unroll
 			for (int k = 0; k < 32; k++) Z[k] = Y0[k];
 		} else {
@@ -682,6 +730,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lane, next_bs);
 			fifth_lane<32, true>(Y0, h5, Y1);
 			archive_regs(Y0, std::integral_constant<int, 32>(), 1);
+			if (MFMA0 && RTLFM_MFMA_RELOAD_AT == 2) reload(gt, more);
 			if constexpr (P == 2) {
 #pragma unroll
 				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
@@ -785,7 +834,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			const int cr = dot2_first(c, b);
 			const int cj = dot2_first(c, bx);
 			int v;
-			if (STD) {
+			if (RTLFM_ABLATE & 1) {
+				v = cj ^ cr;
+			} else if (STD) {
 				v = atan2_q14(cj, cr, nodes);
 			} else {
 				if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);

@@ -12,7 +12,9 @@
 template <int PATTERN, int DEPTH>
 __global__ void __launch_bounds__(64) k_read(const uint8_t* __restrict__ base, size_t seg_bytes, uint32_t* out)
 {
+	extern __shared__ uint32_t dyn_lds[];  // only to limit occupancy (size given at launch)
 	const int lane = threadIdx.x;
+	if (seg_bytes == 1) dyn_lds[lane] = lane;  // never true: keeps the allocation
 	const uint8_t* p = base + (size_t)blockIdx.x * seg_bytes;
 	const int tiles = (int)(seg_bytes / 8192);
 	uint4 acc = make_uint4(0, 0, 0, 0);
@@ -85,22 +87,35 @@ template <typename F> float timeit(F f, int reps = 10)
 	return ms / reps;
 }
 
+__global__ void k_fill(uint32_t* d, size_t n, int mode)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		uint32_t x = (uint32_t)i * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+		d[i] = mode == 0 ? 0x01010101u : mode == 1 ? x : (0x7f7f7f7fu + (x & 0x03030303u));  // 2: IQ-like small noise around 127
+	}
+}
+
 int main(int argc, char** argv)
 {
 	size_t total = (size_t)4 << 30;
 	uint8_t* d; uint32_t* o;
 	CK(hipMalloc(&d, total)); CK(hipMalloc(&o, 1 << 24));
-	CK(hipMemset(d, 1, total));
-	for (int waves : {2048, 4096, 8192, 16384, 32768}) {
-		size_t seg = total / waves;
-		float t0 = timeit([&] { hipLaunchKernelGGL((k_read<0, 2>), dim3(waves), dim3(64), 0, 0, d, seg, o); });
-		float t1 = timeit([&] { hipLaunchKernelGGL((k_read<1, 2>), dim3(waves), dim3(64), 0, 0, d, seg, o); });
-		float t2 = timeit([&] { hipLaunchKernelGGL((k_read<0, 3>), dim3(waves), dim3(64), 0, 0, d, seg, o); });
-		float t3 = timeit([&] { hipLaunchKernelGGL((k_read<1, 3>), dim3(waves), dim3(64), 0, 0, d, seg, o); });
-		float t4 = timeit([&] { hipLaunchKernelGGL((k_read256<0>), dim3(waves / 4), dim3(256), 0, 0, d, seg, o); });
-		float t5 = timeit([&] { hipLaunchKernelGGL((k_read256<1>), dim3(waves / 4), dim3(256), 0, 0, d, seg, o); });
-		printf("waves %6d seg %8zu B | lane-contig d2 %7.1f GB/s  coalesced d2 %7.1f | lane-contig d3 %7.1f  coalesced d3 %7.1f | wg256 lane-contig %7.1f coalesced %7.1f\n",
-		       waves, seg, total / t0 / 1e6, total / t1 / 1e6, total / t2 / 1e6, total / t3 / 1e6, total / t4 / 1e6, total / t5 / 1e6);
+	const char* names[3] = {"constant 0x01", "random bytes", "127 +- small noise"};
+	for (int mode = 0; mode < 3; mode++) {
+		hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint32_t*)d, total / 4, mode);
+		CK(hipDeviceSynchronize());
+		for (int lds_kb : {0, 5, 10, 13}) {
+			for (int waves : {4096, 8192, 16384}) {
+				size_t seg = total / waves;
+				float t0 = timeit([&] { hipLaunchKernelGGL((k_read<0, 2>), dim3(waves), dim3(64), lds_kb * 1024, 0, d, seg, o); }, 20);
+				float t1 = timeit([&] { hipLaunchKernelGGL((k_read<1, 2>), dim3(waves), dim3(64), lds_kb * 1024, 0, d, seg, o); }, 20);
+				float t3 = timeit([&] { hipLaunchKernelGGL((k_read<1, 3>), dim3(waves), dim3(64), lds_kb * 1024, 0, d, seg, o); }, 20);
+				printf("%-20s lds %2d KiB/wave waves %6d | lane-contig d2 %7.1f GB/s  coalesced d2 %7.1f  coalesced d3 %7.1f\n",
+				       names[mode], lds_kb, waves, total / t0 / 1e6, total / t1 / 1e6, total / t3 / 1e6);
+			}
+		}
 	}
 	return 0;
 }
