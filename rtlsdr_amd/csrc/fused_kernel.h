@@ -914,16 +914,16 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.taps = make_taps(p.rotate != 0);
 	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the
-	// faster one for the configuration as measured on MI355X (tools/sweep_engines.sh): the
-	// MFMA form everywhere except 3 passes + FIR, whose LDS footprint would drop it to
-	// three waves per SIMD.
+	// faster one for the configuration as measured on MI355X (tools/sweep_engines.sh,
+	// interleaved launches): the MFMA form wins by 3-18 % for 1, 2, 5 and 6 passes, v_dot4
+	// by 2-6 % for 3 and 4 passes.
 	int engine = ws.pass0_engine;
 	if (engine < 0) {
 		const char *e = getenv("RTLFM_PASS0");
 		if (e && !strcmp(e, "mfma")) engine = 1;
 		else if (e && !strcmp(e, "valu")) engine = 0;
 		else if (!RTLFM_PASS0_DEFAULT) engine = 0;
-		else engine = !(c.downsample_passes == 3 && c.comp_fir_size == 9);
+		else engine = !(c.downsample_passes == 3 || c.downsample_passes == 4);
 	}
 	if (engine == 1) {
 		uint32_t *&t = ws.mfma_taps[p.rotate];

@@ -462,8 +462,15 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		                                                           c.post_downsample);
 		cur = d; cur_stride = ds; T = Tout; per_block = T / nblocks;
 	}
-	if (tp.deemph)
-		k_deemph<<<grid_for(S, 64), 64, 0, q>>>(cur, cur_stride, T, cnt, S, c.deemph_a, sin, sout);
+	if (tp.deemph) {
+		DeemphStep st;
+		st.a = (uint32_t)c.deemph_a; st.half = (uint32_t)(c.deemph_a / 2);
+		const bool magic = c.deemph_a >= 2 && c.deemph_a <= 32768;
+		st.magic = magic ? (uint32_t)((0x100000000ull + st.a - 1) / st.a) : 0;
+		const unsigned grid = (unsigned)((S + 63) / 64);
+		if (magic) k_deemph<true><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		else k_deemph<false><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+	}
 	if (tp.adc) {
 		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, per_block, nblocks, h->d_sums);
 		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, per_block, nblocks, S, c.adc_block_const, sin,

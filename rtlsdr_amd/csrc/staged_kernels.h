@@ -447,23 +447,81 @@ k_post_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__rest
 	}
 }
 
-// deemph_filter (src/rtl_fm.c:1011-1026): non-linear one-pole IIR, one lane
-// per stream walks the stream's run in order.  len[s] (or T) samples.
-__global__ void k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt,
-                         int nstreams, int a, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+// deemph_filter (src/rtl_fm.c:1011-1026): non-linear one-pole IIR
+//     d = x - avg;  avg += d > 0 ? (d + a/2) / a : (d - a/2) / a;  x = (int16_t)avg
+// The rounding makes it order-dependent, so one lane walks one stream's run in
+// order (len[s] or T samples) and the cost is the length of the dependent chain
+// per sample.  It is kept to four instructions:
+//   * C's truncating division is odd-symmetric, so the step is sign(d) * ((|d| + a/2) / a);
+//   * x and avg are carried biased by +32768, which makes |d| + a/2 one v_sad_u32;
+//   * (|d| + a/2) < 2^17, so the quotient is v_mul_hi_u32 with M = ceil(2^32 / a), exact
+//     for every a <= 32768 (Granlund-Montgomery: (M*a - 2^32) * 2^17 <= 2^32); MAGIC = false
+//     keeps the hardware division for a == 1 and larger a;
+//   * add / subtract are both formed, the compare that picks one is off the chain.
+// Samples move in 16-byte groups (eight at a time) with the next group's load in flight.
+struct DeemphStep {
+	uint32_t a, half, magic;
+	template <bool MAGIC>
+	__device__ __forceinline__ uint32_t step(uint32_t xb, uint32_t avgb) const
+	{
+		const uint32_t n = (xb > avgb ? xb - avgb : avgb - xb) + half;
+		const uint32_t q = MAGIC ? __umulhi(n, magic) : n / a;
+		const uint32_t up = avgb + q, dn = avgb - q;
+		return xb > avgb ? up : dn;
+	}
+};
+
+template <bool MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+         DeemphStep ds, const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
-	RTLFM_GRID_STRIDE(s, nstreams) {
+	const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	int16_t *r = R + s * rstride;
+	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {
+		// a state outside the int16 range can only come from rtlfm_gpu_state_set: plain form
 		int avg = sin[s].deemph_avg;
-		const int n = cnt ? cnt[s] : T;
-		int16_t *r = R + s * rstride;
-		const int half = a / 2;
+		const int a = (int)ds.a, half = (int)ds.half;
 		for (int k = 0; k < n; k++) {
 			int d = r[k] - avg;
 			avg += d > 0 ? (d + half) / a : (d - half) / a;
 			r[k] = (int16_t)avg;
 		}
 		sout[s].deemph_avg = avg;
+		return;
 	}
+	uint32_t avgb = (uint32_t)(sin[s].deemph_avg + 32768);
+	auto one = [&](int k) {
+		avgb = ds.step<MAGIC>((uint32_t)(uint16_t)r[k] ^ 0x8000u, avgb);
+		r[k] = (int16_t)(uint16_t)(avgb ^ 0x8000u);
+	};
+	int k = 0;
+	// head: up to the first 16-byte boundary
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	for (; k < head && k < n; k++) one(k);
+	// body: groups of eight
+	if (k + 8 <= n) {
+		uint4 cur = *reinterpret_cast<const uint4 *>(r + k);
+		for (; k + 8 <= n; k += 8) {
+			uint4 nxt = cur;
+			if (k + 16 <= n) nxt = *reinterpret_cast<const uint4 *>(r + k + 8);
+			uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint32_t b = w[j] ^ 0x80008000u;
+				avgb = ds.step<MAGIC>(b & 0xffffu, avgb);
+				const uint32_t lo = avgb;
+				avgb = ds.step<MAGIC>(b >> 16, avgb);
+				w[j] = ((lo & 0xffffu) | (avgb << 16)) ^ 0x80008000u;
+			}
+			*reinterpret_cast<uint4 *>(r + k) = make_uint4(w[0], w[1], w[2], w[3]);
+			cur = nxt;
+		}
+	}
+	for (; k < n; k++) one(k);
+	sout[s].deemph_avg = (int)avgb - 32768;
 }
 
 // dc_block_audio_filter (src/rtl_fm.c:1028-1041).  Block sums in parallel ...

@@ -19,8 +19,8 @@ from .capi import RtlfmCfg, RtlfmStreamState, check
 class GpuDemod:
     """``nstreams`` independent rtl_fm demodulators sharing one configuration."""
 
-    def __init__(self, cfg: RtlfmCfg, nstreams: int = 1, device: int = 0):
-        self.lib = capi.load()
+    def __init__(self, cfg: RtlfmCfg, nstreams: int = 1, device: int = 0, lib_path: str | None = None):
+        self.lib = capi.load(lib_path)  # lib_path: another build of the library (A/B measurements)
         self.cfg = cfg
         self.nstreams = nstreams
         self.device = device

@@ -258,6 +258,39 @@ def test_fused_extreme_patterns(oracle_lib, engine, offs):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
 
 
+@pytest.mark.parametrize("a", [1, 2, 3, 7, 13, 100, 1023, 32768, 40000])
+def test_deemph_filter_every_divisor_form(oracle_lib, a):
+    """deemph_filter (src/rtl_fm.c:1011-1026) with the multiply-high division (2 <= a <= 32768),
+    the a == 1 and a > 32768 fall-backs, odd run lengths / unaligned rows, a carried state, and a
+    state outside the int16 range injected through rtlfm_gpu_state_set."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, nb, ns = 16896, 3, 5
+    ov = dict(downsample=8, downsample_passes=3, deemph=1, deemph_a=a, rate_out=128000,
+              custom_atan=2, post_downsample=11)  # 96 samples per block; rows start at any 2-byte offset
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=300 + a % 97, fs=1.024e6, dev_hz=60e3, amplitude=90.0)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=2)
+    outs, sts, _ = gpu_run(cfg, iq, path=0, splits=[(0, 1), (1, nb)])
+    for s in range(ns):
+        assert np.array_equal(outs[s], want[s, :want_len[s]]), (a, s)
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+    # injected state: avg far outside int16
+    st0 = oracle_lib.new_states(ns)
+    for s in range(ns):
+        st0[s].deemph_avg = (-1) ** s * (70000 + 1000 * s)
+    st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
+    c2 = RtlfmCfg.from_buffer_copy(bytes(cfg)); c2.max_blocks = nb
+    with GpuDemod(c2, ns, 0) as g:
+        for s in range(ns):
+            g.state_set(s, st_copy[s])
+        o, n = g.run_torch(torch.from_numpy(iq).cuda()); g.sync()
+        o = o.cpu().numpy(); n = n.cpu().numpy()
+        for s in range(ns):
+            assert np.array_equal(o[s, :n[s]], want[s, :want_len[s]]), ("injected", a, s)
+            assert g.state_get(s).deemph_avg == wst[s].deemph_avg
+
+
 def test_atan2_q14_against_libm_and_oracle(oracle_lib):
     """The kernels' 45-instruction atan2->Q14 against the device libm chain and
     the host (glibc) chain of polar_discriminant, on 6e6 pairs incl. every

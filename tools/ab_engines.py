@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=60)
     ap.add_argument("--burst", type=int, default=5, help="launches per engine per round")
     ap.add_argument("--paths", type=int, nargs="+", default=[3, 4])
+    ap.add_argument("--libs", nargs="+", default=None,
+                    help="one library build per entry of --paths (default: the in-tree build for all)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     D = 1 << a.passes
@@ -41,8 +43,11 @@ def main():
     S, NB, L = a.streams, a.blocks, a.block_len
     iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=2.4e6, dev_hz=75e3, amplitude=40.0 if a.atan == "fast" else 60.0)
     hs = []
-    for path in a.paths:
-        g = GpuDemod(cfg, S, 0)
+    libs = a.libs or [None] * len(a.paths)
+    if len(libs) != len(a.paths):
+        ap.error("--libs needs one entry per --paths entry")
+    for path, lib in zip(a.paths, libs):
+        g = GpuDemod(cfg, S, 0, lib_path=lib and os.path.abspath(lib))
         g.set_path(path)
         hs.append(g)
     cap = hs[0].result_cap(NB)

@@ -87,6 +87,90 @@ template <typename F> float timeit(F f, int reps = 10)
 	return ms / reps;
 }
 
+// pattern 3: the fused kernel's skeleton around the coalesced stream: a per-tile 4-byte-per-lane
+// store (FEAT & 1), an LDS-zeroing prologue (FEAT & 2), one extra warm-up tile and a repeated
+// last tile per segment (FEAT & 4)
+template <int FEAT>
+__global__ void __launch_bounds__(64) k_skel(const uint8_t* __restrict__ base, size_t seg_bytes, uint32_t* out, uint32_t* pcm)
+{
+	extern __shared__ uint32_t dyn_lds[];
+	const int lane = threadIdx.x;
+	if (FEAT & 2) { for (int k = lane; k < 2400; k += 64) dyn_lds[k] = 0; }
+	const uint8_t* p = base + (size_t)blockIdx.x * seg_bytes;
+	const int tiles = (int)(seg_bytes / 8192);
+	const int t0 = (FEAT & 4) && blockIdx.x ? -1 : 0;
+	uint4 acc = make_uint4(0, 0, 0, 0);
+	uint4 cur[8];
+	auto issue = [&](int t) {
+		const uint8_t* q = p + (ptrdiff_t)t * 8192;
+#pragma unroll
+		for (int k = 0; k < 8; k++) cur[k] = *reinterpret_cast<const uint4*>(q + k * 1024 + lane * 16);
+	};
+	issue(t0);
+	uint32_t held = 0; uint32_t* held_dst = nullptr;
+	for (int t = t0; t < tiles; t++) {
+		uint4 x[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) x[k] = cur[k];
+		if (FEAT & 1) { if (held_dst) *held_dst = held; }
+		if (FEAT & 4) issue(t + 1 < tiles ? t + 1 : t); else if (t + 1 < tiles) issue(t + 1);
+#pragma unroll
+		for (int k = 0; k < 8; k++) { acc.x ^= x[k].x; acc.y += x[k].y; acc.z ^= x[k].z; acc.w += x[k].w; }
+		if (FEAT & 1) { held = acc.x ^ acc.y; held_dst = t >= 0 ? pcm + ((size_t)blockIdx.x * tiles + t) * 64 + lane : nullptr; }
+	}
+	if (FEAT & 1) { if (held_dst) *held_dst = held; }
+	uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	if (r == 0x12345678u) out[blockIdx.x * 64 + lane] = r + ((FEAT & 2) ? dyn_lds[lane] : 0);
+}
+
+// store variants, same bytes written: MODE 0 = 4 B/lane every tile, 1 = 16 B/lane every 4th tile,
+// 2 = 4 B/lane nontemporal, 3 = 16 B/lane every 4th tile nontemporal, 4 = 16 B/lane x4 every 16th tile
+template <int MODE>
+__global__ void __launch_bounds__(64) k_store(const uint8_t* __restrict__ base, size_t seg_bytes, uint32_t* out, uint32_t* pcm)
+{
+	extern __shared__ uint32_t dyn_lds[];
+	const int lane = threadIdx.x;
+	if (seg_bytes == 1) dyn_lds[lane] = lane;
+	const uint8_t* p = base + (size_t)blockIdx.x * seg_bytes;
+	const int tiles = (int)(seg_bytes / 8192);
+	uint4 acc = make_uint4(0, 0, 0, 0);
+	uint4 cur[8];
+	auto issue = [&](int t) {
+		const uint8_t* q = p + (ptrdiff_t)t * 8192;
+#pragma unroll
+		for (int k = 0; k < 8; k++) cur[k] = *reinterpret_cast<const uint4*>(q + k * 1024 + lane * 16);
+	};
+	issue(0);
+	uint32_t* wbase = pcm + (size_t)blockIdx.x * tiles * 64;
+	uint4 hold[4] = {};
+	for (int t = 0; t < tiles; t++) {
+		uint4 x[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) x[k] = cur[k];
+		// stores go out before the reload, like the fused kernel's deferred PCM store
+		if (MODE == 0 && t > 0) wbase[(t - 1) * 64 + lane] = acc.x;
+		if (MODE == 2 && t > 0) __builtin_nontemporal_store(acc.x, wbase + (t - 1) * 64 + lane);
+		if (MODE == 1 && t > 0 && (t & 3) == 0) reinterpret_cast<uint4*>(wbase + (t - 4) * 64)[lane] = acc;
+		if (MODE == 3 && t > 0 && (t & 3) == 0) {
+			uint32_t* q = wbase + (t - 4) * 64 + lane * 4;
+			__builtin_nontemporal_store(acc.x, q); __builtin_nontemporal_store(acc.y, q + 1);
+			__builtin_nontemporal_store(acc.z, q + 2); __builtin_nontemporal_store(acc.w, q + 3);
+		}
+		if (MODE == 4) {
+			if ((t & 3) == 0 && t > 0) hold[((t >> 2) - 1) & 3] = acc;
+			if (t > 0 && (t & 15) == 0) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) reinterpret_cast<uint4*>(wbase + (t - 16 + 4 * k) * 64)[lane] = hold[k];
+			}
+		}
+		issue(t + 1 < tiles ? t + 1 : t);
+#pragma unroll
+		for (int k = 0; k < 8; k++) { acc.x ^= x[k].x; acc.y += x[k].y; acc.z ^= x[k].z; acc.w += x[k].w; }
+	}
+	uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	if (r == 0x12345678u) out[blockIdx.x * 64 + lane] = r;
+}
+
 __global__ void k_fill(uint32_t* d, size_t n, int mode)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,22 +184,22 @@ __global__ void k_fill(uint32_t* d, size_t n, int mode)
 int main(int argc, char** argv)
 {
 	size_t total = (size_t)4 << 30;
-	uint8_t* d; uint32_t* o;
-	CK(hipMalloc(&d, total)); CK(hipMalloc(&o, 1 << 24));
-	const char* names[3] = {"constant 0x01", "random bytes", "127 +- small noise"};
-	for (int mode = 0; mode < 3; mode++) {
-		hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint32_t*)d, total / 4, mode);
-		CK(hipDeviceSynchronize());
-		for (int lds_kb : {0, 5, 10, 13}) {
-			for (int waves : {4096, 8192, 16384}) {
-				size_t seg = total / waves;
-				float t0 = timeit([&] { hipLaunchKernelGGL((k_read<0, 2>), dim3(waves), dim3(64), lds_kb * 1024, 0, d, seg, o); }, 20);
-				float t1 = timeit([&] { hipLaunchKernelGGL((k_read<1, 2>), dim3(waves), dim3(64), lds_kb * 1024, 0, d, seg, o); }, 20);
-				float t3 = timeit([&] { hipLaunchKernelGGL((k_read<1, 3>), dim3(waves), dim3(64), lds_kb * 1024, 0, d, seg, o); }, 20);
-				printf("%-20s lds %2d KiB/wave waves %6d | lane-contig d2 %7.1f GB/s  coalesced d2 %7.1f  coalesced d3 %7.1f\n",
-				       names[mode], lds_kb, waves, total / t0 / 1e6, total / t1 / 1e6, total / t3 / 1e6);
-			}
-		}
+	uint8_t* d; uint32_t* o; uint32_t* pcm;
+	CK(hipMalloc(&d, total)); CK(hipMalloc(&o, 1 << 24)); CK(hipMalloc(&pcm, total / 32));
+	hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint32_t*)d, total / 4, 1);
+	CK(hipDeviceSynchronize());
+	const int waves = 8192, lds = 9560;
+	const size_t seg = total / waves;
+	for (int rep = 0; rep < 3; rep++) {
+		float t[8];
+		t[0] = timeit([&] { hipLaunchKernelGGL((k_skel<0>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[1] = timeit([&] { hipLaunchKernelGGL((k_store<0>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[2] = timeit([&] { hipLaunchKernelGGL((k_store<1>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[3] = timeit([&] { hipLaunchKernelGGL((k_store<2>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[4] = timeit([&] { hipLaunchKernelGGL((k_store<3>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[5] = timeit([&] { hipLaunchKernelGGL((k_store<4>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		printf("no store %.4f ms | 4B/lane each tile %.4f | 16B/lane every 4th %.4f | 4B nt %.4f | 16B every 4th nt %.4f | 4x16B every 16th %.4f\n",
+		       t[0], t[1], t[2], t[3], t[4], t[5]);
 	}
 	return 0;
 }
