@@ -458,7 +458,7 @@ k_post_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__rest
 //     for every a <= 32768 (Granlund-Montgomery: (M*a - 2^32) * 2^17 <= 2^32); MAGIC = false
 //     keeps the hardware division for a == 1 and larger a;
 //   * add / subtract are both formed, the compare that picks one is off the chain.
-// Samples move in 16-byte groups (eight at a time) with the next group's load in flight.
+// Samples move in 16-byte groups, a 128-byte line at a time with the next line in flight.
 struct DeemphStep {
 	uint32_t a, half, magic;
 	template <bool MAGIC>
@@ -501,24 +501,43 @@ k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restri
 	// head: up to the first 16-byte boundary
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
 	for (; k < head && k < n; k++) one(k);
-	// body: groups of eight
-	if (k + 8 <= n) {
-		uint4 cur = *reinterpret_cast<const uint4 *>(r + k);
-		for (; k + 8 <= n; k += 8) {
-			uint4 nxt = cur;
-			if (k + 16 <= n) nxt = *reinterpret_cast<const uint4 *>(r + k + 8);
-			uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+	// body: 128-byte lines (64 samples), the next line's eight loads in flight while this one
+	// is walked: every lane reads its own row, so each line is a separate trip to HBM and one
+	// line of the chain (~3000 cycles) is about what that trip takes
+	auto group = [&](uint4 &g) {
+		uint32_t w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const uint32_t b = w[j] ^ 0x80008000u;
-				avgb = ds.step<MAGIC>(b & 0xffffu, avgb);
-				const uint32_t lo = avgb;
-				avgb = ds.step<MAGIC>(b >> 16, avgb);
-				w[j] = ((lo & 0xffffu) | (avgb << 16)) ^ 0x80008000u;
-			}
-			*reinterpret_cast<uint4 *>(r + k) = make_uint4(w[0], w[1], w[2], w[3]);
-			cur = nxt;
+		for (int j = 0; j < 4; j++) {
+			const uint32_t b = w[j] ^ 0x80008000u;
+			avgb = ds.step<MAGIC>(b & 0xffffu, avgb);
+			const uint32_t lo = avgb;
+			avgb = ds.step<MAGIC>(b >> 16, avgb);
+			w[j] = ((lo & 0xffffu) | (avgb << 16)) ^ 0x80008000u;
 		}
+		g = make_uint4(w[0], w[1], w[2], w[3]);
+	};
+	if (k + 64 <= n) {
+		uint4 cur[8], nxt[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
+		for (; k + 64 <= n; k += 64) {
+			const bool more = k + 128 <= n;
+			const uint4 *np = reinterpret_cast<const uint4 *>(r + (more ? k + 64 : k));
+#pragma unroll
+			for (int j = 0; j < 8; j++) nxt[j] = np[j];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				group(cur[j]);
+				reinterpret_cast<uint4 *>(r + k)[j] = cur[j];
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+		}
+	}
+	for (; k + 8 <= n; k += 8) {
+		uint4 g = *reinterpret_cast<const uint4 *>(r + k);
+		group(g);
+		*reinterpret_cast<uint4 *>(r + k) = g;
 	}
 	for (; k < n; k++) one(k);
 	sout[s].deemph_avg = (int)avgb - 32768;
