@@ -215,6 +215,15 @@ int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches);
  */
 int rtlfm_gpu_selftest_atan2(int device, const int32_t *yx, int n, int32_t *q14, int32_t *q14_libm);
 
+/*
+ * rotate_90 on raw u8 IQ (src/rtl_fm.c:437-447, NEG_U8(x) = 255 - x, :375-392): sample n
+ * times (+j)^n, in place on device memory, len bytes (a multiple of 8, 16-byte aligned
+ * buffer), on hip_stream (NULL = the default stream).  The reference keeps this function
+ * but never calls it (its live path rotates the int16 copy by -90 degrees, which the
+ * decimating kernels fold into their taps); it is offered as a standalone operator.
+ */
+int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream);
+
 const char *rtlfm_gpu_strerror(int err);
 /* (major<<16)|(minor<<8)|patch */
 int rtlfm_gpu_version(void);

@@ -177,6 +177,8 @@ class Reference:
         L.ref_optimal_settings.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, _i32p]
         L.ref_atan_lut.restype = _P(C.c_int)
+        L.ref_rotate_90_u8.argtypes = [C.c_void_p, C.c_uint32]
+        L.ref_rotate_90_u8.restype = None
         L.ref_reset()
 
     def close(self):

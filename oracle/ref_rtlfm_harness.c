@@ -177,3 +177,9 @@ const int *ref_atan_lut(void)
 		atan_lut_init();
 	return atan_lut;
 }
+
+/* the reference's u8 rotate_90 (src/rtl_fm.c:437-447, dead code there), in place */
+void ref_rotate_90_u8(unsigned char *buf, uint32_t len)
+{
+	rotate_90(buf, len);
+}

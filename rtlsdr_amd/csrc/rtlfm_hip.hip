@@ -781,6 +781,43 @@ extern "C" int rtlfm_gpu_selftest_atan2(int device, const int32_t *yx, int n, in
 	return 0;
 }
 
+// rotate_90 (u8): per 8 bytes [a0 b0 a1 b1 a2 b2 a3 b3] -> [a0 b0 ~b1 a1 ~a2 ~b2 b3 ~a3]
+// (~x = 255 - x).  Pure byte shuffling: one v_perm and one v_xor per dword, 16 bytes per lane.
+__global__ void __launch_bounds__(256) k_rotate_90_u8(uint4 *buf, size_t n16)
+{
+	RTLFM_GRID_STRIDE(i, n16) {
+		uint4 v = buf[i];
+		v.x = __builtin_amdgcn_perm(0, v.x, 0x02030100u) ^ 0x00ff0000u;
+		v.y = __builtin_amdgcn_perm(0, v.y, 0x02030100u) ^ 0xff00ffffu;
+		v.z = __builtin_amdgcn_perm(0, v.z, 0x02030100u) ^ 0x00ff0000u;
+		v.w = __builtin_amdgcn_perm(0, v.w, 0x02030100u) ^ 0xff00ffffu;
+		buf[i] = v;
+	}
+}
+
+__global__ void k_rotate_90_u8_tail(uint2 *p)  // an odd group of eight bytes at the end
+{
+	uint2 v = *p;
+	v.x = __builtin_amdgcn_perm(0, v.x, 0x02030100u) ^ 0x00ff0000u;
+	v.y = __builtin_amdgcn_perm(0, v.y, 0x02030100u) ^ 0xff00ffffu;
+	*p = v;
+}
+
+extern "C" int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream)
+{
+	if (!d_buf || (len & 7) || ((uintptr_t)d_buf & 15)) return -EINVAL;
+	if (len == 0) return 0;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	hipStream_t q = (hipStream_t)hip_stream;
+	const size_t n16 = len / 16;
+	if (n16) k_rotate_90_u8<<<grid_for(n16), 256, 0, q>>>((uint4 *)d_buf, n16);
+	if (len & 8) k_rotate_90_u8_tail<<<1, 1, 0, q>>>((uint2 *)((uint8_t *)d_buf + len - 8));
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 extern "C" const char *rtlfm_gpu_strerror(int err)
 {
 	switch (err) {

@@ -101,3 +101,28 @@ def test_batch_threads_equal_serial(oracle_lib):
     for s in range(5):
         o, _ = oracle_lib.run_stream(cfg, iq[s])
         assert np.array_equal(o, o1[s, :n1[s]])
+
+
+def test_rotate_90_u8_oracle_vs_reference_and_known_answer(oracle_lib):
+    """rotate_90 on raw bytes (src/rtl_fm.c:437-447, dead code in the reference): the
+    restatement against the reference's own function (when built here) and a known answer."""
+    po = oracle_lib
+    lib = po.oracle()
+    rng = np.random.default_rng(90)
+    for n in (8, 16, 512, 16384):
+        x = rng.integers(0, 256, n, dtype=np.uint8)
+        got = x.copy()
+        lib.orc_rotate_90_u8(got.ctypes.data, n)
+        # sample n times (+j)^n with NEG_U8(v) = 255 - v
+        want = x.copy().reshape(-1, 8)
+        src = x.reshape(-1, 8)
+        want[:, 2] = 255 - src[:, 3]; want[:, 3] = src[:, 2]
+        want[:, 4] = 255 - src[:, 4]; want[:, 5] = 255 - src[:, 5]
+        want[:, 6] = src[:, 7]; want[:, 7] = 255 - src[:, 6]
+        assert np.array_equal(got, want.ravel())
+        if po.have_reference():
+            ref = po.Reference()
+            r = x.copy()
+            ref.lib.ref_rotate_90_u8(r.ctypes.data, n)
+            assert np.array_equal(r, got)
+            ref.close()

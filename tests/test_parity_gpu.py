@@ -291,6 +291,20 @@ def test_deemph_filter_every_divisor_form(oracle_lib, a):
             assert g.state_get(s).deemph_avg == wst[s].deemph_avg
 
 
+@pytest.mark.parametrize("n", [8, 16, 24, 4096, 262144 + 8])
+def test_rotate_90_u8_operator(oracle_lib, n):
+    """rtlfm_gpu_rotate_90_u8 (the reference's u8 rotate_90, src/rtl_fm.c:437-447) against the oracle."""
+    lib = capi.load()
+    x = synth.random_u8(1, n, seed=n)[0]
+    want = x.copy()
+    oracle_lib.oracle().orc_rotate_90_u8(want.ctypes.data, n)
+    d = torch.from_numpy(x.copy()).cuda()
+    assert lib.rtlfm_gpu_rotate_90_u8(0, d.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), want)
+    assert lib.rtlfm_gpu_rotate_90_u8(0, d.data_ptr(), 12, None) == -22  # not a multiple of 8
+
+
 def test_atan2_q14_against_libm_and_oracle(oracle_lib):
     """The kernels' 45-instruction atan2->Q14 against the device libm chain and
     the host (glibc) chain of polar_discriminant, on 6e6 pairs incl. every
