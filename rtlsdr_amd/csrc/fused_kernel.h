@@ -394,6 +394,15 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	state_t *sout = p.sout + s;
 	const int rotate = p.rotate;
 
+	// The carried state is double-buffered (read sin, write sout).  The wave that ends a
+	// stream's run first copies the whole record, so that fields this kernel does not own
+	// (boxcar, resampler, deemph, DC state) carry over without a separate copy kernel per run.
+	if (writes_state) {
+		const uint32_t *a = reinterpret_cast<const uint32_t *>(sin);
+		uint32_t *b = reinterpret_cast<uint32_t *>(sout);
+		static_assert(sizeof(state_t) % 4 == 0, "state record is copied dword-wise");
+		for (int k = lane; k < (int)(sizeof(state_t) / 4); k += 64) b[k] = a[k];
+	}
 	unsigned long long st_clk = 0, st_rt = 0;
 	if (p.debug & 2) { st_clk = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
 	// ---- carried history at the start of the segment ---------------------------

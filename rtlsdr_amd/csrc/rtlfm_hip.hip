@@ -658,14 +658,16 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	if (stream_stride < (size_t)nblocks * h->cfg.block_len) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
 	const size_t S = (size_t)h->nstreams;
-	// state is double-buffered: kernels read st[cur], write st[cur^1]
-	HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
-	                       hipMemcpyDeviceToDevice, h->stream));
 	bool can_fuse = fused::supported(h->cfg, nblocks);
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	int r;
 	if (h->path == 2 && !can_fuse) return -ENOTSUP;
+	// state is double-buffered: kernels read st[cur], write st[cur^1].  The staged kernels each
+	// update their own fields, so the record is copied first; the fused kernel copies it itself.
+	if (!(h->path != 1 && can_fuse))
+		HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
+		                       hipMemcpyDeviceToDevice, h->stream));
 	if (h->path != 1 && can_fuse) {
 		r = run_fused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
