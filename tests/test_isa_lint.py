@@ -1,0 +1,25 @@
+"""The generated gfx950 ISA of the fused kernels keeps the next tile's loads in flight.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU suite.  It guards a
+performance property that no parity test can see: a register-allocator copy of a
+freshly loaded register puts an HBM round trip into every tile (13 % on the headline
+workload when it happened).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_fused_kernels_keep_their_prefetch_in_flight():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    # every -A std instantiation (6 pass counts x FIR on/off x two pass-0 engines) was looked at
+    assert r.stdout.count("std=1") == 24, r.stdout[-3000:]
+    assert "STALL" not in r.stdout
