@@ -71,15 +71,17 @@ def test_c2_full_size_256_streams(oracle_lib):
 
 def test_c3_full_size_4096_nbfm_streams(oracle_lib):
     """configs[2] / one GPU's share of configs[4]: 4096 NBFM streams at 1.024 MS/s, /64 + FIR9 +
-    deemph + arbitrary_resample 16k -> 22.05k, one 262144-B buffer each (1 GiB), two launches."""
-    S, NB, L = 4096, 2, 262144
+    deemph + arbitrary_resample 16k -> 22.05k, one 262144-B buffer each (1 GiB) per launch,
+    eight launches with carried state."""
+    S, NB, L = 4096, 8, 262144
     cfg = RtlfmCfg.default(downsample=64, downsample_passes=6, comp_fir_size=9, deemph=1, deemph_a=2,
                            rate_out=16000, rate_out2=22050, resampler=RESAMPLE_ARBITRARY,
                            block_len=L, max_blocks=1)
     iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0), fs=1.024e6, dev_hz=2.5e3)
-    fo, fl, fst, used = _run(cfg, iq, 2, splits=[(0, 1), (1, 2)])
+    launches = [(b, b + 1) for b in range(NB)]
+    fo, fl, fst, used = _run(cfg, iq, 2, splits=launches)
     assert used == 2
-    so, sl, sst, _ = _run(cfg, iq, 1, splits=[(0, 1), (1, 2)])
+    so, sl, sst, _ = _run(cfg, iq, 1, splits=launches)
     per = 2048 * 22050 // 16000
     assert int(fl[0][0]) == per == 2822
     f = _concat(fo, fl); s_ = _concat(so, sl)
