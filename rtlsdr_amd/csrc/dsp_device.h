@@ -202,6 +202,30 @@ __device__ __forceinline__ int lut_atan2_q14(int cj, int cr, const int32_t *__re
 	return cj > 0 ? 16384 - lut[-x] : -lut[-x];
 }
 
+// The same function with the table entry computed instead of gathered:
+// atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) == atan2_q14(i, 256) for every
+// i < 131072 (checked exhaustively, tests/test_parity_gpu.py).  Used by the fused kernel,
+// where a gather would share the in-order vmcnt with the prefetched tile and force it to
+// land.  Branch structure and quirks (x == 0 fall-through, cj << 8 wrap) as above.
+template <class Nodes>
+__device__ __forceinline__ int lut_atan2_q14_direct(int cj, int cr, Nodes nodes)
+{
+	if (cr == 0 || cj == 0) {
+		if (cr == 0 && cj == 0) return 0;
+		if (cr == 0) return cj > 0 ? 8192 : -8192;
+		return cr > 0 ? 0 : 16384;
+	}
+	int scaled = (int)((uint32_t)cj << 8);
+	int x = (scaled == INT32_MIN && cr == -1) ? INT32_MIN : scaled / cr;
+	long long mag = x < 0 ? -(long long)x : (long long)x;
+	if (mag >= 131072)
+		return cj > 0 ? 8192 : -8192;
+	const int e = atan2_q14((int)mag, 256, nodes);  // atan_lut[|x|]
+	if (x > 0)
+		return cj > 0 ? e : e - 16384;
+	return cj > 0 ? 16384 - e : -e;
+}
+
 __device__ __forceinline__ int disc_lut(int ar, int aj, int br, int bj, const int32_t *__restrict__ lut)
 {
 	int cr, cj;

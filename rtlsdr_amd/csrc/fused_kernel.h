@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				v = atan2_q14(cj, cr, nodes);
 			} else {
 				if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
-				else v = lut_atan2_q14(cj, cr, p.lut);
+				else v = lut_atan2_q14_direct(cj, cr, nodes);
 				if (n == 0 && bs) {
 					// first output of a buffer is always polar_discriminant (:935-937)
 					int vs = atan2_q14(cj, cr, nodes);

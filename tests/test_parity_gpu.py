@@ -305,6 +305,20 @@ def test_rotate_90_u8_operator(oracle_lib, n):
     assert lib.rtlfm_gpu_rotate_90_u8(0, d.data_ptr(), 12, None) == -22  # not a multiple of 8
 
 
+def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
+    """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
+    atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
+    gathering it from the 512 KiB table."""
+    lib = capi.load()
+    n = 131072
+    lut = np.ctypeslib.as_array(oracle_lib.oracle().orc_atan_lut(), shape=(n,)).copy()
+    yx = np.empty((n, 2), np.int32)
+    yx[:, 0] = np.arange(n); yx[:, 1] = 256
+    a = np.empty(n, np.int32)
+    assert lib.rtlfm_gpu_selftest_atan2(0, yx.ctypes.data, n, a.ctypes.data, None) == 0
+    assert np.array_equal(a, lut), np.flatnonzero(a != lut)[:10]
+
+
 def test_atan2_q14_against_libm_and_oracle(oracle_lib):
     """The kernels' 45-instruction atan2->Q14 against the device libm chain and
     the host (glibc) chain of polar_discriminant, on 6e6 pairs incl. every

@@ -11,7 +11,7 @@ between the tile loads and the loop back-edge that forces one of them to
 complete (vmcnt counts in order: a wait for N forces every operation that has
 at least N younger ones).
 
-    python tools/check_prefetch.py [-DNAME=VALUE ...]      exit 1 if any -A std kernel stalls
+    python tools/check_prefetch.py [-DNAME=VALUE ...]      exit 1 if any kernel stalls
 """
 import os
 import re
@@ -86,12 +86,6 @@ def main():
         m = re.match(r"_ZN5rtlfm5fused7k_fusedILi(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
         tag = "P=%s fir9=%s std=%s mfma=%s" % m.groups() if m else name
         pr = check(name, body)
-        if pr and m and m.group(3) == "0":
-            # run-time discriminator kernels: the -A lut table gathers share the in-order vmcnt
-            # with the tile loads, so waiting for a gather also lands the prefetched tile
-            # (known); -A fast takes the other branch and does not wait
-            print(f"{tag}: lut-gather wait (known)")
-            continue
         if pr:
             bad += 1
             print(f"{tag}: STALL")
