@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--blocks", type=int, default=64, help="callback buffers per stream per step")
     ap.add_argument("--block-len", type=int, default=262144)
     ap.add_argument("--passes", type=int, default=4)
+    ap.add_argument("--boxcar", type=int, default=0,
+                    help="D > 0: the reference's default low_pass boxcar /D instead of fifth_order passes "
+                         "(config 1 / -M wbfm shaped work; not the default line)")
     ap.add_argument("--fir9", type=int, default=0)
     ap.add_argument("--atan", choices=["std", "fast", "lut"], default="std")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 staged, 2 fused")
@@ -151,7 +154,9 @@ def main():
     from rtlsdr_amd.demod import GpuDemod
 
     atan = {"std": ATAN_STD, "fast": ATAN_FAST, "lut": ATAN_LUT}[a.atan]
-    D = 1 << a.passes
+    if a.boxcar:
+        a.passes, a.fir9 = 0, 0
+    D = a.boxcar if a.boxcar else 1 << a.passes
     fs = 2.4e6
     cfg = RtlfmCfg.default(downsample=D, downsample_passes=a.passes, comp_fir_size=9 if a.fir9 else 0,
                            custom_atan=atan, rate_out=int(fs / D), block_len=a.block_len,
@@ -230,9 +235,10 @@ def main():
             "dtype": "int16/int32 fixed point (fp64 atan2)",
             "data": "synthetic",
             "config": {
-                "workload": f"rtl_fm -M fm -s {int(fs / D)} -F {9 if a.fir9 else 0} -A {a.atan}: "
-                            f"{S} streams/GPU x {NB} buffers x {L} B u8 IQ @2.4 MS/s, "
-                            f"{a.passes}x fifth_order (/{D}) + polar discriminant -> int16 PCM",
+                "workload": f"rtl_fm -M fm -s {int(fs / D)} " + ("" if a.boxcar else f"-F {9 if a.fir9 else 0} ")
+                            + f"-A {a.atan}: {S} streams/GPU x {NB} buffers x {L} B u8 IQ @2.4 MS/s, "
+                            + (f"low_pass boxcar /{D}" if a.boxcar else f"{a.passes}x fifth_order (/{D})")
+                            + " + polar discriminant -> int16 PCM",
                 "streams_per_gpu": S, "buffers_per_step": NB, "block_len": L, "passes": a.passes,
                 "path": {1: "staged", 2: "fused"}.get(path_used, str(path_used)),
                 "parallelism": f"streams sharded {S}/GPU over {world} GPU(s), no data-path collective",

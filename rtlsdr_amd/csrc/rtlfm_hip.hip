@@ -17,6 +17,7 @@
 #include "../../include/rtlfm_hip.h"
 #include "staged_kernels.h"
 #include "fused_kernel.h"
+#include "boxcar_kernel.h"
 
 using namespace rtlfm;
 
@@ -649,6 +650,37 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
 }
 
+// The boxcar (low_pass) front end in one launch; output counts may differ per buffer and
+// per stream (d_cnt), which the order-insensitive tail stages accept (run_tail, varcnt).
+static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
+                        size_t out_stride, int32_t *d_out_len)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	hipStream_t q = h->stream;
+	const state_t *sin = h->st[h->st_cur];
+	state_t *sout = h->st[h->st_cur ^ 1];
+	TailPlan tp = plan_tail(c);
+	if (tp.any()) {
+		int r = ensure_res_buffers(h);
+		if (r < 0) return r;
+	}
+	int16_t *dd; size_t dds;
+	tail_route(h, tp, d_out, out_stride, &dd, &dds);
+	std::pair<hipEvent_t, hipEvent_t> ev;
+	int r = timing_begin(h, ev);
+	if (r < 0) return r;
+	r = boxfused::launch(c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt, sin, sout, q);
+	if (r < 0) return r;
+	r = timing_end(h, ev);
+	if (r < 0) return r;
+	const int N0 = (int)(c.block_len / 2), D = c.downsample;
+	const int Tin = nblocks * N0;
+	const bool varcnt = (N0 % D) != 0;
+	const int T = varcnt ? Tin / D + 1 : Tin / D;
+	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, d_out, out_stride, d_out_len);
+}
+
 extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
                                     int16_t *d_out, size_t out_stride, int32_t *d_out_len)
 {
@@ -661,14 +693,18 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	bool can_fuse = fused::supported(h->cfg, nblocks);
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
+	const bool can_box = boxfused::supported(h->cfg);
 	int r;
-	if (h->path == 2 && !can_fuse) return -ENOTSUP;
+	if (h->path == 2 && !can_fuse && !can_box) return -ENOTSUP;
 	// state is double-buffered: kernels read st[cur], write st[cur^1].  The staged kernels each
-	// update their own fields, so the record is copied first; the fused kernel copies it itself.
-	if (!(h->path != 1 && can_fuse))
+	// update their own fields, so the record is copied first; the fused kernels copy it themselves.
+	if (!(h->path != 1 && (can_fuse || can_box)))
 		HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
 		                       hipMemcpyDeviceToDevice, h->stream));
-	if (h->path != 1 && can_fuse) {
+	if (h->path != 1 && can_box) {
+		r = run_boxfused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+		h->last_path = 2;
+	} else if (h->path != 1 && can_fuse) {
 		r = run_fused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
 	} else {

@@ -305,6 +305,68 @@ def test_rotate_90_u8_operator(oracle_lib, n):
     assert lib.rtlfm_gpu_rotate_90_u8(0, d.data_ptr(), 12, None) == -22  # not a multiple of 8
 
 
+BOXCAR_CASES = [
+    # D, atan, offset_tuning
+    (2, 0, 0), (3, 2, 0), (5, 0, 0), (6, 1, 0), (7, 0, 1), (8, 0, 0), (10, 1, 0), (10, 0, 0),
+    (16, 2, 0), (17, 0, 0), (32, 0, 1), (64, 1, 0), (100, 0, 0), (255, 2, 0), (256, 0, 0),
+]
+
+
+@pytest.mark.parametrize("D,atan,offs", BOXCAR_CASES)
+@pytest.mark.parametrize("L,nb,ns", [(8192, 5, 3), (16384, 4, 40), (262144, 3, 2)])
+def test_fused_boxcar_vs_oracle_and_staged(oracle_lib, D, atan, offs, L, nb, ns):
+    """The one-launch low_pass (boxcar) + fm_demod kernel: bit-exact against the oracle and the
+    staged kernels for window lengths that divide the buffer and that do not (outputs per
+    buffer then vary), all three discriminators, runs split into segments and launches, and
+    the carried now_r / now_j / prev_index / pre_r / pre_j."""
+    ov = dict(downsample=D, downsample_passes=0, custom_atan=atan, offset_tuning=offs,
+              rate_out=int(2.4e6) // D)
+    cfg = make_cfg(ov, L, nb)
+    # -A fast wraps above |z| ~ 724 (SURVEY 8 a10): keep the boxcar gain D under it
+    amp = 60.0 if atan != 1 else max(2.0, min(60.0, 600.0 / D))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=2000 + D, fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    want, want_len, wstates = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    fo, fs_, used = gpu_run(cfg, iq, path=2)
+    assert used == 2
+    so, ss, used1 = gpu_run(cfg, iq, path=1)
+    assert used1 == 1
+    for s in range(ns):
+        assert len(fo[s]) == want_len[s] == len(so[s])
+        assert np.array_equal(fo[s], so[s]), f"fused boxcar != staged, stream {s}"
+        assert_parity(fo[s], want[s, :want_len[s]], cfg, f"boxcar[{s}]")
+        assert gu.state_dict(fs_[s], False) == gu.state_dict(wstates[s], False)
+    fo2, fs2, _ = gpu_run(cfg, iq, path=2, splits=[(0, 1), (1, 2), (2, nb)])
+    for s in range(ns):
+        assert np.array_equal(fo2[s], fo[s])
+        assert gu.state_dict(fs2[s], False) == gu.state_dict(fs_[s], False)
+
+
+@pytest.mark.parametrize("D", [6, 10, 13])
+def test_fused_boxcar_fullscale_and_tail(oracle_lib, D):
+    """Full-scale random bytes through the fused boxcar (integer wrap of the int16 store), and
+    the wbfm-style tail (deemph + low_pass_real) behind per-stream output counts."""
+    L, nb, ns = 16384, 3, 9
+    ov = dict(downsample=D, downsample_passes=0, custom_atan=2, rate_out=1020000 // D)
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.random_u8(ns, L * nb, seed=70 + D)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    outs, sts, used = gpu_run(cfg, iq, path=2)
+    assert used == 2
+    for s in range(ns):
+        assert np.array_equal(outs[s], want[s, :want_len[s]]), (D, s)
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+    ov = dict(downsample=D, downsample_passes=0, custom_atan=1, deemph=1, deemph_a=13, rate_out=170000,
+              rate_out2=32000, resampler=capi.RESAMPLE_LOW_PASS_REAL)
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=80 + D, fs=1.02e6, dev_hz=75e3, amplitude=50.0)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    outs, sts, used = gpu_run(cfg, iq, path=2, splits=[(0, 2), (2, nb)])
+    assert used == 2
+    for s in range(ns):
+        assert np.array_equal(outs[s], want[s, :want_len[s]]), ("tail", D, s)
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
