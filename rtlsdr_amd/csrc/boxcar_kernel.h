@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 	auto load_tile = [&](int tile) {
 		const uint8_t *tb = stream_base + (size_t)tile * kTileBytes;
 #pragma unroll
-		for (int k = 0; k < 8; k++) cur[k] = *reinterpret_cast<const uint4 *>(tb + k * 1024 + lane * 16);
+		for (int k = 0; k < 8; k++) cur[k] = fused::load_stream16(tb + k * 1024 + lane * 16);
 	};
 	load_tile(gt_begin);
 

@@ -160,6 +160,17 @@ inline void make_mfma_taps(bool rotate, uint32_t out[256])
 		}
 }
 
+// 16 bytes of the input stream, read once: a non-temporal load (global_load_dwordx4 ... nt).
+// The 4 GiB stream otherwise allocates in L2 / the Infinity Cache on its way through and
+// pushes the kernel's own PCM stores out to HBM in the middle of the read stream; with nt
+// loads the same read+write skeleton runs 9 % faster (tools/bw_probe.hip).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_stream16(const uint8_t *p)
+{
+	const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // dot4 / dot2 with a zero accumulator in the VOP3 form (inline constant 0):
 // hipcc otherwise emits v_mov 0 + the accumulate-in-place VOP2 form.
 __device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
@@ -446,8 +457,12 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	auto load_tile = [&](int tile) {
 		const uint8_t *tb = stream_base + (size_t)tile * kTileBytes;
 #pragma unroll
-		for (int k = 0; k < 8; k++)
-			cur[k] = *reinterpret_cast<const uint4 *>(MFMA0 ? tb + k * 1024 + lane * 16 : tb + lane * 128 + k * 16);
+		for (int k = 0; k < 8; k++) {
+			// non-temporal only where one instruction covers whole lines: the lane-contiguous
+			// pattern touches each 128-byte line eight times and would refetch it (2x slower)
+			if constexpr (MFMA0) cur[k] = load_stream16(tb + k * 1024 + lane * 16);
+			else cur[k] = *reinterpret_cast<const uint4 *>(tb + lane * 128 + k * 16);
+		}
 	};
 	load_tile(gt_begin);
 	// The reload is unconditional: were it skipped for the last tile of a segment, the
@@ -922,17 +937,18 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.sin = sin; p.sout = sout; p.lut = lut;
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.taps = make_taps(p.rotate != 0);
-	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the
-	// faster one for the configuration as measured on MI355X (tools/sweep_engines.sh,
-	// interleaved launches): the MFMA form wins by 3-18 % for 1, 2, 5 and 6 passes, v_dot4
-	// by 2-6 % for 3 and 4 passes.
+	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the MFMA
+	// form: its coalesced tile loads can be non-temporal (load_stream16), which removes the cost
+	// of mixing the PCM stores into the read stream, and with that it is the faster engine at
+	// every decimation depth on MI355X (tools/sweep_engines.sh, interleaved launches: 6 % at 4
+	// passes, 11 % at 5).  The v_dot4 form needs no matrix pipe and no LDS staging.
 	int engine = ws.pass0_engine;
 	if (engine < 0) {
 		const char *e = getenv("RTLFM_PASS0");
 		if (e && !strcmp(e, "mfma")) engine = 1;
 		else if (e && !strcmp(e, "valu")) engine = 0;
 		else if (!RTLFM_PASS0_DEFAULT) engine = 0;
-		else engine = !(c.downsample_passes == 3 || c.downsample_passes == 4);
+		else engine = 1;
 	}
 	if (engine == 1) {
 		uint32_t *&t = ws.mfma_taps[p.rotate];

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) k_skel(const uint8_t* __restrict__ base, s
 
 // store variants, same bytes written: MODE 0 = 4 B/lane every tile, 1 = 16 B/lane every 4th tile,
 // 2 = 4 B/lane nontemporal, 3 = 16 B/lane every 4th tile nontemporal, 4 = 16 B/lane x4 every 16th tile
-template <int MODE>
+template <int MODE, int LOADNT = 0>
 __global__ void __launch_bounds__(64) k_store(const uint8_t* __restrict__ base, size_t seg_bytes, uint32_t* out, uint32_t* pcm)
 {
 	extern __shared__ uint32_t dyn_lds[];
@@ -138,10 +138,17 @@ __global__ void __launch_bounds__(64) k_store(const uint8_t* __restrict__ base, 
 	auto issue = [&](int t) {
 		const uint8_t* q = p + (ptrdiff_t)t * 8192;
 #pragma unroll
-		for (int k = 0; k < 8; k++) cur[k] = *reinterpret_cast<const uint4*>(q + k * 1024 + lane * 16);
+		for (int k = 0; k < 8; k++) {
+			const uint4* a = reinterpret_cast<const uint4*>(q + k * 1024 + lane * 16);
+			if (LOADNT == 0) cur[k] = *a;
+			if (LOADNT == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(cur[k]) : "v"(a) : "memory");
+			if (LOADNT == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(cur[k]) : "v"(a) : "memory");
+			if (LOADNT == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(cur[k]) : "v"(a) : "memory");
+		}
+		if (LOADNT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // asm loads are not tracked by the compiler (no prefetch here)
 	};
 	issue(0);
-	uint32_t* wbase = pcm + (size_t)blockIdx.x * tiles * 64;
+	uint32_t* wbase = pcm + (size_t)(MODE == 6 ? (blockIdx.x & 63) : blockIdx.x) * tiles * (MODE >= 5 ? 128 : 64);
 	uint4 hold[4] = {};
 	for (int t = 0; t < tiles; t++) {
 		uint4 x[8];
@@ -149,6 +156,14 @@ __global__ void __launch_bounds__(64) k_store(const uint8_t* __restrict__ base, 
 		for (int k = 0; k < 8; k++) x[k] = cur[k];
 		// stores go out before the reload, like the fused kernel's deferred PCM store
 		if (MODE == 0 && t > 0) wbase[(t - 1) * 64 + lane] = acc.x;
+		if ((MODE == 5 || MODE == 6) && t > 0) reinterpret_cast<uint2*>(wbase)[(size_t)(t - 1) * 64 + lane] = make_uint2(acc.x, acc.y);
+		if (MODE >= 7 && MODE <= 9 && t > 0) {
+			uint2* q = reinterpret_cast<uint2*>(wbase) + (size_t)(t - 1) * 64 + lane;
+			uint2 v = make_uint2(acc.x, acc.y);
+			if (MODE == 7) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");
+			if (MODE == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+			if (MODE == 9) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" :: "v"(q), "v"(v) : "memory");
+		}
 		if (MODE == 2 && t > 0) __builtin_nontemporal_store(acc.x, wbase + (t - 1) * 64 + lane);
 		if (MODE == 1 && t > 0 && (t & 3) == 0) reinterpret_cast<uint4*>(wbase + (t - 4) * 64)[lane] = acc;
 		if (MODE == 3 && t > 0 && (t & 3) == 0) {
@@ -171,6 +186,44 @@ __global__ void __launch_bounds__(64) k_store(const uint8_t* __restrict__ base, 
 	if (r == 0x12345678u) out[blockIdx.x * 64 + lane] = r;
 }
 
+// lane-contiguous pattern (lane l reads its own 128 bytes as eight 16-byte loads) with the PCM
+// store, and a non-temporal hint on: NT 0 none, 1 all eight, 2 only the first touch of a line,
+// 3 only the last touch; NT 4 = coalesced pattern, all nt (reference)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ void __launch_bounds__(64) k_lc(const uint8_t* __restrict__ base, size_t seg_bytes, uint32_t* out, uint32_t* pcm)
+{
+	extern __shared__ uint32_t dyn_lds[];
+	const int lane = threadIdx.x;
+	if (seg_bytes == 1) dyn_lds[lane] = lane;
+	const uint8_t* p = base + (size_t)blockIdx.x * seg_bytes;
+	const int tiles = (int)(seg_bytes / 8192);
+	u32x4_t acc = {0, 0, 0, 0};
+	u32x4_t cur[8];
+	auto issue = [&](int t) {
+		const uint8_t* q = p + (ptrdiff_t)t * 8192;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const u32x4_t* a = reinterpret_cast<const u32x4_t*>(NT == 4 ? q + k * 1024 + lane * 16 : q + lane * 128 + k * 16);
+			const bool nt = NT == 1 || NT == 4 || (NT == 2 && k == 0) || (NT == 3 && k == 7);
+			cur[k] = nt ? __builtin_nontemporal_load(a) : *a;
+		}
+	};
+	issue(0);
+	uint2* wbase = reinterpret_cast<uint2*>(pcm) + (size_t)blockIdx.x * tiles * 64;
+	for (int t = 0; t < tiles; t++) {
+		u32x4_t x[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) x[k] = cur[k];
+		if (t > 0) wbase[(size_t)(t - 1) * 64 + lane] = make_uint2(acc.x, acc.y);
+		issue(t + 1 < tiles ? t + 1 : t);
+#pragma unroll
+		for (int k = 0; k < 8; k++) acc ^= x[k];
+	}
+	uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	if (r == 0x12345678u) out[blockIdx.x * 64 + lane] = r;
+}
+
 __global__ void k_fill(uint32_t* d, size_t n, int mode)
 {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,21 +238,20 @@ int main(int argc, char** argv)
 {
 	size_t total = (size_t)4 << 30;
 	uint8_t* d; uint32_t* o; uint32_t* pcm;
-	CK(hipMalloc(&d, total)); CK(hipMalloc(&o, 1 << 24)); CK(hipMalloc(&pcm, total / 32));
+	CK(hipMalloc(&d, total)); CK(hipMalloc(&o, 1 << 24)); CK(hipMalloc(&pcm, total / 16));
 	hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (uint32_t*)d, total / 4, 1);
 	CK(hipDeviceSynchronize());
 	const int waves = 8192, lds = 9560;
 	const size_t seg = total / waves;
 	for (int rep = 0; rep < 3; rep++) {
-		float t[8];
-		t[0] = timeit([&] { hipLaunchKernelGGL((k_skel<0>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
-		t[1] = timeit([&] { hipLaunchKernelGGL((k_store<0>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
-		t[2] = timeit([&] { hipLaunchKernelGGL((k_store<1>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
-		t[3] = timeit([&] { hipLaunchKernelGGL((k_store<2>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
-		t[4] = timeit([&] { hipLaunchKernelGGL((k_store<3>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
-		t[5] = timeit([&] { hipLaunchKernelGGL((k_store<4>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
-		printf("no store %.4f ms | 4B/lane each tile %.4f | 16B/lane every 4th %.4f | 4B nt %.4f | 16B every 4th nt %.4f | 4x16B every 16th %.4f\n",
-		       t[0], t[1], t[2], t[3], t[4], t[5]);
+		float t[12];
+		t[0] = timeit([&] { hipLaunchKernelGGL((k_lc<0>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[1] = timeit([&] { hipLaunchKernelGGL((k_lc<1>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[2] = timeit([&] { hipLaunchKernelGGL((k_lc<2>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[3] = timeit([&] { hipLaunchKernelGGL((k_lc<3>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		t[4] = timeit([&] { hipLaunchKernelGGL((k_lc<4>), dim3(waves), dim3(64), lds, 0, d, seg, o, pcm); }, 20);
+		printf("8B stores + lane-contiguous loads: plain %.4f ms | all nt %.4f | first touch nt %.4f | last touch nt %.4f || coalesced, all nt %.4f\n",
+		       t[0], t[1], t[2], t[3], t[4]);
 	}
 	return 0;
 }
