@@ -50,6 +50,7 @@ struct Params {
 	const state_t *sin;
 	state_t *sout;
 	int variant, rotate;
+	int mode, output_scale;
 	int D, q4096, r4096;  // 4096 = q4096 * D + r4096
 	int out_cap;          // 4096 / D + 2
 	int segs, blocks_per_seg;
@@ -213,7 +214,8 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 				const int cr = fused::dot2_first(z, b);
 				const int cj = fused::dot2_first(z, bx);
 				int v;
-				if (STD || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
+				if (!STD && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
+				else if (STD || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
 				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
 				pcm[e] = (uint16_t)(int16_t)v;
@@ -234,15 +236,15 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 		sout->now_r = (int)lds[Lds::carry];
 		sout->now_j = (int)lds[Lds::carry + 1];
 		const iq16 w = unpack_iq(lds[O0]);
-		sout->pre_r = w.i;
-		sout->pre_j = w.q;
+		if (STD || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
 		p.cnt[s] = kb;
 	}
 }
 
 inline bool supported(const rtlfm_cfg &c)
 {
-	if (c.mode != RTLFM_MODE_FM) return false;
+	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
+		return false;
 	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > 256) return false;
 	if (c.comp_fir_size || c.dc_block_raw || c.squelch_level) return false;
 	if (c.block_len % kTileBytes) return false;
@@ -259,6 +261,7 @@ inline int launch(const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t 
 	p.out = d_out; p.out_stride = out_stride; p.cnt = d_cnt;
 	p.sin = sin; p.sout = sout;
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
+	p.mode = c.mode; p.output_scale = c.output_scale;
 	p.D = c.downsample; p.q4096 = kTileSamples / p.D; p.r4096 = kTileSamples % p.D;
 	p.out_cap = kTileSamples / p.D + 2;
 	int target_waves = 8192;
@@ -270,7 +273,7 @@ inline int launch(const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t 
 	p.segs = segs; p.blocks_per_seg = bps;
 	const int waves = nstreams * segs;
 	const size_t lds_bytes = (size_t)Lds::total(p.out_cap) * 4;
-	if (c.custom_atan == RTLFM_ATAN_STD)
+	if (c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM)
 		hipLaunchKernelGGL((k_boxcar_fused<true>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else
 		hipLaunchKernelGGL((k_boxcar_fused<false>), dim3(waves), dim3(64), lds_bytes, q, p);

@@ -72,6 +72,23 @@ __device__ __forceinline__ void conj_product(int ar, int aj, int br, int bj, int
 }
 
 // ---- atan2 -> Q14 ----------------------------------------------------------
+// am_demod / usb_demod / lsb_demod (src/rtl_fm.c:961-1007) on one decimated sample w = (I, Q):
+// the int16 cast comes before the multiplication by output_scale, the product is stored as int16
+__device__ __forceinline__ int16_t simple_demod(int mode, uint32_t w, int output_scale)
+{
+	const iq16 v = unpack_iq(w);
+	int16_t base;
+	if (mode == RTLFM_MODE_AM) {
+		const int pcm = v.i * v.i + v.q * v.q;
+		base = (int16_t)sqrt((double)pcm);
+	} else if (mode == RTLFM_MODE_USB) {
+		base = (int16_t)(v.i + v.q);
+	} else {
+		base = (int16_t)(v.i - v.q);
+	}
+	return (int16_t)(int)((uint32_t)(int)base * (uint32_t)output_scale);
+}
+
 // polar_discriminant (src/rtl_fm.c:842-849) ends in
 //     (int)(atan2((double)cj, (double)cr) / 3.14159 * (1<<14))
 // i.e. trunc(theta * K) with K = 16384/3.14159 (note the literal).  The library

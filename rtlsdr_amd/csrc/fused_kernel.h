@@ -197,6 +197,7 @@ struct Params {
 	state_t *sout;
 	const int32_t *lut;
 	int variant, rotate;
+	int mode, output_scale;  // RTLFM_MODE_FM, or AM / USB / LSB (run-time discriminator kernels only)
 	int segs, blocks_per_seg;
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps, 4 = reload one (cached) tile
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			pv = prev[0];
 			if (archive) {
 				iq16 w = unpack_iq(V[CZ - 1]);
-				sout->pre_r = w.i; sout->pre_j = w.q;
+				if (STD || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
 			}
 		}
 		int16_t pcm[CZ];
@@ -863,9 +864,10 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			} else if (STD) {
 				v = atan2_q14(cj, cr, nodes);
 			} else {
-				if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
+				if (p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, c, p.output_scale);
+				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
-				if (n == 0 && bs) {
+				if (n == 0 && bs && p.mode == RTLFM_MODE_FM) {
 					// first output of a buffer is always polar_discriminant (:935-937)
 					int vs = atan2_q14(cj, cr, nodes);
 					if (lane == 0) v = vs;
@@ -904,7 +906,8 @@ struct Workspace {
 
 inline bool supported(const rtlfm_cfg &c, int nblocks)
 {
-	if (c.mode != RTLFM_MODE_FM) return false;
+	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
+		return false;
 	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
 	if (c.block_len % kTileBytes) return false;
 	if (c.dc_block_raw || c.squelch_level) return false;
@@ -936,6 +939,8 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.out = d_out; p.out_stride = out_stride;
 	p.sin = sin; p.sout = sout; p.lut = lut;
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
+	p.mode = c.mode; p.output_scale = c.output_scale;
+	if (c.mode != RTLFM_MODE_FM) p.variant = RTLFM_ATAN_FAST;  // any value but STD: the run-time kernels carry the mode switch
 	p.taps = make_taps(p.rotate != 0);
 	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the MFMA
 	// form: its coalesced tile loads can be non-temporal (load_stream16), which removes the cost

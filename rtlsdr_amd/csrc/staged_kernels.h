@@ -412,21 +412,11 @@ k_simple_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restri
 		const int Ts = cnt ? cnt[s] : T;
 		if (t >= Ts) continue;
 		uint32_t w = X[s * xstride + t];
-		iq16 v = unpack_iq(w);
 		if (mode == RTLFM_MODE_RAW) {
 			reinterpret_cast<uint32_t *>(R + s * rstride)[t] = w;
 			continue;
 		}
-		int16_t base;
-		if (mode == RTLFM_MODE_AM) {
-			int pcm = v.i * v.i + v.q * v.q;
-			base = (int16_t)sqrt((double)pcm);
-		} else if (mode == RTLFM_MODE_USB) {
-			base = (int16_t)(v.i + v.q);
-		} else {
-			base = (int16_t)(v.i - v.q);
-		}
-		R[s * rstride + t] = (int16_t)(int)((uint32_t)(int)base * (uint32_t)output_scale);
+		R[s * rstride + t] = simple_demod(mode, w, output_scale);
 	}
 }
 

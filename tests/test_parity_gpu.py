@@ -367,6 +367,30 @@ def test_fused_boxcar_fullscale_and_tail(oracle_lib, D):
         assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
 
 
+@pytest.mark.parametrize("mode", [capi.MODE_AM, capi.MODE_USB, capi.MODE_LSB])
+@pytest.mark.parametrize("dec", [dict(downsample=16, downsample_passes=4), dict(downsample=8, downsample_passes=3, comp_fir_size=9),
+                                 dict(downsample=10, downsample_passes=0), dict(downsample=64, downsample_passes=6)])
+def test_fused_am_usb_lsb(oracle_lib, mode, dec):
+    """am_demod / usb_demod / lsb_demod (src/rtl_fm.c:961-1007) behind the one-launch front ends
+    (fifth_order chain and boxcar), with output_scale, against the oracle and the staged kernels;
+    pre_r / pre_j must stay untouched (only fm_demod writes them)."""
+    L, nb, ns = 16384, 3, 6
+    ov = dict(mode=mode, output_scale=3 if mode == capi.MODE_AM else 1, rate_out=24000, **dec)
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=400 + mode, fs=1.024e6, dev_hz=5e3, amplitude=50.0)
+    iq[0] = synth.random_u8(1, L * nb, seed=401)[0]  # full-scale bytes: the int16 wraps
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    fo, fst, used = gpu_run(cfg, iq, path=2, splits=[(0, 1), (1, nb)])
+    assert used == 2
+    so, sst, used1 = gpu_run(cfg, iq, path=1)
+    assert used1 == 1
+    for s in range(ns):
+        assert np.array_equal(fo[s], so[s]), (mode, s)
+        assert_parity(fo[s], want[s, :want_len[s]], cfg, f"mode {mode}[{s}]")
+        assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False)
+        assert fst[s].pre_r == 0 and fst[s].pre_j == 0
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
