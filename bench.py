@@ -47,11 +47,11 @@ def parse():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 staged, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--check", type=int, default=1, help="verify a slice against the oracle before timing")
+    ap.add_argument("--check", type=int, default=1, help="have the cpu_baseline leg compare a slice of the GPU output with the CPU path")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, iq_host_sample, seconds):
+def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
     """CPU baseline on the GPU box's host cores, bounded to roughly `seconds`.
 
     kind "reference": the reference's own rtlsdr_callback() + full_demod(), compiled
@@ -63,7 +63,15 @@ def cpu_baseline(cfg, iq_host_sample, seconds):
     """
     import ctypes as C
 
+    import numpy as np
     from oracle import pyoracle as po
+    if gate is not None:
+        # parity of the measured product path with the CPU path on a slice of the same input
+        gcfg, giq, gout, glen = gate
+        want, wl, _ = po.run_batch(gcfg, giq, nthreads=4)
+        assert (glen == wl).all(), "parity gate: output counts differ"
+        d = np.abs(gout[:, :wl[0]].astype(np.int32) - want[:, :wl[0]].astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, f"parity gate failed: max {d.max()}, {(d != 0).sum()} differ"
     cores = os.cpu_count() or 1
     ns, nbytes = iq_host_sample.shape
     L = int(cfg.block_len)
@@ -182,20 +190,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # parity gate on a slice before any timing (rank 0): the same handle type, same kernels
-    if a.check and rank == 0:
-        from oracle import pyoracle as po
+    # a slice through the product before any timing (rank 0): the same handle type, same kernels;
+    # the cpu_baseline leg below compares it with the CPU path's output for the same bytes
+    gate = None
+    if a.check and rank == 0 and not a.no_cpu_baseline and world == 1:
         cs, cb = min(S, 8), min(NB, 2)
         ccfg = RtlfmCfg.from_buffer_copy(bytes(cfg)); ccfg.max_blocks = cb
         sub = iq[:cs, :cb * L].contiguous()
         with GpuDemod(ccfg, cs, local_rank) as gc:
             gc.set_path(a.path)
             o, n = gc.run_torch(sub); gc.sync()
-        want, wl, _ = po.run_batch(ccfg, sub.cpu().numpy(), nthreads=4)
-        o = o.cpu().numpy(); n = n.cpu().numpy()
-        assert (n == wl).all()
-        d = np.abs(o[:, :wl[0]].astype(np.int32) - want[:, :wl[0]].astype(np.int32))
-        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, f"parity gate failed: max {d.max()}, {(d != 0).sum()} differ"
+        gate = (ccfg, sub.cpu().numpy(), o.cpu().numpy(), n.cpu().numpy())
 
     for _ in range(a.warmup):
         step()
@@ -258,7 +263,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             cs = min(S, os.cpu_count() or 1)
             sample = iq[:cs, :min(NB, 2) * L].contiguous().cpu().numpy()
-            res["cpu_baseline"] = cpu_baseline(cfg, sample, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(cfg, sample, a.cpu_seconds, gate)
+            res["cpu_baseline"]["parity_checked"] = gate is not None
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
