@@ -391,6 +391,68 @@ def test_fused_am_usb_lsb(oracle_lib, mode, dec):
         assert fst[s].pre_r == 0 and fst[s].pre_j == 0
 
 
+def _random_cfg(rng):
+    """One random but valid-looking rtl_fm configuration (the library may still reject it)."""
+    ov = {}
+    ov["mode"] = int(rng.choice([capi.MODE_FM] * 5 + [capi.MODE_AM, capi.MODE_USB, capi.MODE_LSB, capi.MODE_RAW]))
+    if rng.random() < 0.55:
+        p_ = int(rng.integers(1, 8))
+        ov.update(downsample=1 << p_, downsample_passes=p_, comp_fir_size=int(rng.choice([0, 9])))
+    else:
+        ov.update(downsample=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 25, 32, 50, 64, 128, 255, 256])),
+                  downsample_passes=0)
+    ov["custom_atan"] = int(rng.integers(0, 3))
+    ov["offset_tuning"] = int(rng.random() < 0.25)
+    ov["output_scale"] = int(rng.choice([1, 1, 2, 5]))
+    ov["rate_out"] = int(rng.choice([8000, 16000, 24000, 48000, 170000]))
+    if rng.random() < 0.35:
+        ov.update(deemph=1, deemph_a=int(rng.choice([1, 2, 3, 9, 13, 19, 400])))
+    if rng.random() < 0.2:
+        ov["dc_block_audio"] = 1
+    if rng.random() < 0.15:
+        ov.update(dc_block_raw=1)
+    if rng.random() < 0.15:
+        ov["post_downsample"] = int(rng.choice([2, 3, 4]))
+    if rng.random() < 0.15:
+        ov["squelch_level"] = int(rng.choice([5, 50, 2000]))
+    r = rng.random()
+    if r < 0.2:
+        ov.update(rate_out2=int(ov["rate_out"] * rng.choice([0.25, 0.4, 0.5, 0.9])), resampler=capi.RESAMPLE_LOW_PASS_REAL)
+    elif r < 0.4:
+        ov.update(rate_out2=int(ov["rate_out"] * rng.choice([0.5, 0.73, 1.38, 2.0])), resampler=RESAMPLE_ARBITRARY)
+    return ov
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations_vs_oracle(oracle_lib, seed):
+    """Seeded random configurations through the automatic path selection (fused fifth_order /
+    fused boxcar / staged, + tail) and through the staged kernels only, against the oracle:
+    same outputs, same carried state, also when the run is split into launches."""
+    from rtlsdr_amd.demod import GpuDemod
+    rng = np.random.default_rng(9000 + seed)
+    ov = _random_cfg(rng)
+    L = int(rng.choice([8192, 16384, 16384, 32768, 4096, 24576]))
+    nb = int(rng.integers(2, 6))
+    ns = int(rng.choice([1, 2, 5, 33]))
+    cfg = make_cfg(ov, L, nb)
+    try:
+        GpuDemod(cfg, ns, 0).close()
+    except capi.RtlfmError as e:
+        pytest.skip(f"configuration rejected by rtlfm_gpu_create: {e}")
+    amp = 25.0 if ov["custom_atan"] == 1 and ov["mode"] == capi.MODE_FM else 55.0
+    if ov["custom_atan"] == 1 and ov["downsample_passes"] == 0:
+        amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=7000 + seed, fs=1.024e6, dev_hz=20e3, amplitude=amp)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=2)
+    cut = int(rng.integers(1, nb))
+    for path, splits in ((0, None), (0, [(0, cut), (cut, nb)]), (1, None)):
+        outs, sts, _ = gpu_run(cfg, iq, path=path, splits=splits)
+        for s in range(ns):
+            assert len(outs[s]) == want_len[s], (ov, L, nb, path, splits, s)
+            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{ov} L={L} nb={nb} path={path} splits={splits} [{s}]")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
