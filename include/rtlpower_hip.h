@@ -49,7 +49,8 @@ typedef struct rtlpower_cfg {
 	int32_t boxcar;             /* global boxcar, default 1 (:118) */
 	int32_t comp_fir_size;      /* 0 or 9 (:119) */
 	int32_t peak_hold;          /* :120 */
-	uint32_t buf_len;           /* bytes per read */
+	uint32_t buf_len;           /* bytes per read; the last FFT frame of a read must end inside it
+	                             * (frequency_range() uses 2 * 2^bin_e * downsample, at least 16384) */
 } rtlpower_cfg;
 
 /*

@@ -196,6 +196,21 @@ static int validate(const rtlpower_cfg *c)
 		if (c->buf_len % (4u << c->downsample_passes)) return -EINVAL;
 		if ((c->buf_len >> c->downsample_passes) < 48) return -EINVAL;  // ease-in reads x[0..8], fir 9 more
 	}
+	// scanner() transforms frames at offsets 0, 2N, ... < buf_len/ds (src/rtl_power.c:695).  A
+	// trailing frame may run past the decimated data; inside buf_len it then sees this read's
+	// own leftovers (reproduced here), but past buf_len it would see the previous read's FFT
+	// output still lying in the reference's static fft_buf.  The reference's planner never
+	// produces that (buf_len = 2N * downsample, at least 16384: src/rtl_power.c:501-504); it is rejected here.
+	{
+		const long long two_n = 2ll << c->bin_e;
+		const long long per = (long long)c->buf_len / c->downsample;
+		const long long frames = (per + two_n - 1) / two_n;
+		if (frames * two_n > (long long)c->buf_len) return -EINVAL;
+		// With fifth_order passes a partial trailing frame would cover the intermediate passes'
+		// leftovers; powers of two never produce one through frequency_range(), only the boxcar
+		// with an odd ratio does, and that case is reproduced.
+		if (!c->boxcar && c->downsample_passes && per % two_n) return -EINVAL;
+	}
 	return 0;
 }
 

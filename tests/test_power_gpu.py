@@ -61,6 +61,38 @@ def test_power_batched_vs_oracle(oracle_lib, kw):
             assert np.array_equal(res[s][0], want[s]), (kw, s, split)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_power_random_configurations(oracle_lib, seed):
+    """Seeded random rtl_power configurations (bin size, window, boxcar / fifth_order + FIR
+    decimation, peak hold, read size, streams, reads split over launches) against the oracle."""
+    from rtlsdr_amd import capi
+    from rtlsdr_amd.power import GpuPower
+    rng = np.random.default_rng(5000 + seed)
+    kw = dict(bin_e=int(rng.integers(0, 15)), window=int(rng.integers(0, 8)), peak_hold=int(rng.random() < 0.25))
+    kw["buf_len"] = int(rng.choice([16384, 16384, 32768, 65536]))
+    r = rng.random()
+    if r < 0.3:
+        kw.update(downsample=int(rng.choice([2, 3, 5, 7, 16])), boxcar=1)
+    elif r < 0.6:
+        p_ = int(rng.integers(1, 5))
+        kw.update(downsample=1 << p_, downsample_passes=p_, boxcar=0, comp_fir_size=int(rng.choice([0, 9])))
+    cfg = RtlpowerCfg.default(**kw)
+    ns = int(rng.choice([1, 3, 10]))
+    try:
+        GpuPower(cfg, ns, 0).close()
+    except capi.RtlfmError as e:
+        pytest.skip(f"rejected by rtlpower_gpu_create: {e}")
+    L, nr = int(cfg.buf_len), int(rng.integers(2, 5))
+    iq = np.concatenate([synth.fm_iq_u8(ns, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=100 + seed),
+                         synth.random_u8(1, L * nr, seed=200 + seed)])
+    want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=2)
+    for split in (None, 1):
+        res = gpu_scan(cfg, iq, split=split)
+        for s in range(ns + 1):
+            assert res[s][1] == wn[s], (kw, s, split)
+            assert np.array_equal(res[s][0], want[s]), (kw, s, split)
+
+
 def test_power_host_scanner_and_clear(oracle_lib):
     """rtlsdr_read_sync-shaped entry point (one tuning state, one host buffer) + csv_dbm's reset."""
     from rtlsdr_amd.power import GpuPower
