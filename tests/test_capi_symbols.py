@@ -74,6 +74,38 @@ def test_planner_matches_oracle(lib, oracle_lib):
             assert lib.rtlfm_deemph_a(rate, tc) == oracle_lib.oracle().orc_deemph_a(rate, tc)
 
 
+def test_planner_random_against_live_reference(lib, oracle_lib):
+    """rtlfm_optimal_settings / rtlfm_deemph_a against the reference's own static optimal_settings()
+    and deemph_a expression, compiled in place, on a seeded random sweep of tool arguments."""
+    if not oracle_lib.have_reference():
+        pytest.skip("oracle/_ref not built here")
+    import numpy as np
+    rng = np.random.default_rng(1234)
+    ref = oracle_lib.Reference()
+    try:
+        for _ in range(400):
+            mode = int(rng.integers(0, 5))
+            freq = int(rng.integers(24_000_000, 1_700_000_000))
+            rate_in = int(rng.choice([8000, 12000, 16000, 24000, 32000, 48000, 150000, 170000, 240000, 250000,
+                                      int(rng.integers(3000, 1_200_000))]))
+            mcr = int(rng.choice([1_000_000, 1_300_000, 2_200_000, int(rng.integers(900_000, 3_000_000))]))
+            fifth = int(rng.integers(0, 2))
+            edge = int(rng.integers(0, 2))
+            offs = int(rng.integers(0, 2))
+            want = ref.optimal_settings(freq, rate_in, mcr, fifth, edge, mode, offs)
+            cfg = capi.RtlfmCfg.default(mode=mode, offset_tuning=offs)
+            cf, cr = C.c_uint32(), C.c_uint32()
+            assert lib.rtlfm_optimal_settings(C.byref(cfg), freq, rate_in, mcr, fifth, edge, C.byref(cf), C.byref(cr)) == 0
+            got = dict(downsample=cfg.downsample, downsample_passes=cfg.downsample_passes,
+                       output_scale=cfg.output_scale, capture_freq=cf.value, capture_rate=cr.value)
+            assert got == want, (mode, freq, rate_in, mcr, fifth, edge, offs)
+    finally:
+        ref.close()
+    for rate in rng.integers(4000, 400000, 300):
+        for tc in (75, 50, 25, 10):
+            assert lib.rtlfm_deemph_a(int(rate), tc) == oracle_lib.oracle().orc_deemph_a(int(rate), tc)
+
+
 def test_result_len_and_cap(lib, oracle_lib):
     from cases import CASES, make_cfg
     for name, ov, _ in CASES:

@@ -134,3 +134,43 @@ def test_planner_and_csv_match_reference(oracle_lib, arg, crop, boxcar):
             assert n == rn and buf.value == rbuf.value
     finally:
         ref.close()
+
+
+def test_planner_random_against_live_reference(oracle_lib):
+    """rtlpower_frequency_range against the reference's frequency_range() (compiled in place) on a
+    seeded random sweep of ranges, bin sizes, crop factors and both decimator kinds."""
+    if not oracle_lib.have_power_reference():
+        pytest.skip("oracle/_ref not built here")
+    from rtlsdr_amd import capi
+    from rtlsdr_amd import build as hipbuild
+    hipbuild.build()
+    lib = capi.load()
+    rng = np.random.default_rng(77)
+    ref = oracle_lib.PowerReference()
+    try:
+        ref.lib.ref_frequency_range.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        for _ in range(250):
+            lo = int(rng.integers(24_000_000, 1_600_000_000))
+            width = int(rng.choice([rng.integers(20_000, 900_000), rng.integers(900_000, 3_000_000),
+                                    rng.integers(3_000_000, 400_000_000)]))
+            step = int(rng.choice([rng.integers(500, 20_000), rng.integers(20_000, 900_000),
+                                   rng.integers(1_000_000, 2_500_000)]))
+            crop = float(rng.choice([0.0, 0.0, 0.1, 0.25, 0.5]))
+            boxcar = int(rng.integers(0, 2))
+            arg = f"{lo}:{lo + width}:{step}"
+            plan = capi.RtlpowerPlan()
+            r = lib.rtlpower_frequency_range(lo, lo + width, step, crop, boxcar, C.byref(plan))
+            if r != 0:
+                continue  # rejected (the reference would exit or misbehave); covered by the fixed cases
+            o = np.zeros(10, dtype=np.int32); rc = C.c_double()
+            ref.lib.ref_frequency_range(arg.encode(), crop, boxcar, o.ctypes.data, C.byref(rc))
+            assert plan.tune_count == o[0], (arg, crop, boxcar)
+            if plan.tune_count == 0:
+                continue  # an empty plan (giant bins wider than the range): nothing else is defined
+            last = plan.tune_count - 1
+            got = (plan.rate, plan.bin_e, plan.downsample, plan.downsample_passes, plan.buf_len,
+                   lib.rtlpower_tune_freq(C.byref(plan), 0), lib.rtlpower_tune_freq(C.byref(plan), last), plan.crop)
+            want = (o[2], o[3], o[4], o[5], o[6], o[7], o[8], rc.value)
+            assert got == want, (arg, crop, boxcar)
+    finally:
+        ref.close()
