@@ -91,6 +91,77 @@ def test_oracle_matches_live_reference(oracle_lib, name, ov, sig):
     assert gu.state_dict(st) == gu.state_dict(rst)
 
 
+def _random_ref_cfg(rng):
+    """A random configuration the reference itself can run (no division by zero in low_pass_real,
+    passes within cic_9_tables, amplitudes that keep -A fast clear of its int32 wrap)."""
+    from rtlsdr_amd import capi
+    ov = {"mode": int(rng.choice([capi.MODE_FM] * 5 + [capi.MODE_AM, capi.MODE_USB, capi.MODE_LSB, capi.MODE_RAW]))}
+    if rng.random() < 0.55:
+        p_ = int(rng.integers(1, 9))
+        ov.update(downsample=1 << p_, downsample_passes=p_, comp_fir_size=int(rng.choice([0, 9])))
+    else:
+        ov.update(downsample=int(rng.choice([1, 2, 3, 5, 6, 10, 16, 25, 64, 100, 255, 256])), downsample_passes=0)
+    ov["custom_atan"] = int(rng.integers(0, 3))
+    ov["offset_tuning"] = int(rng.random() < 0.25)
+    ov["output_scale"] = int(rng.choice([1, 1, 2, 5]))
+    ov["rate_out"] = int(rng.choice([8000, 16000, 24000, 48000, 170000]))
+    if rng.random() < 0.4:
+        ov.update(deemph=1, deemph_a=int(rng.choice([1, 2, 3, 9, 13, 19, 400])))
+    if rng.random() < 0.25:
+        ov["dc_block_audio"] = 1
+    if rng.random() < 0.2:
+        ov["dc_block_raw"] = 1
+    if rng.random() < 0.2:
+        ov["post_downsample"] = int(rng.choice([2, 3, 4]))
+    if rng.random() < 0.2:
+        ov["squelch_level"] = int(rng.choice([5, 50, 2000]))
+    r = rng.random()
+    if r < 0.25:
+        ov.update(rate_out2=int(ov["rate_out"] * rng.choice([0.25, 0.4, 0.5, 0.9])), resampler=capi.RESAMPLE_LOW_PASS_REAL)
+    elif r < 0.45:
+        ov.update(rate_out2=int(ov["rate_out"] * rng.choice([0.5, 0.73, 1.38, 2.0])), resampler=capi.RESAMPLE_ARBITRARY)
+    return ov
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_oracle_random_configurations_vs_live_reference(oracle_lib, seed):
+    """The restatement against the reference's own full_demod() (compiled in place) on seeded
+    random configurations: every sample and the complete carried state."""
+    if not oracle_lib.have_reference():
+        pytest.skip("oracle/_ref not built here")
+    rng = np.random.default_rng(31000 + seed)
+    ov = _random_ref_cfg(rng)
+    L = int(rng.choice([1024, 2048, 4096, 8192, 16384]))
+    if ov["downsample_passes"]:
+        while L % (2 << ov["downsample_passes"]) or (L // 2) >> ov["downsample_passes"] < 8:
+            L *= 2
+    nb = int(rng.integers(2, 6))
+    cfg = make_cfg(ov, L)
+    # stages that need the same count in every buffer are defined only when the boxcar divides it
+    per = (L // 2) // ov["downsample"] if ov["downsample_passes"] == 0 else (L // 2) >> ov["downsample_passes"]
+    uneven = ov["downsample_passes"] == 0 and (L // 2) % ov["downsample"]
+    if uneven and (ov.get("post_downsample", 1) > 1 or ov.get("dc_block_audio") or ov.get("resampler") == 1 and ov.get("rate_out2", 0) > 0):
+        pytest.skip("per-buffer stage behind a boxcar that does not divide the buffer")
+    if ov.get("post_downsample", 1) > 1 and per % ov["post_downsample"]:
+        pytest.skip("post_downsample does not divide the buffer's output")
+    amp = 55.0
+    if ov["custom_atan"] == 1 and ov["mode"] == 0:
+        gain = ov["downsample"] if ov["downsample_passes"] == 0 else 1 << ov["downsample_passes"]
+        amp = max(2.0, min(40.0, 500.0 / gain))
+    iq = synth.fm_iq_u8(1, L // 2 * nb, seed=600 + seed, fs=1.024e6, dev_hz=20e3, amplitude=amp)[0]
+    try:
+        got, st = oracle_lib.run_stream(cfg, iq)
+    except RuntimeError:
+        pytest.skip("configuration rejected by the oracle")
+    ref = oracle_lib.Reference()
+    try:
+        want, rst = ref.run_stream(cfg, iq)
+    finally:
+        ref.close()
+    assert np.array_equal(got, want), (ov, L, nb)
+    assert gu.state_dict(st) == gu.state_dict(rst), (ov, L, nb)
+
+
 def test_batch_threads_equal_serial(oracle_lib):
     ov, sig = CASES[1][1], CASES[1][2]
     cfg = make_cfg(ov, 2048)
