@@ -33,8 +33,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    # a launch is ~0.9 ms; after idle the GPU needs ~50 of them to reach its steady clock
+    # (30 timed launches behind 5 warm-ups measure the ramp: 0.91 ms against 0.83 ms)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=64, help="callback buffers per stream per step")
     ap.add_argument("--block-len", type=int, default=262144)
