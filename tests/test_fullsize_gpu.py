@@ -95,6 +95,30 @@ def test_c3_full_size_4096_nbfm_streams(oracle_lib):
         assert gu.state_dict(fst[s], False) == gu.state_dict(sst[s], False)
 
 
+def test_c5_stream_count_on_one_gpu(oracle_lib):
+    """configs[4]'s whole population (32768 NBFM streams) on one GPU, one 262144-B buffer each
+    (8 GiB of IQ): fused front end + tail against the staged kernels on every sample, and against
+    the oracle on sampled streams."""
+    S, NB, L = 32768, 1, 262144
+    cfg = RtlfmCfg.default(downsample=64, downsample_passes=6, comp_fir_size=9, deemph=1, deemph_a=2,
+                           rate_out=16000, rate_out2=22050, resampler=RESAMPLE_ARBITRARY,
+                           block_len=L, max_blocks=1)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0), fs=1.024e6, dev_hz=2.5e3)
+    fo, fl, fst, used = _run(cfg, iq, 2)
+    assert used == 2
+    so, sl, sst, _ = _run(cfg, iq, 1)
+    n = int(fl[0][0])
+    assert n == 2822 and torch.equal(fl[0], sl[0])
+    assert torch.equal(fo[0][:, :n], so[0][:, :n])
+    for s in (0, 4095, 4096, 20000, 32767):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        got = fo[0][s, :n].cpu().numpy()
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()))
+    for s in fst:
+        assert gu.state_dict(fst[s], False) == gu.state_dict(sst[s], False)
+
+
 def test_default_buffer_size_many_buffers(oracle_lib):
     """rtl_fm's default 16384-B buffers (every 2nd tile starts a buffer): 64 streams x 512 buffers."""
     S, NB, L = 64, 512, 16384
