@@ -200,7 +200,8 @@ struct Params {
 	int mode, output_scale;  // RTLFM_MODE_FM, or AM / USB / LSB (run-time discriminator kernels only)
 	int segs, blocks_per_seg;
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
-	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps, 4 = reload one (cached) tile
+	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps (printed per launch; +16 = 18:
+	            // only on timing_read, i.e. for the last launch of an uninterrupted run), 4 = reload one (cached) tile
 	unsigned long long *stamps;  // [waves][4] when debug & 2
 	Pass0Taps taps;
 };

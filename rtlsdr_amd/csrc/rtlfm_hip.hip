@@ -353,11 +353,18 @@ extern "C" int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on)
 	return 0;
 }
 
+static int fused_debug();
+static int report_clock_stamps(rtlfm_gpu *h);
+
 extern "C" int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches)
 {
 	if (!h) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	if (h->fws.stamps && (fused_debug() & 16)) {
+		int r2 = report_clock_stamps(h);
+		if (r2 < 0) return r2;
+	}
 	double total = 0;
 	int n = 0;
 	for (auto &p : h->ev_pending) {
@@ -610,6 +617,29 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, d_out, out_stride, d_out_len);
 }
 
+static int fused_debug()
+{
+	const char *e = getenv("RTLFM_FUSED_DEBUG");
+	return e ? atoi(e) : 0;
+}
+
+// diagnostic: shader clock held during the last fused launch (s_memtime vs the 100 MHz s_memrealtime)
+static int report_clock_stamps(rtlfm_gpu *h)
+{
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	std::vector<unsigned long long> st((size_t)h->fws.stamp_waves * 4);
+	HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+	double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+	for (int w = 0; w < h->fws.stamp_waves; w++) {
+		double dc = (double)(st[w * 4 + 1] - st[w * 4]), dr = (double)(st[w * 4 + 3] - st[w * 4 + 2]);
+		if (dr > 0) { sum += dc / dr * 100.0; n++; }
+		if (st[w * 4 + 2] < t0) t0 = st[w * 4 + 2];
+		if (st[w * 4 + 3] > t1) t1 = st[w * 4 + 3];
+	}
+	fprintf(stderr, "rtlfm_hip[debug]: mean shader clock %.0f MHz over %d waves, kernel span %.3f ms\n", sum / n, n, (t1 - t0) / 1e5);
+	return 0;
+}
+
 static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
                      size_t out_stride, int32_t *d_out_len)
 {
@@ -632,19 +662,12 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
-	if (h->fws.stamps && getenv("RTLFM_FUSED_DEBUG") && (atoi(getenv("RTLFM_FUSED_DEBUG")) & 2)) {
-		// diagnostic: shader clock held during the launch (s_memtime vs the 100 MHz s_memrealtime)
-		HIP_TRY(hipStreamSynchronize(q));
-		std::vector<unsigned long long> st((size_t)h->fws.stamp_waves * 4);
-		HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
-		double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
-		for (int w = 0; w < h->fws.stamp_waves; w++) {
-			double dc = (double)(st[w * 4 + 1] - st[w * 4]), dr = (double)(st[w * 4 + 3] - st[w * 4 + 2]);
-			if (dr > 0) { sum += dc / dr * 100.0; n++; }
-			if (st[w * 4 + 2] < t0) t0 = st[w * 4 + 2];
-			if (st[w * 4 + 3] > t1) t1 = st[w * 4 + 3];
-		}
-		fprintf(stderr, "rtlfm_hip[debug]: mean shader clock %.0f MHz over %d waves, kernel span %.3f ms\n", sum / n, n, (t1 - t0) / 1e5);
+	// bit 2 with bit 8: report the stamps of every launch (synchronises, so the GPU idles between
+	// launches and clocks up); bit 2 alone with bit 16: only when timing_read() asks, i.e. the last
+	// launch of an uninterrupted sequence
+	if (h->fws.stamps && (fused_debug() & 2) && !(fused_debug() & 16)) {
+		int r2 = report_clock_stamps(h);
+		if (r2 < 0) return r2;
 	}
 	const int T = nblocks * (int)((c.block_len / 2) >> c.downsample_passes);
 	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
