@@ -198,6 +198,10 @@ struct Params {
 	const int32_t *lut;
 	int variant, rotate;
 	int mode, output_scale;  // RTLFM_MODE_FM, or AM / USB / LSB (run-time discriminator kernels only)
+	// 7..10 passes: the 6-pass kernel stops after its last pass and emits the /64 IQ (packed int16
+	// pairs, index = tile * 64 + lane) for the staged kernels to finish (run_fused_deep)
+	uint32_t *emit_iq;
+	size_t emit_iq_stride;  // dwords between streams
 	int segs, blocks_per_seg;
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps (printed per launch; +16 = 18:
@@ -485,7 +489,12 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	// into the wait that precedes pass 0 of the next tile.
 	int16_t held[CZ];
 	int16_t *held_dst = nullptr;
+	uint32_t held_iq = 0;
+	uint32_t *held_iq_dst = nullptr;
 	auto flush_held = [&]() {
+		if constexpr (P == 6) {
+			if (held_iq_dst) { *held_iq_dst = held_iq; held_iq_dst = nullptr; }
+		}
 		if (held_dst) {
 			int16_t *dst = held_dst;
 			if constexpr (CZ >= 8) {
@@ -799,6 +808,15 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 
 		RTLFM_MARK("passes_done");
+		if constexpr (P == 6) {
+			if (p.emit_iq) {
+				if (emit) {
+					held_iq_dst = p.emit_iq + (size_t)s * p.emit_iq_stride + (size_t)gt * 64 + lane;
+					held_iq = Z[0];
+				}
+				continue;
+			}
+		}
 		// --------------------------------------------------------- generic_fir ----
 		uint32_t V[CZ];  // what fm_demod sees
 		if constexpr (FIR9) {
@@ -905,6 +923,16 @@ struct Workspace {
 	}
 };
 
+// 7..10 passes: the six-pass kernel in emit_iq mode plus the staged kernels for the rest
+inline bool supported_deep(const rtlfm_cfg &c)
+{
+	if (c.mode == RTLFM_MODE_RAW) return false;
+	if (c.downsample_passes <= kMaxP || c.downsample_passes > RTLFM_MAX_PASSES) return false;
+	if (c.block_len % kTileBytes) return false;
+	if (c.dc_block_raw || c.squelch_level) return false;
+	return true;
+}
+
 inline bool supported(const rtlfm_cfg &c, int nblocks)
 {
 	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
@@ -929,12 +957,14 @@ static int launch_one(const Params &p, int waves, hipStream_t q)
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 
+// emit_iq != nullptr: 7..10 passes - run the first six and emit the /64 IQ instead of PCM
 inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, const state_t *sin, state_t *sout,
-                  const int32_t *lut, hipStream_t q)
+                  const int32_t *lut, hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0)
 {
-	if (((uintptr_t)d_out & 15) || (out_stride & 7)) return -EINVAL;
+	if (!emit_iq && (((uintptr_t)d_out & 15) || (out_stride & 7))) return -EINVAL;
 	Params p{};
+	p.emit_iq = emit_iq; p.emit_iq_stride = emit_iq_stride;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
 	p.nblocks = nblocks; p.nstreams = nstreams;
 	p.out = d_out; p.out_stride = out_stride;
@@ -980,6 +1010,10 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	if (p.debug & 2) {
 		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
 		p.stamps = ws.stamps;
+	}
+	if (emit_iq) {
+		p.variant = RTLFM_ATAN_STD; p.mode = RTLFM_MODE_FM;  // no discriminator runs: any 6-pass instantiation will do
+		return launch_one<6, false>(p, waves, q);
 	}
 	const bool fir = c.comp_fir_size == 9;
 	switch (c.downsample_passes * 2 + (fir ? 1 : 0)) {

@@ -50,6 +50,8 @@ struct rtlfm_gpu {
 	int16_t *d_result = nullptr;      // run()/fetch() result, rstride
 	int32_t *d_result_len = nullptr;  // [nstreams]
 	int32_t *d_cnt = nullptr, *d_cnt2 = nullptr;
+	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
+	size_t deep_stride = 0;
 	state_t *st[2] = {nullptr, nullptr};
 	int st_cur = 0;
 	int32_t *d_lut = nullptr;
@@ -278,7 +280,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	hipStreamSynchronize(h->stream);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
+	void *ptrs[] = {h->deepA, h->deepB, h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
 	                h->st[0], h->st[1], h->d_lut, h->d_mute, h->d_sums, h->d_rdc_avg, h->d_adc_avg, h->d_in};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -673,6 +675,60 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
 }
 
+// 7..10 fifth_order passes: the six-pass fused kernel emits the /64 IQ into a small work buffer
+// (same layout as the staged path's level-6 buffer: a stream's buffers back to back), and the
+// staged kernels run the remaining passes, the FIR and the demodulator on 1/64 of the data.
+static int run_fused_deep(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
+                          size_t out_stride, int32_t *d_out_len)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	const int N0 = (int)(c.block_len / 2);
+	hipStream_t q = h->stream;
+	const state_t *sin = h->st[h->st_cur];
+	state_t *sout = h->st[h->st_cur ^ 1];
+	if (!h->deepA) {
+		h->deep_stride = (size_t)h->cap_blocks * (N0 >> 6);
+		HIP_TRY(hipMalloc(&h->deepA, (size_t)S * h->deep_stride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc(&h->deepB, (size_t)S * h->deep_stride * sizeof(uint32_t)));
+	}
+	TailPlan tp = plan_tail(c);
+	if (tp.any()) {
+		int r = ensure_res_buffers(h);
+		if (r < 0) return r;
+	}
+	std::pair<hipEvent_t, hipEvent_t> ev;
+	int r = timing_begin(h, ev);
+	if (r < 0) return r;
+	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, sin, sout, h->d_lut, q, h->deepA,
+	                  h->deep_stride);
+	if (r < 0) return r;
+	r = timing_end(h, ev);
+	if (r < 0) return r;
+	uint32_t *cur = h->deepA, *oth = h->deepB;
+	for (int p = 6; p < c.downsample_passes; p++) {
+		const int N = N0 >> p;
+		k_fifth<<<grid_for((size_t)S * nblocks * (N / 2)), 256, 0, q>>>(cur, oth, h->deep_stride, N, nblocks, S, p,
+		                                                              sin, sout);
+		std::swap(cur, oth);
+	}
+	const int Nblk = N0 >> c.downsample_passes;
+	const int T = nblocks * Nblk;
+	if (c.comp_fir_size == 9) {
+		k_fir9<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, oth, h->deep_stride, T, S, c.downsample_passes, sin, sout);
+		std::swap(cur, oth);
+	}
+	int16_t *dd; size_t dds;
+	tail_route(h, tp, d_out, out_stride, &dd, &dds);
+	if (c.mode == RTLFM_MODE_FM)
+		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, Nblk, 1, c.custom_atan,
+		                                                 h->d_lut, nullptr, sin, sout);
+	else
+		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, c.mode,
+		                                                     c.output_scale, nullptr);
+	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
+}
+
 // The boxcar (low_pass) front end in one launch; output counts may differ per buffer and
 // per stream (d_cnt), which the order-insensitive tail stages accept (run_tail, varcnt).
 static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
@@ -717,15 +773,19 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
+	const bool can_deep = fused::supported_deep(h->cfg);
 	int r;
-	if (h->path == 2 && !can_fuse && !can_box) return -ENOTSUP;
+	if (h->path == 2 && !can_fuse && !can_box && !can_deep) return -ENOTSUP;
 	// state is double-buffered: kernels read st[cur], write st[cur^1].  The staged kernels each
 	// update their own fields, so the record is copied first; the fused kernels copy it themselves.
-	if (!(h->path != 1 && (can_fuse || can_box)))
+	if (!(h->path != 1 && (can_fuse || can_box || can_deep)))
 		HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
 		                       hipMemcpyDeviceToDevice, h->stream));
 	if (h->path != 1 && can_box) {
 		r = run_boxfused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+		h->last_path = 2;
+	} else if (h->path != 1 && can_deep) {
+		r = run_fused_deep(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
 	} else if (h->path != 1 && can_fuse) {
 		r = run_fused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);

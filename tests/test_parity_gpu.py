@@ -453,6 +453,31 @@ def test_random_configurations_vs_oracle(oracle_lib, seed):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
 
 
+@pytest.mark.parametrize("passes,fir9,atan,mode", [
+    (7, 0, 0, 0), (7, 1, 0, 0), (7, 1, 2, 0), (8, 0, 0, 0), (8, 1, 1, 0), (9, 1, 0, 0), (10, 0, 0, 0), (10, 1, 2, 0),
+    (7, 0, 0, 1), (8, 1, 0, 2), (9, 0, 0, 3),
+])
+@pytest.mark.parametrize("L,nb,ns", [(16384, 5, 3), (32768, 3, 33), (262144, 2, 2)])
+def test_fused_deep_passes(oracle_lib, passes, fir9, atan, mode, L, nb, ns):
+    """7..10 fifth_order passes (rtl_fm -F at 12 kHz and below): the six-pass fused kernel emits
+    the /64 IQ and the staged kernels finish; against the oracle and the all-staged path, with
+    split launches and the complete carried state (lp hist of every pass, droop, pre)."""
+    ov = dict(mode=mode, downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0,
+              custom_atan=atan, rate_out=max(1000, int(1.024e6) >> passes), deemph=1, deemph_a=3)
+    cfg = make_cfg(ov, L, nb)
+    amp = 20.0 if atan == 1 else 55.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=3000 + passes, fs=1.024e6, dev_hz=2.5e3, amplitude=amp)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    fo, fst, used = gpu_run(cfg, iq, path=2, splits=[(0, 1), (1, nb)])
+    assert used == 2
+    so, sst, used1 = gpu_run(cfg, iq, path=1)
+    assert used1 == 1
+    for s in range(ns):
+        assert np.array_equal(fo[s], so[s]), (passes, s)
+        assert_parity(fo[s], want[s, :want_len[s]], cfg, f"deep P={passes}[{s}]")
+        assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False)
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
