@@ -198,8 +198,8 @@ struct Params {
 	const int32_t *lut;
 	int variant, rotate;
 	int mode, output_scale;  // RTLFM_MODE_FM, or AM / USB / LSB (run-time discriminator kernels only)
-	// 7..10 passes: the 6-pass kernel stops after its last pass and emits the /64 IQ (packed int16
-	// pairs, index = tile * 64 + lane) for the staged kernels to finish (run_fused_deep)
+	// emit mode: stop after the FIR and store the decimated IQ (packed int16 pairs in time order)
+	// instead of PCM: -M raw, and the input of the staged kernels that finish 7..10 passes
 	uint32_t *emit_iq;
 	size_t emit_iq_stride;  // dwords between streams
 	int segs, blocks_per_seg;
@@ -489,12 +489,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	// into the wait that precedes pass 0 of the next tile.
 	int16_t held[CZ];
 	int16_t *held_dst = nullptr;
-	uint32_t held_iq = 0;
-	uint32_t *held_iq_dst = nullptr;
 	auto flush_held = [&]() {
-		if constexpr (P == 6) {
-			if (held_iq_dst) { *held_iq_dst = held_iq; held_iq_dst = nullptr; }
-		}
 		if (held_dst) {
 			int16_t *dst = held_dst;
 			if constexpr (CZ >= 8) {
@@ -808,15 +803,6 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 
 		RTLFM_MARK("passes_done");
-		if constexpr (P == 6) {
-			if (p.emit_iq) {
-				if (emit) {
-					held_iq_dst = p.emit_iq + (size_t)s * p.emit_iq_stride + (size_t)gt * 64 + lane;
-					held_iq = Z[0];
-				}
-				continue;
-			}
-		}
 		// --------------------------------------------------------- generic_fir ----
 		uint32_t V[CZ];  // what fm_demod sees
 		if constexpr (FIR9) {
@@ -853,6 +839,28 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			for (int k = 0; k < CZ; k++) V[k] = Z[k];
 		}
 
+		if constexpr (!STD) {
+			// emit mode: what full_demod() would hand to mode_demod (the decimated, FIR-compensated
+			// IQ), tile-major and lane-contiguous = time order; used for -M raw and as the input of
+			// the staged kernels that finish 7..10 passes or apply the squelch
+			if (p.emit_iq) {
+				if (emit) {
+					// stored right away (no deferral as for the PCM: keeping CZ more registers alive
+					// through the next tile would cost every kernel of this family its occupancy)
+					uint32_t *dst = p.emit_iq + (size_t)s * p.emit_iq_stride + ((size_t)gt * 64 + lane) * CZ;
+					if constexpr (CZ >= 4) {
+#pragma unroll
+						for (int k = 0; k < CZ / 4; k++)
+							reinterpret_cast<uint4 *>(dst)[k] = make_uint4(V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]);
+					} else if constexpr (CZ == 2) {
+						*reinterpret_cast<uint2 *>(dst) = make_uint2(V[0], V[1]);
+					} else {
+						*dst = V[0];
+					}
+				}
+				continue;
+			}
+		}
 		RTLFM_MARK("fir_done");
 		// ------------------------------------------------------------ fm_demod ----
 		uint32_t pv;
@@ -923,14 +931,14 @@ struct Workspace {
 	}
 };
 
-// 7..10 passes: the six-pass kernel in emit_iq mode plus the staged kernels for the rest
-inline bool supported_deep(const rtlfm_cfg &c)
+// What the front end in emit mode plus staged kernels covers beyond supported(): 7..10 passes,
+// -M raw, and the squelch (rtlfm_hip.hip: run_fused_emit)
+inline bool supported_emit(const rtlfm_cfg &c)
 {
-	if (c.mode == RTLFM_MODE_RAW) return false;
-	if (c.downsample_passes <= kMaxP || c.downsample_passes > RTLFM_MAX_PASSES) return false;
+	if (c.downsample_passes < 1 || c.downsample_passes > RTLFM_MAX_PASSES) return false;
 	if (c.block_len % kTileBytes) return false;
-	if (c.dc_block_raw || c.squelch_level) return false;
-	return true;
+	if (c.dc_block_raw) return false;
+	return c.downsample_passes > kMaxP || c.mode == RTLFM_MODE_RAW || c.squelch_level != 0;
 }
 
 inline bool supported(const rtlfm_cfg &c, int nblocks)
@@ -957,7 +965,8 @@ static int launch_one(const Params &p, int waves, hipStream_t q)
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 
-// emit_iq != nullptr: 7..10 passes - run the first six and emit the /64 IQ instead of PCM
+// emit_iq != nullptr: store the decimated (and FIR-compensated) IQ instead of PCM; with 7..10
+// passes configured, the first six run here (without the FIR)
 inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, const state_t *sin, state_t *sout,
                   const int32_t *lut, hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0)
@@ -1011,10 +1020,8 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
 		p.stamps = ws.stamps;
 	}
-	if (emit_iq) {
-		p.variant = RTLFM_ATAN_STD; p.mode = RTLFM_MODE_FM;  // no discriminator runs: any 6-pass instantiation will do
-		return launch_one<6, false>(p, waves, q);
-	}
+	if (emit_iq) p.variant = RTLFM_ATAN_FAST;  // the emit path lives in the run-time-discriminator kernels
+	if (emit_iq && c.downsample_passes > kMaxP) return launch_one<6, false>(p, waves, q);  // the rest is staged
 	const bool fir = c.comp_fir_size == 9;
 	switch (c.downsample_passes * 2 + (fir ? 1 : 0)) {
 	case 2: return launch_one<1, false>(p, waves, q);

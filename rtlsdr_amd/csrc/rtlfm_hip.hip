@@ -675,20 +675,24 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
 }
 
-// 7..10 fifth_order passes: the six-pass fused kernel emits the /64 IQ into a small work buffer
-// (same layout as the staged path's level-6 buffer: a stream's buffers back to back), and the
-// staged kernels run the remaining passes, the FIR and the demodulator on 1/64 of the data.
-static int run_fused_deep(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
+// The fused front end in emit mode + staged kernels for what it does not do itself: with up to
+// six passes it emits the decimated, FIR-compensated IQ (what full_demod() hands on after
+// src/rtl_fm.c:1202); with 7..10 passes the /64 IQ, and the staged kernels run the remaining
+// passes and the FIR on 1/64 of the data.  Then, as in full_demod(): squelch (:1204-1215),
+// mode_demod incl. -M raw (:1256-1259), audio tail.  The work buffer has the staged path's
+// layout for that level (a stream's buffers back to back).
+static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
                           size_t out_stride, int32_t *d_out_len)
 {
 	const rtlfm_cfg &c = h->cfg;
 	const int S = h->nstreams;
 	const int N0 = (int)(c.block_len / 2);
+	const int level = c.downsample_passes < fused::kMaxP ? c.downsample_passes : fused::kMaxP;
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[h->st_cur ^ 1];
 	if (!h->deepA) {
-		h->deep_stride = (size_t)h->cap_blocks * (N0 >> 6);
+		h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
 		HIP_TRY(hipMalloc(&h->deepA, (size_t)S * h->deep_stride * sizeof(uint32_t)));
 		HIP_TRY(hipMalloc(&h->deepB, (size_t)S * h->deep_stride * sizeof(uint32_t)));
 	}
@@ -706,7 +710,7 @@ static int run_fused_deep(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	r = timing_end(h, ev);
 	if (r < 0) return r;
 	uint32_t *cur = h->deepA, *oth = h->deepB;
-	for (int p = 6; p < c.downsample_passes; p++) {
+	for (int p = level; p < c.downsample_passes; p++) {
 		const int N = N0 >> p;
 		k_fifth<<<grid_for((size_t)S * nblocks * (N / 2)), 256, 0, q>>>(cur, oth, h->deep_stride, N, nblocks, S, p,
 		                                                              sin, sout);
@@ -714,9 +718,16 @@ static int run_fused_deep(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	}
 	const int Nblk = N0 >> c.downsample_passes;
 	const int T = nblocks * Nblk;
-	if (c.comp_fir_size == 9) {
+	if (c.downsample_passes > level && c.comp_fir_size == 9) {
 		k_fir9<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, oth, h->deep_stride, T, S, c.downsample_passes, sin, sout);
 		std::swap(cur, oth);
+	}
+	if (c.squelch_level) {
+		k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, Nblk, 1, nblocks, sin, c.squelch_level,
+		                                         c.dc_block_raw, h->d_mute);
+		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
+		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, Nblk, 1, nblocks, S, T, sin,
+		                                                     h->d_mute);
 	}
 	int16_t *dd; size_t dds;
 	tail_route(h, tp, d_out, out_stride, &dd, &dds);
@@ -726,6 +737,10 @@ static int run_fused_deep(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	else
 		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, c.mode,
 		                                                     c.output_scale, nullptr);
+	if (c.mode == RTLFM_MODE_RAW) {
+		if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T);
+		return 0;
+	}
 	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
 }
 
@@ -773,7 +788,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
-	const bool can_deep = fused::supported_deep(h->cfg);
+	const bool can_deep = fused::supported_emit(h->cfg);
 	int r;
 	if (h->path == 2 && !can_fuse && !can_box && !can_deep) return -ENOTSUP;
 	// state is double-buffered: kernels read st[cur], write st[cur^1].  The staged kernels each
@@ -785,7 +800,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 		r = run_boxfused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
 	} else if (h->path != 1 && can_deep) {
-		r = run_fused_deep(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+		r = run_fused_emit(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
 	} else if (h->path != 1 && can_fuse) {
 		r = run_fused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);

@@ -478,6 +478,37 @@ def test_fused_deep_passes(oracle_lib, passes, fir9, atan, mode, L, nb, ns):
         assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False)
 
 
+@pytest.mark.parametrize("ov", [
+    dict(mode=capi.MODE_RAW, downsample=16, downsample_passes=4),
+    dict(mode=capi.MODE_RAW, downsample=2, downsample_passes=1, comp_fir_size=9),
+    dict(mode=capi.MODE_RAW, downsample=64, downsample_passes=6, comp_fir_size=9, offset_tuning=1),
+    dict(mode=capi.MODE_RAW, downsample=256, downsample_passes=8, comp_fir_size=9),
+    dict(mode=capi.MODE_FM, downsample=16, downsample_passes=4, squelch_level=40, custom_atan=2),
+    dict(mode=capi.MODE_FM, downsample=32, downsample_passes=5, comp_fir_size=9, squelch_level=3000, deemph=1, deemph_a=2),
+    dict(mode=capi.MODE_AM, downsample=128, downsample_passes=7, squelch_level=200, output_scale=2),
+    dict(mode=capi.MODE_USB, downsample=8, downsample_passes=3, squelch_level=1),
+])
+def test_fused_emit_raw_and_squelch(oracle_lib, ov):
+    """-M raw and the power squelch behind the fused front end in emit mode (decimated,
+    FIR-compensated IQ handed to the staged squelch / demod kernels): against the oracle and the
+    all-staged path, incl. squelch_hits and streams that are muted (low amplitude) or not."""
+    L, nb, ns = 16384, 4, 6
+    cfg = make_cfg(dict(rate_out=24000, **ov), L, nb)
+    loud = synth.fm_iq_u8(ns // 2, L // 2 * nb, seed=4100, fs=1.024e6, dev_hz=5e3, amplitude=60.0)
+    quiet = synth.fm_iq_u8(ns - ns // 2, L // 2 * nb, seed=4101, fs=1.024e6, dev_hz=5e3, amplitude=1.5)
+    iq = np.concatenate([loud, quiet])
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    fo, fst, used = gpu_run(cfg, iq, path=2, splits=[(0, 2), (2, nb)])
+    assert used == 2
+    so, sst, used1 = gpu_run(cfg, iq, path=1)
+    assert used1 == 1
+    for s in range(ns):
+        assert len(fo[s]) == want_len[s]
+        assert np.array_equal(fo[s], so[s]), (ov, s)
+        assert_parity(fo[s], want[s, :want_len[s]], cfg, f"emit {ov}[{s}]")
+        assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False)
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
