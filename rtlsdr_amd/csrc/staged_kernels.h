@@ -638,18 +638,34 @@ k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restric
                int len1, int len2, int nblocks, int nstreams)
 {
 	const size_t total = (size_t)nstreams * nblocks * len2;
+	const bool small = (long long)len1 * len2 < (1ll << 31) && total < (1ull << 32);
 	RTLFM_GRID_STRIDE(g, total) {
-		int j = (int)(g % len2);
-		size_t sb = g / len2;
-		int b = (int)(sb % nblocks);
-		size_t s = sb / nblocks;
-		const int16_t *a = A + s * astride + (size_t)b * len1;
-		long long adv = (long long)j * len1;
-		int i, tick;
-		if (adv == 0) {
-			i = 1; tick = 0;
+		int j, b;
+		size_t s;
+		if (small) {
+			const uint32_t g32 = (uint32_t)g, sb = g32 / (uint32_t)len2;
+			j = (int)(g32 - sb * (uint32_t)len2);
+			s = sb / (uint32_t)nblocks;
+			b = (int)(sb - (uint32_t)s * (uint32_t)nblocks);
 		} else {
-			long long q = (adv - 1) / len2;
+			j = (int)(g % len2);
+			const size_t sb = g / len2;
+			b = (int)(sb % nblocks);
+			s = sb / nblocks;
+		}
+		const int16_t *a = A + s * astride + (size_t)b * len1;
+		int i, tick;
+		if (j == 0) {
+			i = 1; tick = 0;
+		} else if (small) {
+			// j * len1 < len1 * len2 < 2^31: one 32-bit division instead of a 64-bit one
+			const uint32_t adv = (uint32_t)j * (uint32_t)len1;
+			const uint32_t q = (adv - 1u) / (uint32_t)len2;
+			i = 1 + (int)q;
+			tick = (int)(adv - q * (uint32_t)len2);
+		} else {
+			const long long adv = (long long)j * len1;
+			const long long q = (adv - 1) / len2;
 			i = 1 + (int)q;
 			tick = (int)(adv - q * len2);
 		}
