@@ -475,11 +475,15 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	if (tp.deemph) {
 		DeemphStep st;
 		st.a = (uint32_t)c.deemph_a; st.half = (uint32_t)(c.deemph_a / 2);
-		const bool magic = c.deemph_a >= 2 && c.deemph_a <= 32768;
-		st.magic = magic ? (uint32_t)((0x100000000ull + st.a - 1) / st.a) : 0;
+		const bool pow2 = c.deemph_a >= 1 && c.deemph_a <= 32768 && (c.deemph_a & (c.deemph_a - 1)) == 0;
+		const bool magic = !pow2 && c.deemph_a >= 2 && c.deemph_a <= 32768;
+		st.magic = 0;
+		if (pow2) { while ((1u << st.magic) < st.a) st.magic++; }
+		else if (magic) st.magic = (uint32_t)((0x100000000ull + st.a - 1) / st.a);
 		const unsigned grid = (unsigned)((S + 63) / 64);
-		if (magic) k_deemph<true><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
-		else k_deemph<false><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		if (pow2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		else if (magic) k_deemph<1><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 	}
 	if (tp.adc) {
 		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, per_block, nblocks, h->d_sums);

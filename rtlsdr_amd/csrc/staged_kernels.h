@@ -449,19 +449,21 @@ k_post_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__rest
 //     keeps the hardware division for a == 1 and larger a;
 //   * add / subtract are both formed, the compare that picks one is off the chain.
 // Samples move in 16-byte groups, a 128-byte line at a time with the next line in flight.
+// MAGIC: 0 = hardware division, 1 = multiply-high, 2 = a is a power of two (a = 2 at 16 / 24 kHz,
+// 4 at 44.1 / 48 kHz): a shift, which takes the quarter-rate v_mul_hi_u32 out of the chain
 struct DeemphStep {
-	uint32_t a, half, magic;
-	template <bool MAGIC>
+	uint32_t a, half, magic;  // magic: M for MAGIC 1, log2(a) for MAGIC 2
+	template <int MAGIC>
 	__device__ __forceinline__ uint32_t step(uint32_t xb, uint32_t avgb) const
 	{
 		const uint32_t n = (xb > avgb ? xb - avgb : avgb - xb) + half;
-		const uint32_t q = MAGIC ? __umulhi(n, magic) : n / a;
+		const uint32_t q = MAGIC == 2 ? n >> magic : MAGIC == 1 ? __umulhi(n, magic) : n / a;
 		const uint32_t up = avgb + q, dn = avgb - q;
 		return xb > avgb ? up : dn;
 	}
 };
 
-template <bool MAGIC>
+template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
          DeemphStep ds, const state_t *__restrict__ sin, state_t *__restrict__ sout)

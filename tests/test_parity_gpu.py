@@ -258,7 +258,7 @@ def test_fused_extreme_patterns(oracle_lib, engine, offs):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
 
 
-@pytest.mark.parametrize("a", [1, 2, 3, 7, 13, 100, 1023, 32768, 40000])
+@pytest.mark.parametrize("a", [1, 2, 3, 4, 7, 13, 64, 100, 1023, 16384, 32768, 40000, 65536])
 def test_deemph_filter_every_divisor_form(oracle_lib, a):
     """deemph_filter (src/rtl_fm.c:1011-1026) with the multiply-high division (2 <= a <= 32768),
     the a == 1 and a > 32768 fall-backs, odd run lengths / unaligned rows, a carried state, and a
