@@ -50,6 +50,9 @@ struct rtlfm_gpu {
 	int16_t *d_result = nullptr;      // run()/fetch() result, rstride
 	int32_t *d_result_len = nullptr;  // [nstreams]
 	int32_t *d_cnt = nullptr, *d_cnt2 = nullptr;
+	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
+	uint32_t *d_deemph_inc = nullptr;
+	int deemph_chunks = 0;
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
 	size_t deep_stride = 0;
 	state_t *st[2] = {nullptr, nullptr};
@@ -280,7 +283,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	hipStreamSynchronize(h->stream);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->deepA, h->deepB, h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->deepA, h->deepB, h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
 	                h->st[0], h->st[1], h->d_lut, h->d_mute, h->d_sums, h->d_rdc_avg, h->d_adc_avg, h->d_in};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
@@ -481,7 +484,36 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		if (pow2) { while ((1u << st.magic) < st.a) st.magic++; }
 		else if (magic) st.magic = (uint32_t)((0x100000000ull + st.a - 1) / st.a);
 		const unsigned grid = (unsigned)((S + 63) / 64);
-		if (pow2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		// few, long streams: parallel over time (staged_kernels.h, k_deemph_scan_*); the interval
+		// of candidate states must fit a wave (2a + 2 <= kDeemphGap)
+		const bool scan = T >= 4 * kDeemphChunk && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap &&
+		                  !getenv("RTLFM_DEEMPH_SEQUENTIAL");
+		if (scan) {
+			const int mc = T / kDeemphChunk + 2;
+			if (mc > h->deemph_chunks) {
+				if (h->d_deemph_tab) { HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); }
+				h->d_deemph_tab = nullptr; h->d_deemph_inc = nullptr;
+				HIP_TRY(hipMalloc(&h->d_deemph_tab, (size_t)S * mc * sizeof(DeemphChunk)));
+				HIP_TRY(hipMalloc(&h->d_deemph_inc, (size_t)S * mc * sizeof(uint32_t)));
+				h->deemph_chunks = mc;
+			}
+			const int mcs = h->deemph_chunks;
+			int lpc = 8;  // lanes per chunk in pass A: the contracted interval (<= 2a + 2 states) must fit
+			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
+			const size_t per_wave = 64 / lpc;
+			const unsigned ga = (unsigned)(((size_t)S * mcs + per_wave - 1) / per_wave), gc = (unsigned)(((size_t)S * mcs + 63) / 64);
+#define RTLFM_DEEMPH_SCAN(M)                                                                                        \
+	do {                                                                                                            \
+		k_deemph_scan_a<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, lpc, h->d_deemph_tab);             \
+		k_deemph_scan_b<M><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, h->d_deemph_tab,                 \
+		                                       h->d_deemph_inc, sin, sout);                                         \
+		k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, h->d_deemph_inc, sout);            \
+	} while (0)
+			if (pow2) RTLFM_DEEMPH_SCAN(2);
+			else if (magic) RTLFM_DEEMPH_SCAN(1);
+			else RTLFM_DEEMPH_SCAN(0);
+#undef RTLFM_DEEMPH_SCAN
+		} else if (pow2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 		else if (magic) k_deemph<1><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 	}

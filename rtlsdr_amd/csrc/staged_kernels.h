@@ -463,39 +463,21 @@ struct DeemphStep {
 	}
 };
 
-template <int MAGIC>
-__global__ void __launch_bounds__(64)
-k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-         DeemphStep ds, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+// n samples at r from the biased state avgb; WRITE: store the filtered samples.  Samples move in
+// 128-byte lines (64 samples) with the next line's eight loads in flight while this one is
+// walked: every lane reads its own row, so each line is a separate trip to HBM and one line of
+// the chain (~3000 cycles) is about what that trip takes.
+template <int MAGIC, bool WRITE>
+__device__ __forceinline__ uint32_t deemph_walk(int16_t *r, int n, uint32_t avgb, const DeemphStep &ds)
 {
-	const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
-	if (s >= (size_t)nstreams) return;
-	const int n = cnt ? cnt[s] : T;
-	int16_t *r = R + s * rstride;
-	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {
-		// a state outside the int16 range can only come from rtlfm_gpu_state_set: plain form
-		int avg = sin[s].deemph_avg;
-		const int a = (int)ds.a, half = (int)ds.half;
-		for (int k = 0; k < n; k++) {
-			int d = r[k] - avg;
-			avg += d > 0 ? (d + half) / a : (d - half) / a;
-			r[k] = (int16_t)avg;
-		}
-		sout[s].deemph_avg = avg;
-		return;
-	}
-	uint32_t avgb = (uint32_t)(sin[s].deemph_avg + 32768);
 	auto one = [&](int k) {
 		avgb = ds.step<MAGIC>((uint32_t)(uint16_t)r[k] ^ 0x8000u, avgb);
-		r[k] = (int16_t)(uint16_t)(avgb ^ 0x8000u);
+		if (WRITE) r[k] = (int16_t)(uint16_t)(avgb ^ 0x8000u);
 	};
 	int k = 0;
 	// head: up to the first 16-byte boundary
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
 	for (; k < head && k < n; k++) one(k);
-	// body: 128-byte lines (64 samples), the next line's eight loads in flight while this one
-	// is walked: every lane reads its own row, so each line is a separate trip to HBM and one
-	// line of the chain (~3000 cycles) is about what that trip takes
 	auto group = [&](uint4 &g) {
 		uint32_t w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -520,7 +502,7 @@ k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restri
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
 				group(cur[j]);
-				reinterpret_cast<uint4 *>(r + k)[j] = cur[j];
+				if (WRITE) reinterpret_cast<uint4 *>(r + k)[j] = cur[j];
 			}
 #pragma unroll
 			for (int j = 0; j < 8; j++) cur[j] = nxt[j];
@@ -529,10 +511,176 @@ k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restri
 	for (; k + 8 <= n; k += 8) {
 		uint4 g = *reinterpret_cast<const uint4 *>(r + k);
 		group(g);
-		*reinterpret_cast<uint4 *>(r + k) = g;
+		if (WRITE) *reinterpret_cast<uint4 *>(r + k) = g;
 	}
 	for (; k < n; k++) one(k);
+	return avgb;
+}
+
+// the plain form, for a state outside the int16 range (it can only come from rtlfm_gpu_state_set)
+__device__ __forceinline__ int deemph_plain(int16_t *r, int n, int avg, int a)
+{
+	const int half = a / 2;
+	for (int k = 0; k < n; k++) {
+		int d = r[k] - avg;
+		avg += d > 0 ? (d + half) / a : (d - half) / a;
+		r[k] = (int16_t)avg;
+	}
+	return avg;
+}
+
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+         DeemphStep ds, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	int16_t *r = R + s * rstride;
+	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {
+		sout[s].deemph_avg = deemph_plain(r, n, sin[s].deemph_avg, (int)ds.a);
+		return;
+	}
+	const uint32_t avgb = deemph_walk<MAGIC, true>(r, n, (uint32_t)(sin[s].deemph_avg + 32768), ds);
 	sout[s].deemph_avg = (int)avgb - 32768;
+}
+
+// ---- the same filter for few, long streams: exact parallelisation over time ------------------
+// One lane per stream leaves the GPU idle when there are a thousand streams of 350 k samples
+// (-M wbfm at scale: 9 ms of a 12 ms step).  The step f_x(v) = v + rdiv(x - v, a) is monotone
+// and 1-Lipschitz in the state v, so a state interval maps onto the interval between the images
+// of its ends, and it contracts (gap -> gap - gap/a + 1): from the whole int16 range to at most
+// a few dozen within ~100 samples for the usual a.  Per chunk of kDeemphChunk samples:
+//   A (a group of lanes per chunk, all chunks at once): run the two extreme states until they
+//     are close enough for the group (after k samples), then one lane per candidate state to the
+//     end of the chunk: table[j] = outgoing state for the state lo + j after k samples;
+//   B (one lane per stream, short): thread the true state through: k samples of the chunk, one
+//     table lookup, next chunk; record every chunk's incoming state;
+//   C (one lane per chunk, all chunks at once): replay the chunk from its incoming state, writing.
+// Every step is the reference's integer step; chunks whose interval does not contract in time
+// (or a true state outside the tracked interval) are simply walked in B.
+constexpr int kDeemphChunk = 4096;
+constexpr int kDeemphGap = 62;
+struct DeemphChunk {
+	int32_t lo;   // biased lower end after k samples
+	int32_t k;    // samples consumed before the table applies; -1: not contracted
+	int32_t n;    // candidate states in the table
+	int16_t table[64];
+};
+// chunk c of a run of n samples whose first 16-byte boundary is `head` samples in: [begin, end)
+__device__ __forceinline__ void deemph_chunk_range(int c, int n, int head, int &begin, int &end)
+{
+	begin = c == 0 ? 0 : head + c * kDeemphChunk;
+	end = head + (c + 1) * kDeemphChunk;
+	if (end > n) end = n;
+	if (begin > n) begin = n;
+}
+__device__ __forceinline__ int deemph_chunks(int n, int head)
+{
+	const int m = n - head;
+	return m <= kDeemphChunk ? 1 : (m + kDeemphChunk - 1) / kDeemphChunk;
+}
+
+// lpc lanes per chunk (a power of two >= 2a + 3, so that the contracted interval fits), 64 / lpc
+// chunks per wave
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_scan_a(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                DeemphStep ds, int max_chunks, int lpc, DeemphChunk *__restrict__ tab)
+{
+	const int sub = threadIdx.x & (lpc - 1);
+	const size_t g = (size_t)blockIdx.x * (64 / lpc) + threadIdx.x / lpc;  // (stream, chunk) index
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	int16_t *r = R + s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	if (c >= deemph_chunks(n, head) - 1) return;  // the last chunk's outgoing state comes from pass C
+	int begin, end;
+	deemph_chunk_range(c, n, head, begin, end);
+	const uint32_t gap_max = (uint32_t)(lpc - 2);
+	// the two extreme states (every lane of the group computes them)
+	uint32_t lo = 0, hi = 65535;
+	int k = begin;
+	while (k + 8 <= end && hi - lo > gap_max) {
+		uint32_t x[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) x[j] = (uint32_t)(uint16_t)r[k + j] ^ 0x8000u;
+#pragma unroll
+		for (int j = 0; j < 8; j++) { lo = ds.step<MAGIC>(x[j], lo); hi = ds.step<MAGIC>(x[j], hi); }
+		k += 8;
+	}
+	DeemphChunk *t = tab + s * max_chunks + c;
+	if (hi - lo > gap_max) {
+		if (sub == 0) { t->lo = 0; t->k = -1; }
+		return;
+	}
+	// one lane per candidate state lo .. hi (lanes beyond the interval repeat hi)
+	uint32_t v = lo + (uint32_t)sub;
+	if (v > hi) v = hi;
+	v = deemph_walk<MAGIC, false>(r + k, end - k, v, ds);
+	t->table[sub] = (int16_t)(uint16_t)(v ^ 0x8000u);
+	if (sub == 0) { t->lo = (int32_t)lo; t->k = k - begin; t->n = (int32_t)(hi - lo + 1); }
+}
+
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                DeemphStep ds, int max_chunks, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
+                const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	int16_t *r = R + s * rstride;
+	uint32_t *inc = incoming + s * max_chunks;
+	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {
+		sout[s].deemph_avg = deemph_plain(r, n, sin[s].deemph_avg, (int)ds.a);
+		inc[0] = 0xffffffffu;  // pass C leaves this stream alone
+		return;
+	}
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	const int nc = deemph_chunks(n, head);
+	uint32_t v = (uint32_t)(sin[s].deemph_avg + 32768);
+	inc[0] = v;
+	for (int c = 0; c + 1 < nc; c++) {
+		int begin, end;
+		deemph_chunk_range(c, n, head, begin, end);
+		const DeemphChunk *t = tab + s * max_chunks + c;
+		const int k = t->k;
+		if (k < 0) {
+			v = deemph_walk<MAGIC, false>(r + begin, end - begin, v, ds);
+		} else {
+			v = deemph_walk<MAGIC, false>(r + begin, k, v, ds);
+			const uint32_t j = v - (uint32_t)t->lo;
+			if (j < (uint32_t)t->n) v = (uint32_t)(uint16_t)t->table[j] ^ 0x8000u;
+			else v = deemph_walk<MAGIC, false>(r + begin + k, end - begin - k, v, ds);  // outside the tracked interval
+		}
+		inc[c + 1] = v;
+	}
+}
+
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                DeemphStep ds, int max_chunks, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout)
+{
+	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
+	if (s >= (size_t)nstreams) return;
+	if (incoming[s * max_chunks] == 0xffffffffu) return;
+	const int n = cnt ? cnt[s] : T;
+	int16_t *r = R + s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	const int nc = deemph_chunks(n, head);
+	if (c >= nc) return;
+	int begin, end;
+	deemph_chunk_range(c, n, head, begin, end);
+	const uint32_t v = deemph_walk<MAGIC, true>(r + begin, end - begin, incoming[s * max_chunks + c], ds);
+	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
 
 // dc_block_audio_filter (src/rtl_fm.c:1028-1041).  Block sums in parallel ...

@@ -509,6 +509,44 @@ def test_fused_emit_raw_and_squelch(oracle_lib, ov):
         assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False)
 
 
+@pytest.mark.parametrize("a", [2, 3, 8, 13, 19, 30, 31])
+@pytest.mark.parametrize("front", [dict(downsample=8, downsample_passes=3), dict(downsample=6, downsample_passes=0)])
+def test_deemph_time_parallel(oracle_lib, a, front):
+    """deemph_filter on long runs (>= 16384 samples per stream per launch): the exact
+    time-parallel form (interval of candidate states per chunk + tables, staged_kernels.h) for
+    2 <= a <= 30, the sequential kernel beyond; loud, quiet (the interval does not collapse) and
+    full-scale streams, split launches, variable counts behind the boxcar, and a state outside the
+    int16 range injected with rtlfm_gpu_state_set."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, nb, ns = 262144, 3, 5
+    ov = dict(deemph=1, deemph_a=a, rate_out=128000, custom_atan=2, **front)
+    cfg = make_cfg(ov, L, nb)
+    iq = np.concatenate([
+        synth.fm_iq_u8(2, L // 2 * nb, seed=500 + a, fs=1.024e6, dev_hz=60e3, amplitude=90.0),
+        synth.fm_iq_u8(2, L // 2 * nb, seed=501 + a, fs=1.024e6, dev_hz=2e3, amplitude=1.2),
+        synth.random_u8(1, L * nb, seed=502 + a),
+    ])
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    outs, sts, _ = gpu_run(cfg, iq, path=0, splits=[(0, 2), (2, nb)])
+    for s in range(ns):
+        assert np.array_equal(outs[s], want[s, :want_len[s]]), (a, s)
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+    st0 = oracle_lib.new_states(ns)
+    for s in range(ns):
+        st0[s].deemph_avg = (-1) ** s * (40000 + 5000 * s) if s != 2 else 1234
+    st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=4)
+    c2 = RtlfmCfg.from_buffer_copy(bytes(cfg)); c2.max_blocks = nb
+    with GpuDemod(c2, ns, 0) as g:
+        for s in range(ns):
+            g.state_set(s, st_copy[s])
+        o, n = g.run_torch(torch.from_numpy(iq).cuda()); g.sync()
+        o = o.cpu().numpy(); n = n.cpu().numpy()
+        for s in range(ns):
+            assert np.array_equal(o[s, :n[s]], want[s, :want_len[s]]), ("injected", a, s)
+            assert g.state_get(s).deemph_avg == wst[s].deemph_avg
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of

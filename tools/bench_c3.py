@@ -26,16 +26,25 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tail", type=int, default=1, help="0: front end only (no deemph / resampler)")
+    ap.add_argument("--preset", choices=["c3", "wbfm"], default="c3",
+                    help="wbfm: rtl_fm -M wbfm (boxcar /6, -A fast, deemph, low_pass_real 170k -> 32k) on 1.02 MS/s streams")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = load()
-    kw = dict(downsample=64, downsample_passes=6, comp_fir_size=9, rate_out=16000, block_len=a.block_len,
-              max_blocks=a.blocks)
-    if a.tail:
-        kw.update(deemph=1, deemph_a=lib.rtlfm_deemph_a(16000, 75), rate_out2=22050, resampler=RESAMPLE_ARBITRARY)
+    if a.preset == "wbfm":
+        from rtlsdr_amd.capi import ATAN_FAST, RESAMPLE_LOW_PASS_REAL
+        kw = dict(downsample=6, downsample_passes=0, custom_atan=ATAN_FAST, rate_out=170000, block_len=a.block_len,
+                  max_blocks=a.blocks)
+        if a.tail:
+            kw.update(deemph=1, deemph_a=lib.rtlfm_deemph_a(170000, 75), rate_out2=32000, resampler=RESAMPLE_LOW_PASS_REAL)
+    else:
+        kw = dict(downsample=64, downsample_passes=6, comp_fir_size=9, rate_out=16000, block_len=a.block_len,
+                  max_blocks=a.blocks)
+        if a.tail:
+            kw.update(deemph=1, deemph_a=lib.rtlfm_deemph_a(16000, 75), rate_out2=22050, resampler=RESAMPLE_ARBITRARY)
     cfg = RtlfmCfg.default(**kw)
     S, NB, L = a.streams, a.blocks, a.block_len
-    iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=1.024e6, dev_hz=5e3, amplitude=60.0)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=1.024e6, dev_hz=5e3, amplitude=40.0 if a.preset == "wbfm" else 60.0)
     g = GpuDemod(cfg, S, 0)
     cap = g.result_cap(NB)
     out = torch.empty((S, cap), dtype=torch.int16, device=dev)
@@ -53,7 +62,7 @@ def main():
     g.sync(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     nbytes = S * NB * L
-    print(f"C3 tail={a.tail}: {S} streams x {NB} x {L} B: {dt * 1e3:.3f} ms/step, {nbytes / 2 / dt / 1e9:.1f} GS/s, "
+    print(f"{a.preset} tail={a.tail}: {S} streams x {NB} x {L} B: {dt * 1e3:.3f} ms/step, {nbytes / 2 / dt / 1e9:.1f} GS/s, "
           f"{nbytes / dt / 1e9:.0f} GB/s of input; out_len[0]={int(out_len[0])} path={g.last_path}")
 
 
