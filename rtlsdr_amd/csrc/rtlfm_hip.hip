@@ -486,28 +486,34 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		const unsigned grid = (unsigned)((S + 63) / 64);
 		// few, long streams: parallel over time (staged_kernels.h, k_deemph_scan_*); the interval
 		// of candidate states must fit a wave (2a + 2 <= kDeemphGap)
-		const bool scan = T >= 4 * kDeemphChunk && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap &&
+		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap &&
 		                  !getenv("RTLFM_DEEMPH_SEQUENTIAL");
 		if (scan) {
-			const int mc = T / kDeemphChunk + 2;
-			if (mc > h->deemph_chunks) {
+			// chunk length: about sixteen chunks per stream, 512 .. 4096 samples (each of the passes
+			// A1 and C is one chunk long in time; B grows with the number of chunks)
+			int L = ((T / 16 + 63) / 64) * 64;
+			if (L < 512) L = 512;
+			if (L > 4096) L = 4096;
+			const int mc = T / L + 2;
+			if ((size_t)mc > (size_t)h->deemph_chunks) {
 				if (h->d_deemph_tab) { HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); }
 				h->d_deemph_tab = nullptr; h->d_deemph_inc = nullptr;
 				HIP_TRY(hipMalloc(&h->d_deemph_tab, (size_t)S * mc * sizeof(DeemphChunk)));
 				HIP_TRY(hipMalloc(&h->d_deemph_inc, (size_t)S * mc * sizeof(uint32_t)));
 				h->deemph_chunks = mc;
 			}
-			const int mcs = h->deemph_chunks;
-			int lpc = 8;  // lanes per chunk in pass A: the contracted interval (<= 2a + 2 states) must fit
+			const int mcs = mc;
+			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
 			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
 			const size_t per_wave = 64 / lpc;
 			const unsigned ga = (unsigned)(((size_t)S * mcs + per_wave - 1) / per_wave), gc = (unsigned)(((size_t)S * mcs + 63) / 64);
 #define RTLFM_DEEMPH_SCAN(M)                                                                                        \
 	do {                                                                                                            \
-		k_deemph_scan_a<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, lpc, h->d_deemph_tab);             \
-		k_deemph_scan_b<M><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, h->d_deemph_tab,                 \
+		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
+		k_deemph_scan_a2<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
+		k_deemph_scan_b<M><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,              \
 		                                       h->d_deemph_inc, sin, sout);                                         \
-		k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, h->d_deemph_inc, sout);            \
+		k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);         \
 	} while (0)
 			if (pow2) RTLFM_DEEMPH_SCAN(2);
 			else if (magic) RTLFM_DEEMPH_SCAN(1);

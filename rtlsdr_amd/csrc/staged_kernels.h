@@ -551,43 +551,111 @@ k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restri
 // (-M wbfm at scale: 9 ms of a 12 ms step).  The step f_x(v) = v + rdiv(x - v, a) is monotone
 // and 1-Lipschitz in the state v, so a state interval maps onto the interval between the images
 // of its ends, and it contracts (gap -> gap - gap/a + 1): from the whole int16 range to at most
-// a few dozen within ~100 samples for the usual a.  Per chunk of kDeemphChunk samples:
-//   A (a group of lanes per chunk, all chunks at once): run the two extreme states until they
-//     are close enough for the group (after k samples), then one lane per candidate state to the
-//     end of the chunk: table[j] = outgoing state for the state lo + j after k samples;
+// a few dozen within ~100 samples for the usual a.  Per chunk of L samples (L a multiple of 64):
+//   A (all chunks at once): A1 runs the two extreme states through the chunk; if they merge the
+//     chunk is done, else A2 takes the interval as it was after k samples (small enough for a
+//     lane group) and walks one lane per candidate state to the end of the chunk: table[j] = outgoing state for the state lo + j after k samples;
 //   B (one lane per stream, short): thread the true state through: k samples of the chunk, one
 //     table lookup, next chunk; record every chunk's incoming state;
 //   C (one lane per chunk, all chunks at once): replay the chunk from its incoming state, writing.
 // Every step is the reference's integer step; chunks whose interval does not contract in time
 // (or a true state outside the tracked interval) are simply walked in B.
-constexpr int kDeemphChunk = 4096;
-constexpr int kDeemphGap = 62;
+constexpr int kDeemphGap = 62;  // candidates per chunk must fit a wave
 struct DeemphChunk {
 	int32_t lo;   // biased lower end after k samples
 	int32_t k;    // samples consumed before the table applies; -1: not contracted
-	int32_t n;    // candidate states in the table
+	int32_t n;    // candidate states in the table; -1: merged, table[0] whatever comes in
 	int16_t table[64];
 };
 // chunk c of a run of n samples whose first 16-byte boundary is `head` samples in: [begin, end)
-__device__ __forceinline__ void deemph_chunk_range(int c, int n, int head, int &begin, int &end)
+__device__ __forceinline__ void deemph_chunk_range(int c, int n, int head, int L, int &begin, int &end)
 {
-	begin = c == 0 ? 0 : head + c * kDeemphChunk;
-	end = head + (c + 1) * kDeemphChunk;
+	begin = c == 0 ? 0 : head + c * L;
+	end = head + (c + 1) * L;
 	if (end > n) end = n;
 	if (begin > n) begin = n;
 }
-__device__ __forceinline__ int deemph_chunks(int n, int head)
+__device__ __forceinline__ int deemph_chunks(int n, int head, int L)
 {
 	const int m = n - head;
-	return m <= kDeemphChunk ? 1 : (m + kDeemphChunk - 1) / kDeemphChunk;
+	return m <= L ? 1 : (m + L - 1) / L;
 }
 
-// lpc lanes per chunk (a power of two >= 2a + 3, so that the contracted interval fits), 64 / lpc
-// chunks per wave
+// A1: one lane per chunk walks the two extreme states through the whole chunk.  It records where
+// the interval first fits a lane group of pass A2 (k, lo_k, hi_k) and whether the two states have
+// merged by the end of the chunk - then the outgoing state does not depend on the incoming one
+// (n = -1, table[0]) and A2 has nothing to do.  Anything but a silent stream merges.
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
-k_deemph_scan_a(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                DeemphStep ds, int max_chunks, int lpc, DeemphChunk *__restrict__ tab)
+k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab)
+{
+	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	int16_t *r = R + s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	if (c >= deemph_chunks(n, head, L) - 1) return;  // the last chunk's outgoing state comes from pass C
+	int begin, end;
+	deemph_chunk_range(c, n, head, L, begin, end);
+	const uint32_t gap_max = (uint32_t)(lpc - 2);
+	uint32_t lo = 0, hi = 65535, lo_k = 0, hi_k = 0;
+	int kfit = -1;
+	auto one = [&](int k) {
+		const uint32_t x = (uint32_t)(uint16_t)r[k] ^ 0x8000u;
+		lo = ds.step<MAGIC>(x, lo); hi = ds.step<MAGIC>(x, hi);
+	};
+	auto note = [&](int k) {  // k: samples consumed so far (relative to begin), a multiple of 8 from the aligned part on
+		if (kfit < 0 && hi - lo <= gap_max) { kfit = k; lo_k = lo; hi_k = hi; }
+	};
+	int k = begin;
+	// chunk 0 may start before the first 16-byte boundary
+	const int pre = (int)(((16 - ((uintptr_t)(r + k) & 15)) & 15) >> 1);
+	for (int j = 0; j < pre && k < end; j++, k++) one(k);
+	if (k + 64 <= end) {
+		uint4 cur[8], nxt[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
+		for (; k + 64 <= end; k += 64) {
+			const uint4 *np = reinterpret_cast<const uint4 *>(r + (k + 128 <= end ? k + 64 : k));
+#pragma unroll
+			for (int j = 0; j < 8; j++) nxt[j] = np[j];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				note(k + 8 * j - begin);
+				const uint32_t w[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const uint32_t b2 = w[i] ^ 0x80008000u;
+					lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
+					lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+		}
+	}
+	for (; k < end; k++) {
+		if (((k - begin - pre) & 7) == 0) note(k - begin);
+		one(k);
+	}
+	DeemphChunk *t = tab + s * max_chunks + c;
+	if (lo == hi) {
+		t->lo = 0; t->k = 0; t->n = -1;
+		t->table[0] = (int16_t)(uint16_t)(lo ^ 0x8000u);
+	} else {
+		t->lo = (int32_t)lo_k; t->k = kfit; t->n = kfit < 0 ? 0 : (int32_t)(hi_k - lo_k + 1);
+	}
+}
+
+// A2: for the chunks A1 left unmerged, lpc lanes per chunk (a power of two >= 2a + 3), one lane per
+// candidate state lo_k .. hi_k from sample k to the end of the chunk -> table
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_scan_a2(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab)
 {
 	const int sub = threadIdx.x & (lpc - 1);
 	const size_t g = (size_t)blockIdx.x * (64 / lpc) + threadIdx.x / lpc;  // (stream, chunk) index
@@ -597,38 +665,21 @@ k_deemph_scan_a(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
-	if (c >= deemph_chunks(n, head) - 1) return;  // the last chunk's outgoing state comes from pass C
-	int begin, end;
-	deemph_chunk_range(c, n, head, begin, end);
-	const uint32_t gap_max = (uint32_t)(lpc - 2);
-	// the two extreme states (every lane of the group computes them)
-	uint32_t lo = 0, hi = 65535;
-	int k = begin;
-	while (k + 8 <= end && hi - lo > gap_max) {
-		uint32_t x[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++) x[j] = (uint32_t)(uint16_t)r[k + j] ^ 0x8000u;
-#pragma unroll
-		for (int j = 0; j < 8; j++) { lo = ds.step<MAGIC>(x[j], lo); hi = ds.step<MAGIC>(x[j], hi); }
-		k += 8;
-	}
+	if (c >= deemph_chunks(n, head, L) - 1) return;
 	DeemphChunk *t = tab + s * max_chunks + c;
-	if (hi - lo > gap_max) {
-		if (sub == 0) { t->lo = 0; t->k = -1; }
-		return;
-	}
-	// one lane per candidate state lo .. hi (lanes beyond the interval repeat hi)
-	uint32_t v = lo + (uint32_t)sub;
-	if (v > hi) v = hi;
-	v = deemph_walk<MAGIC, false>(r + k, end - k, v, ds);
-	t->table[sub] = (int16_t)(uint16_t)(v ^ 0x8000u);
-	if (sub == 0) { t->lo = (int32_t)lo; t->k = k - begin; t->n = (int32_t)(hi - lo + 1); }
+	const int k = t->k, nc = t->n;
+	if (k < 0 || nc <= 0) return;  // not contracted (pass B walks it) or merged
+	int begin, end;
+	deemph_chunk_range(c, n, head, L, begin, end);
+	uint32_t v = (uint32_t)t->lo + (uint32_t)(sub < nc ? sub : nc - 1);
+	v = deemph_walk<MAGIC, false>(r + begin + k, end - begin - k, v, ds);
+	if (sub < nc) t->table[sub] = (int16_t)(uint16_t)(v ^ 0x8000u);
 }
 
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                DeemphStep ds, int max_chunks, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
+                DeemphStep ds, int max_chunks, int L, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
                 const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
 	const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -642,15 +693,17 @@ k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 		return;
 	}
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
-	const int nc = deemph_chunks(n, head);
+	const int nc = deemph_chunks(n, head, L);
 	uint32_t v = (uint32_t)(sin[s].deemph_avg + 32768);
 	inc[0] = v;
 	for (int c = 0; c + 1 < nc; c++) {
 		int begin, end;
-		deemph_chunk_range(c, n, head, begin, end);
+		deemph_chunk_range(c, n, head, L, begin, end);
 		const DeemphChunk *t = tab + s * max_chunks + c;
 		const int k = t->k;
-		if (k < 0) {
+		if (t->n == -1) {
+			v = (uint32_t)(uint16_t)t->table[0] ^ 0x8000u;  // merged: whatever came in
+		} else if (k < 0) {
 			v = deemph_walk<MAGIC, false>(r + begin, end - begin, v, ds);
 		} else {
 			v = deemph_walk<MAGIC, false>(r + begin, k, v, ds);
@@ -665,7 +718,7 @@ k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                DeemphStep ds, int max_chunks, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout)
+                DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
@@ -675,10 +728,10 @@ k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
-	const int nc = deemph_chunks(n, head);
+	const int nc = deemph_chunks(n, head, L);
 	if (c >= nc) return;
 	int begin, end;
-	deemph_chunk_range(c, n, head, begin, end);
+	deemph_chunk_range(c, n, head, L, begin, end);
 	const uint32_t v = deemph_walk<MAGIC, true>(r + begin, end - begin, incoming[s * max_chunks + c], ds);
 	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
