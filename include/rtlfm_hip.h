@@ -214,6 +214,8 @@ int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches);
  * NULL.  Used by the parity tests to pin one against the other.
  */
 int rtlfm_gpu_selftest_atan2(int device, const int32_t *yx, int n, int32_t *q14, int32_t *q14_libm);
+/* The kernels' fast_atan2 (src/rtl_fm.c:851-872, incl. its 32-bit wrap-around) on n host pairs. */
+int rtlfm_gpu_selftest_fast_atan2(int device, const int32_t *yx, int n, int32_t *q14);
 
 /*
  * rotate_90 on raw u8 IQ (src/rtl_fm.c:437-447, NEG_U8(x) = 255 - x, :375-392): sample n

@@ -235,6 +235,8 @@ static int fast_atan2_restated(int32_t y, int32_t x)
 	return y < 0 ? -angle : angle;
 }
 
+int orc_fast_atan2(int y, int x) { return fast_atan2_restated(y, x); }
+
 int orc_polar_disc_fast(int ar, int aj, int br, int bj)
 {
 	/* src/rtl_fm.c:874-879 */

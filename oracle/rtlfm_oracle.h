@@ -49,6 +49,7 @@ const int *orc_cic9_row(int passes);
 /* src/rtl_fm.c:842-849, 851-879, 881-930 */
 int orc_polar_discriminant(int ar, int aj, int br, int bj);
 int orc_polar_disc_fast(int ar, int aj, int br, int bj);
+int orc_fast_atan2(int y, int x); /* fast_atan2 alone (src/rtl_fm.c:851-872) */
 int orc_polar_disc_lut(int ar, int aj, int br, int bj);
 const int32_t *orc_atan_lut(void); /* 131072 entries, built on first use */
 /* src/rtl_fm.c:932-959; returns result_len */

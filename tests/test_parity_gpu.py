@@ -547,6 +547,46 @@ def test_deemph_time_parallel(oracle_lib, a, front):
             assert g.state_get(s).deemph_avg == wst[s].deemph_avg
 
 
+def test_fast_atan2_against_oracle(oracle_lib):
+    """The kernels' fast_atan2 against the oracle's restatement of src/rtl_fm.c:851-872 on 4e6
+    pairs: realistic conjugate products, the 2^19 wrap boundary, near-equal |x| and |y| (quotient
+    near 0), x == +-|y| (quotient exactly +-4096 / 0), huge denominators, zeros and signs."""
+    lib = capi.load()
+    orc = oracle_lib.oracle()
+    orc.orc_fast_atan2.argtypes = [C.c_int, C.c_int]
+    orc.orc_fast_atan2.restype = C.c_int
+    rng = np.random.default_rng(4242)
+    parts = []
+    for scale in (8, 300, 5000, 1 << 17, 1 << 19, 1 << 20, 1 << 24, 1 << 29):
+        parts.append(rng.integers(-scale, scale + 1, size=(400000, 2)))
+    base = rng.integers(-(1 << 21), 1 << 21, size=(300000, 1))
+    parts.append(np.concatenate([base + rng.integers(-3, 4, size=base.shape), base], axis=1))    # |y| ~ |x|
+    parts.append(np.concatenate([base, -base + rng.integers(-2, 3, size=base.shape)], axis=1))
+    parts.append(np.array([[0, 0], [0, 5], [5, 0], [0, -5], [-5, 0], [7, 7], [7, -7], [-7, 7], [-7, -7],
+                           [1 << 19, 1], [1, 1 << 19], [(1 << 19) + 1, 0], [0, (1 << 19) + 1],
+                           [524287, 524288], [-524288, 524287], [(1 << 30) - 1, (1 << 30) - 2]]))
+    yx = np.ascontiguousarray(np.concatenate(parts).astype(np.int32))
+    # the reference divides INT_MIN by -1 nowhere reachable from int16 products; keep clear of it
+    n = len(yx)
+    got = np.empty(n, np.int32)
+    assert lib.rtlfm_gpu_selftest_fast_atan2(0, yx.ctypes.data, n, got.ctypes.data) == 0
+    want = np.fromiter((orc.orc_fast_atan2(int(y), int(x)) for y, x in yx[:200000]), np.int32, 200000)
+    assert np.array_equal(got[:200000], want)
+    # the rest vectorised: the same formula in int64 where nothing wraps, the oracle elsewhere
+    y = yx[:, 0].astype(np.int64); x = yx[:, 1].astype(np.int64)
+    ay = np.abs(y)
+    nowrap = (np.abs(x - ay) < (1 << 19)) & (np.abs(x + ay) < (1 << 19)) & ((x != 0) | (y != 0))
+    num = np.where(x >= 0, x - ay, x + ay); den = np.where(x >= 0, x + ay, ay - x)
+    den_safe = np.where(den == 0, 1, den)
+    q = np.sign(4096 * num) * (np.abs(4096 * num) // den_safe)
+    ang = np.where(x >= 0, 4096, 12288) - np.where(den == 0, 0, q)
+    ref = np.where(y < 0, -ang, ang)
+    assert np.array_equal(got[nowrap], ref[nowrap].astype(np.int32))
+    idx = np.flatnonzero(~nowrap)[:150000]
+    want2 = np.fromiter((orc.orc_fast_atan2(int(yx[i, 0]), int(yx[i, 1])) for i in idx), np.int32, len(idx))
+    assert np.array_equal(got[idx], want2)
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
