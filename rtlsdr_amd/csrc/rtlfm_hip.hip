@@ -489,11 +489,9 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap &&
 		                  !getenv("RTLFM_DEEMPH_SEQUENTIAL");
 		if (scan) {
-			// chunk length: about sixteen chunks per stream, 512 .. 4096 samples (each of the passes
-			// A1 and C is one chunk long in time; B grows with the number of chunks)
-			int L = ((T / 16 + 63) / 64) * 64;
-			if (L < 512) L = 512;
-			if (L > 4096) L = 4096;
+			// chunk length: each of the passes A1 and C is one chunk long in time; a chunk must be
+			// long enough for the interval to contract (~100 samples) and, normally, to merge
+			const int L = T >= 8192 ? 1024 : 512;
 			const int mc = T / L + 2;
 			if ((size_t)mc > (size_t)h->deemph_chunks) {
 				if (h->d_deemph_tab) { HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); }
@@ -511,7 +509,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	do {                                                                                                            \
 		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
 		k_deemph_scan_a2<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
-		k_deemph_scan_b<M><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,              \
+		k_deemph_scan_b<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
 		                                       h->d_deemph_inc, sin, sout);                                         \
 		k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);         \
 	} while (0)

@@ -555,8 +555,8 @@ k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restri
 //   A (all chunks at once): A1 runs the two extreme states through the chunk; if they merge the
 //     chunk is done, else A2 takes the interval as it was after k samples (small enough for a
 //     lane group) and walks one lane per candidate state to the end of the chunk: table[j] = outgoing state for the state lo + j after k samples;
-//   B (one lane per stream, short): thread the true state through: k samples of the chunk, one
-//     table lookup, next chunk; record every chunk's incoming state;
+//   B (one lane per chunk): the chunk's incoming state: look back to the nearest merged chunk and
+//     thread the state forward through the unmerged ones (k samples + one table lookup each);
 //   C (one lane per chunk, all chunks at once): replay the chunk from its incoming state, writing.
 // Every step is the reference's integer step; chunks whose interval does not contract in time
 // (or a true state outside the tracked interval) are simply walked in B.
@@ -676,43 +676,53 @@ k_deemph_scan_a2(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
 	if (sub < nc) t->table[sub] = (int16_t)(uint16_t)(v ^ 0x8000u);
 }
 
+// B: the incoming state of every chunk, one lane per chunk.  A merged chunk fixes its successor's
+// incoming state by itself, so a lane looks back to the nearest merged chunk (or the start of the
+// run), usually its direct predecessor, and threads the state forward from there through the
+// unmerged chunks in between (their first k samples + table).  Lane (stream, 0) also handles a
+// stream whose carried state lies outside the int16 range (plain form, whole run).
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                 DeemphStep ds, int max_chunks, int L, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
                 const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
-	const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
 	if (s >= (size_t)nstreams) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	uint32_t *inc = incoming + s * max_chunks;
 	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {
-		sout[s].deemph_avg = deemph_plain(r, n, sin[s].deemph_avg, (int)ds.a);
-		inc[0] = 0xffffffffu;  // pass C leaves this stream alone
+		if (c == 0) {
+			sout[s].deemph_avg = deemph_plain(r, n, sin[s].deemph_avg, (int)ds.a);
+			inc[0] = 0xffffffffu;  // pass C leaves this stream alone
+		}
 		return;
 	}
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
 	const int nc = deemph_chunks(n, head, L);
-	uint32_t v = (uint32_t)(sin[s].deemph_avg + 32768);
-	inc[0] = v;
-	for (int c = 0; c + 1 < nc; c++) {
+	if (c >= nc) return;
+	const DeemphChunk *t0 = tab + s * max_chunks;
+	int j = c - 1;  // nearest chunk before c whose outgoing state is known without its incoming one
+	while (j >= 0 && t0[j].n != -1) j--;
+	uint32_t v = j < 0 ? (uint32_t)(sin[s].deemph_avg + 32768) : (uint32_t)(uint16_t)t0[j].table[0] ^ 0x8000u;
+	for (int i = j + 1; i < c; i++) {
 		int begin, end;
-		deemph_chunk_range(c, n, head, L, begin, end);
-		const DeemphChunk *t = tab + s * max_chunks + c;
+		deemph_chunk_range(i, n, head, L, begin, end);
+		const DeemphChunk *t = t0 + i;
 		const int k = t->k;
-		if (t->n == -1) {
-			v = (uint32_t)(uint16_t)t->table[0] ^ 0x8000u;  // merged: whatever came in
-		} else if (k < 0) {
+		if (k < 0) {
 			v = deemph_walk<MAGIC, false>(r + begin, end - begin, v, ds);
 		} else {
 			v = deemph_walk<MAGIC, false>(r + begin, k, v, ds);
-			const uint32_t j = v - (uint32_t)t->lo;
-			if (j < (uint32_t)t->n) v = (uint32_t)(uint16_t)t->table[j] ^ 0x8000u;
+			const uint32_t q = v - (uint32_t)t->lo;
+			if (q < (uint32_t)t->n) v = (uint32_t)(uint16_t)t->table[q] ^ 0x8000u;
 			else v = deemph_walk<MAGIC, false>(r + begin + k, end - begin - k, v, ds);  // outside the tracked interval
 		}
-		inc[c + 1] = v;
 	}
+	inc[c] = v;
 }
 
 template <int MAGIC>
