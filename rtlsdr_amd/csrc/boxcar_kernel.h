@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 		flush();  // the previous tile's PCM, before the reload is issued
 		load_tile(more ? gt + 1 : gt);  // unconditional (see fused_kernel.h)
 
-		// ---- 2./3. outputs e = lane, lane + 64, ...; e == Et is the unfinished window (carry)
+		// ---- 2. window sums, outputs e = lane, lane + 64, ...; e == Et is the unfinished window (carry)
 		const int rounds = (Et + 1 + 63) / 64;
 		for (int r = 0; r < rounds; r++) {
 			const int e = r * 64 + lane;
@@ -206,8 +206,15 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 			const uint32_t z = pack_iq((int16_t)ai, (int16_t)aq);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
 			if (active && e < Et) lds[O0 + 1 + e] = z;
 			if (active && e == Et) { lds[Lds::carry] = (uint32_t)ai; lds[Lds::carry + 1] = (uint32_t)aq; }
-			__builtin_amdgcn_wave_barrier();
+		}
+		__builtin_amdgcn_wave_barrier();
+		// ---- 3. discriminator, in a loop of its own: the rounds no longer wait for each other's
+		// LDS store -> load (that dependency, eleven times per tile at /6, was what the kernel cost)
+		for (int r = 0; r < rounds; r++) {
+			const int e = r * 64 + lane;
+			const bool active = e <= Et;
 			if (active && e < Et) {
+				const uint32_t z = lds[O0 + 1 + e];
 				const uint32_t b = lds[O0 + e];  // the previous output (entry 0: the last one of the previous tile)
 				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
 				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
@@ -220,8 +227,8 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
 				pcm[e] = (uint16_t)(int16_t)v;
 			}
-			__builtin_amdgcn_wave_barrier();
 		}
+		__builtin_amdgcn_wave_barrier();
 		// the last complete output becomes entry 0 for the next tile
 		if (lane == 0) lds[O0] = lds[O0 + Et];
 		__builtin_amdgcn_wave_barrier();
