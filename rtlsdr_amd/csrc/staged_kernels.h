@@ -804,6 +804,18 @@ k_adc_apply(int16_t *__restrict__ R, size_t rstride, int per_block, int nblocks,
 // emitted at input ceil(((m+1)*fast - p0)/slow) - 1 and is the sum since the
 // previous emission (plus the carried now_lpr for m == 0) divided by
 // fast/slow (truncating).  n_in[s] (or T) inputs; cnt_out[s] outputs.
+// floor(a / b) for 0 <= a < 2^52, 0 < b < 2^31: the operands are exact in fp64, the correctly
+// rounded quotient is at most one off after truncation, and the remainder says which way (a 64-bit
+// integer division expands to ~100 instructions here, this to ~25)
+__device__ __forceinline__ long long floor_div_pos(long long a, int b)
+{
+	long long q = (long long)((double)a / (double)b);
+	long long r = a - q * (long long)b;
+	if (r < 0) { q -= 1; r += b; }
+	else if (r >= b) { q += 1; r -= b; }
+	return q;
+}
+
 __global__ void __launch_bounds__(256)
 k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
                 int T, const int32_t *__restrict__ n_in, int nstreams, int fast, int slow,
@@ -812,17 +824,29 @@ k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restri
 	const int div = fast / slow;
 	const int maxout = (int)(((long long)fast - 1 + (long long)T * slow) / fast);
 	const size_t total = (size_t)nstreams * (maxout + 1);
+	const bool small = total < (1ull << 32);
 	RTLFM_GRID_STRIDE(g, total) {
-		int m = (int)(g % (maxout + 1));
-		size_t s = g / (maxout + 1);
+		int m;
+		size_t s;
+		if (small) {
+			const uint32_t s32 = (uint32_t)g / (uint32_t)(maxout + 1);
+			m = (int)((uint32_t)g - s32 * (uint32_t)(maxout + 1));
+			s = s32;
+		} else {
+			m = (int)(g % (maxout + 1));
+			s = g / (maxout + 1);
+		}
 		const int n = n_in ? n_in[s] : T;
 		const long long p0 = sin[s].prev_lpr_index;
-		const int E = (int)((p0 + (long long)n * slow) / fast);
+		// p0 < fast and n * slow < 2^31 * 2^20: everything below stays under 2^52 for any run the
+		// library accepts (p0 comes from the carried state: outside [0, fast) only if injected)
+		const bool fits = p0 >= 0 && p0 < fast;
+		const int E = fits ? (int)floor_div_pos(p0 + (long long)n * slow, fast) : (int)((p0 + (long long)n * slow) / fast);
 		const int16_t *a = A + s * astride;
 		// first input index NOT yet consumed by outputs 0..m-1
 		auto end_of = [&](int mm) -> long long {  // inputs consumed once output mm is out
 			long long need = ((long long)mm + 1) * fast - p0;
-			return (need + slow - 1) / slow;
+			return fits ? floor_div_pos(need + slow - 1, slow) : (need + slow - 1) / slow;
 		};
 		if (m < E) {
 			long long lo = m == 0 ? 0 : end_of(m - 1), hi = end_of(m);
