@@ -152,7 +152,13 @@ def main():
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI on a real node; RTLFM_BENCH_BACKEND=gloo only exists to exercise this
+        # control flow where several ranks have to share one GPU (RCCL refuses that)
+        backend = os.environ.get("RTLFM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -222,7 +228,7 @@ def main():
     g.timing_enable(False)
     path_used = g.last_path
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
