@@ -587,6 +587,51 @@ def test_fast_atan2_against_oracle(oracle_lib):
     assert np.array_equal(got[idx], want2)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_callback_path_random_configurations(oracle_lib, seed):
+    """push / run / fetch (the rtlsdr_read_async callback boundary) on random configurations:
+    one pushing thread per stream, a random number of queued buffers per run, results and the
+    carried state against the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    from rtlsdr_amd.demod import GpuDemod
+    rng = np.random.default_rng(12000 + seed)
+    ov = _random_cfg(rng)
+    L = int(rng.choice([8192, 16384, 32768, 4096]))
+    nb = int(rng.integers(3, 7))
+    ns = int(rng.choice([1, 3, 8]))
+    depth = int(rng.integers(1, 4))  # max_blocks: buffers that may be queued per run
+    cfg = make_cfg(ov, L, depth)
+    try:
+        GpuDemod(cfg, ns, 0).close()
+    except capi.RtlfmError as e:
+        pytest.skip(f"configuration rejected by rtlfm_gpu_create: {e}")
+    amp = 25.0 if ov["custom_atan"] == 1 and ov["mode"] == capi.MODE_FM else 55.0
+    if ov["custom_atan"] == 1 and ov["downsample_passes"] == 0:
+        amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=8000 + seed, fs=1.024e6, dev_hz=20e3, amplitude=amp)
+    want, want_len, wst = oracle_lib.run_batch(make_cfg(ov, L, nb), iq, nthreads=2)
+    got = [[] for _ in range(ns)]
+    with GpuDemod(cfg, ns, 0) as g, ThreadPoolExecutor(max_workers=ns) as pool:
+        b = 0
+        while b < nb:
+            k = min(int(rng.integers(1, depth + 1)), nb - b)
+
+            def feed(s, b=b, k=k):
+                for i in range(k):
+                    g.rtlsdr_callback(iq[s, (b + i) * L:(b + i + 1) * L], s)
+            list(pool.map(feed, range(ns)))
+            g.full_demod()
+            for s in range(ns):
+                got[s].append(g.fetch(s))
+            b += k
+        states = [g.state_get(s) for s in range(ns)]
+    for s in range(ns):
+        out = np.concatenate(got[s])
+        assert len(out) == want_len[s], (ov, s)
+        assert_parity(out, want[s, :want_len[s]], cfg, f"callback path {ov} [{s}]")
+        assert gu.state_dict(states[s], False) == gu.state_dict(wst[s], False)
+
+
 def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     """atan_lut[i] = (int)(atan(i/256.0)/3.14159*16384) (src/rtl_fm.c:881-892) equals
     atan2_q14(i, 256) for all 131072 entries: the fused kernel computes the entry instead of
