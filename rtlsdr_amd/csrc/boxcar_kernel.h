@@ -54,6 +54,7 @@ struct Params {
 	int D, q4096, r4096;  // 4096 = q4096 * D + r4096
 	int out_cap;          // 4096 / D + 2
 	int segs, blocks_per_seg;
+	const uint8_t *dummy_tile;  // what the reload reads after a segment's last tile (fused_kernel.h)
 };
 
 // LDS layout in dwords
@@ -127,12 +128,11 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
 	int16_t *out_base = p.out + (size_t)s * p.out_stride;
 	uint4 cur[8];
-	auto load_tile = [&](int tile) {
-		const uint8_t *tb = stream_base + (size_t)tile * kTileBytes;
+	auto load_from = [&](const uint8_t *tb) {
 #pragma unroll
 		for (int k = 0; k < 8; k++) cur[k] = fused::load_stream16(tb + k * 1024 + lane * 16);
 	};
-	load_tile(gt_begin);
+	load_from(stream_base + (size_t)gt_begin * kTileBytes);
 
 	int flush_n = 0, flush_kb = 0;  // PCM of the previous tile, waiting in LDS
 	auto flush = [&]() {
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 		}
 		__builtin_amdgcn_wave_barrier();
 		flush();  // the previous tile's PCM, before the reload is issued
-		load_tile(more ? gt + 1 : gt);  // unconditional (see fused_kernel.h)
+		load_from(more ? stream_base + (size_t)(gt + 1) * kTileBytes : p.dummy_tile);  // unconditional (see fused_kernel.h)
 
 		// ---- 2. window sums, outputs e = lane, lane + 64, ...; e == Et is the unfinished window (carry)
 		const int rounds = (Et + 1 + 63) / 64;
@@ -258,11 +258,13 @@ inline bool supported(const rtlfm_cfg &c)
 	return true;
 }
 
-inline int launch(const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride, int nblocks,
-                  int16_t *d_out, size_t out_stride, int32_t *d_cnt, const state_t *sin, state_t *sout,
+inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
+                  int nblocks, int16_t *d_out, size_t out_stride, int32_t *d_cnt, const state_t *sin, state_t *sout,
                   hipStream_t q)
 {
 	Params p{};
+	if (int r = fused::ensure_dummy_tile(ws)) return r;
+	p.dummy_tile = ws.dummy_tile;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
 	p.nblocks = nblocks; p.nstreams = nstreams;
 	p.out = d_out; p.out_stride = out_stride; p.cnt = d_cnt;

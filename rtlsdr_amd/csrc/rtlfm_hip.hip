@@ -804,7 +804,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
-	r = boxfused::launch(c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt, sin, sout, q);
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt, sin, sout, q);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
