@@ -50,7 +50,41 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=1, help="have the cpu_baseline leg compare a slice of the GPU output with the CPU path")
+    ap.add_argument("--scatter", action="store_true",
+                    help="N > 1: also time shard.scatter_streams (root GPU -> its owner GPUs) of one step's IQ over RCCL")
     return ap.parse_args()
+
+
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` outside torchrun: start one rank per GPU ourselves.
+
+    Runs before anything in this process has touched the GPU: the ranks are children of a
+    `python -m torch.distributed.run` subprocess (never a re-exec of a process that holds the
+    device).  torch.cuda.device_count() only counts, it does not initialise the runtime here.
+    The JSON line is printed by rank 0 of the child job; this process only relays its exit code.
+    """
+    import socket
+    import subprocess
+
+    import torch
+    have = torch.cuda.device_count()
+    n = a.gpus
+    shared = os.environ.get("RTLFM_BENCH_BACKEND", "nccl") != "nccl"  # gloo: ranks may share a device (control-flow tests)
+    if have < 1:
+        print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
+        return 2
+    if n > have and not shared:
+        print(f"bench.py: --gpus {n} asked, {have} visible: running {have} rank(s); n_gpus reports what joined",
+              file=sys.stderr)
+        n = have
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = list(sys.argv[1:])
+    env = dict(os.environ, RTLFM_BENCH_REQUESTED_GPUS=str(a.gpus), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
@@ -120,6 +154,40 @@ def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
     }
 
 
+def time_scatter(dist, rank, world, dev, streams_per_rank, bytes_per_stream, reps=3):
+    """The one optional exchange of the path: all IQ of a step lands on rank 0's
+    GPU and every rank receives its contiguous stream range (shard.scatter_streams: isend/recv
+    per peer, one xGMI link each under RCCL).  Bounded: at most 1 GiB per peer."""
+    import torch
+    from rtlsdr_amd import shard
+    per = min(streams_per_rank, max(1, (1 << 30) // bytes_per_stream))
+    total = per * world
+    gloo = dist.get_backend() != "nccl"
+    where = "cpu" if gloo else dev
+    root = torch.empty((total, bytes_per_stream), dtype=torch.uint8, device=where) if rank == 0 else None
+    if root is not None:
+        root.random_(0, 256)
+    ms = []
+    for i in range(reps + 1):
+        dist.barrier()
+        if not gloo:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mine = shard.scatter_streams(root, total, bytes_per_stream, device=where)
+        if not gloo:
+            torch.cuda.synchronize()
+        dist.barrier()
+        if i:
+            ms.append((time.perf_counter() - t0) * 1e3)
+        assert mine.shape[0] == per
+    t = torch.tensor([min(ms)], dtype=torch.float64, device=where)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sent = per * (world - 1) * bytes_per_stream
+    return {"ms": round(float(t.item()), 3), "bytes_from_root": sent,
+            "GB/s_from_root": round(sent / (float(t.item()) * 1e-3) / 1e9, 1),
+            "what": f"root -> {world - 1} peers, {per} streams x {bytes_per_stream} B each, {dist.get_backend()}"}
+
+
 def measured_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     passes (profiles/pmc_latest.json: FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -136,6 +204,8 @@ def measured_traffic(workload_key):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     import numpy as np
     import torch
 
@@ -227,10 +297,19 @@ def main():
     front_ms, launches = g.timing_read()
     g.timing_enable(False)
     path_used = g.last_path
+    n_devices, scatter = 1, None
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # n_gpus = the devices that actually joined (ranks sharing a device count once)
+        seen = torch.zeros(max(1, torch.cuda.device_count()), dtype=torch.int32, device=cdev)
+        seen[local_rank] = 1
+        dist.all_reduce(seen, op=dist.ReduceOp.MAX)
+        n_devices = int(seen.sum().item())
+        if a.scatter:
+            scatter = time_scatter(dist, rank, world, dev, S, NB * L)
 
     if rank == 0:
         samples_per_step = world * S * nsamp
@@ -242,7 +321,7 @@ def main():
             "metric": "IQ Msamples/s demodulated (whole node)",
             "value": round(value, 1),
             "unit": "Msamples/s",
-            "n_gpus": world,
+            "n_gpus": n_devices,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -258,7 +337,9 @@ def main():
                             + " + polar discriminant -> int16 PCM",
                 "streams_per_gpu": S, "buffers_per_step": NB, "block_len": L, "passes": a.passes,
                 "path": {1: "staged", 2: "fused"}.get(path_used, str(path_used)),
-                "parallelism": f"streams sharded {S}/GPU over {world} GPU(s), no data-path collective",
+                "parallelism": f"streams sharded {S}/GPU over {n_devices} GPU(s), {world} rank(s), no data-path collective",
+                "ranks": world,
+                "requested_gpus": int(os.environ.get("RTLFM_BENCH_REQUESTED_GPUS", a.gpus)),
                 "prewarm_steps": prewarm,
             },
             "roofline": {
@@ -280,6 +361,8 @@ def main():
             res["cpu_baseline"]["parity_checked"] = gate is not None
         else:
             res["cpu_baseline"] = None
+        if scatter:
+            res["scatter"] = scatter
         print(json.dumps(res))
     g.close()
     if dist:
