@@ -188,6 +188,17 @@ int rtlfm_gpu_reset(rtlfm_gpu *h);
 int rtlfm_gpu_sync(rtlfm_gpu *h);
 /* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
 int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *hip_stream);
+/*
+ * Ordering against another HIP stream without a host synchronisation.  The library launches on
+ * its own non-blocking stream, which is NOT ordered with the caller's streams by itself:
+ *   rtlfm_gpu_wait_for(h, p)    work launched on the handle from now on starts after everything
+ *                               already enqueued on p (the producer of d_iq, the allocator of d_out);
+ *   rtlfm_gpu_release_to(h, c)  work enqueued on c from now on starts after everything the handle
+ *                               has launched so far (the consumer of d_out / d_out_len).
+ * NULL names the legacy default stream.  A caller that uses neither must rtlfm_gpu_sync().
+ */
+int rtlfm_gpu_wait_for(rtlfm_gpu *h, void *producer_stream);
+int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
 
 /* 0 = automatic, 1 = staged reference kernels, 2 = fused streaming kernel
  * (fails with -ENOTSUP at run time when the configuration has no fused

@@ -110,6 +110,9 @@ int rtlpower_gpu_fetch(rtlpower_gpu *h, int stream, int64_t *avg, int32_t *sampl
 int rtlpower_gpu_clear(rtlpower_gpu *h);
 int rtlpower_gpu_sync(rtlpower_gpu *h);
 int rtlpower_gpu_set_stream(rtlpower_gpu *h, void *hip_stream);
+/* Cross-stream ordering as rtlfm_gpu_wait_for / rtlfm_gpu_release_to (include/rtlfm_hip.h). */
+int rtlpower_gpu_wait_for(rtlpower_gpu *h, void *producer_stream);
+int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream);
 /* HIP-event timing of the FFT kernel, as rtlfm_gpu_timing_*. */
 int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on);
 int rtlpower_gpu_timing_read(rtlpower_gpu *h, double *ms, int *launches);

@@ -574,6 +574,9 @@ int orc_block(const rtlfm_cfg *cfg, rtlfm_stream_state *st, const uint8_t *iq,
 			orc_generic_fir(lowpassed + 1, lp_len - 1, passes, st->droop_q_hist);
 		}
 	} else {
+		/* a buffer shorter than the boxcar can leave lp_len == 0; fm_demod() then reads
+		 * lowpassed[-2] (src/rtl_fm.c:955-956): outside the reference's domain */
+		if (cfg->downsample > lp_len / 2) return -4;
 		lp_len = orc_low_pass(lowpassed, lp_len, cfg->downsample, &st->now_r,
 		                      &st->now_j, &st->prev_index);
 	}
@@ -604,8 +607,12 @@ int orc_block(const rtlfm_cfg *cfg, rtlfm_stream_state *st, const uint8_t *iq,
 		return n; /* src/rtl_fm.c:1257-1259 */
 	default: return -1;
 	}
-	if (cfg->post_downsample > 1)
+	if (cfg->post_downsample > 1) {
+		/* "no wrap around, length must be multiple of step" (src/rtl_fm.c:740): otherwise the
+		 * reference's last sum reads stale samples past result_len — outside its domain */
+		if (n % cfg->post_downsample) return -3;
 		n = orc_low_pass_simple(result, n, cfg->post_downsample);
+	}
 	if (cfg->deemph)
 		orc_deemph(result, n, cfg->deemph_a, &st->deemph_avg);
 	if (cfg->dc_block_audio)

@@ -173,6 +173,8 @@ _SIGNATURES = [
     ("rtlfm_gpu_reset", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_sync", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rtlfm_gpu_wait_for", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rtlfm_gpu_release_to", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rtlfm_gpu_set_path", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlfm_gpu_last_path", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
@@ -211,6 +213,8 @@ _POWER_SIGNATURES = [
     ("rtlpower_gpu_clear", C.c_int, [C.c_void_p]),
     ("rtlpower_gpu_sync", C.c_int, [C.c_void_p]),
     ("rtlpower_gpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rtlpower_gpu_wait_for", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rtlpower_gpu_release_to", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rtlpower_gpu_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlpower_gpu_timing_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int)]),
 ]

@@ -37,6 +37,7 @@ struct rtlfm_gpu {
 	int device = 0;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
+	hipEvent_t ev_wait = nullptr, ev_release = nullptr;  // rtlfm_gpu_wait_for / _release_to
 	int path = 0, last_path = 0;
 
 	// geometry
@@ -169,7 +170,10 @@ static int validate_cfg(const rtlfm_cfg *c)
 	if (c->downsample_passes < 0 || c->downsample_passes > RTLFM_MAX_PASSES) return -EINVAL;
 	// every fifth_order call must see a length that is a multiple of 4 elements
 	if (c->downsample_passes > 0 && c->block_len % (2u << c->downsample_passes)) return -EINVAL;
-	if (c->downsample_passes == 0 && (c->downsample < 1 || c->downsample > 256)) return -EINVAL;
+	if (c->downsample_passes == 0 && c->downsample < 1) return -EINVAL;
+	// a buffer shorter than the boxcar leaves low_pass() with lp_len == 0 and fm_demod() then reads
+	// lowpassed[-2] (src/rtl_fm.c:955-956): outside the reference's domain
+	if (c->downsample_passes == 0 && (uint32_t)c->downsample > c->block_len / 2) return -EDOM;
 	if (c->comp_fir_size != 0 && c->comp_fir_size != 9) return -EINVAL;
 	if (c->custom_atan < RTLFM_ATAN_STD || c->custom_atan > RTLFM_ATAN_LUT) return -EINVAL;
 	if (c->max_blocks < 1) return -EINVAL;
@@ -177,17 +181,18 @@ static int validate_cfg(const rtlfm_cfg *c)
 	if (c->deemph && c->deemph_a < 1) return -EINVAL;
 	if (c->mode != RTLFM_MODE_RAW) {
 		int per = dec_per_block(c);
-		bool need_uniform = c->post_downsample > 1 || c->dc_block_audio ||
-		                    (c->rate_out2 > 0 && c->resampler == RTLFM_RESAMPLE_ARBITRARY);
-		if (need_uniform && per < 0) return -ENOTSUP;
-		if (c->post_downsample > 1 && per % c->post_downsample) return -EINVAL;
+		// low_pass_simple: "length must be multiple of step" (src/rtl_fm.c:740); otherwise the
+		// reference sums stale samples past result_len.  Behind a boxcar that does not divide the
+		// buffer the per-buffer count alternates, so no step > 1 can divide it every time.
+		if (c->post_downsample > 1 && (per < 0 || per % c->post_downsample)) return -EDOM;
 		if (c->rate_out2 > 0) {
 			if (c->rate_out <= 0) return -EINVAL;
 			if (c->resampler == RTLFM_RESAMPLE_LOW_PASS_REAL) {
 				// the reference divides by zero here (src/rtl_fm.c:769)
 				if (c->rate_out / c->rate_out2 == 0) return -EDOM;
 			} else if (c->resampler == RTLFM_RESAMPLE_ARBITRARY) {
-				int n = per / c->post_downsample;
+				// per < 0: the per-buffer count is n or n + 1 (boxcar not dividing the buffer)
+				int n = per < 0 ? (int)(c->block_len / 2) / c->downsample : per / c->post_downsample;
 				long long len2 = (long long)n * c->rate_out2 / c->rate_out;
 				if (len2 < 1 || n < 2) return -EINVAL;
 			} else {
@@ -208,6 +213,8 @@ static void init_states_host(std::vector<state_t> &v)
 	}
 }
 
+static int create_body(rtlfm_gpu *h);
+
 extern "C" int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device, rtlfm_gpu **out)
 {
 	if (!cfg || !out || nstreams < 1) return -EINVAL;
@@ -224,6 +231,21 @@ extern "C" int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device, 
 	h->cfg = *cfg;
 	h->nstreams = nstreams;
 	h->device = device;
+	// every failure below releases what was allocated so far (a service retrying on -ENOMEM must
+	// not leak device memory); *out is written on success only
+	int r = create_body(h);
+	if (r < 0) {
+		rtlfm_gpu_destroy(h);
+		return r;
+	}
+	*out = h;
+	return 0;
+}
+
+static int create_body(rtlfm_gpu *h)
+{
+	const rtlfm_cfg *cfg = &h->cfg;
+	const int nstreams = h->nstreams;
 	h->cap_blocks = cfg->max_blocks;
 	const size_t L = cfg->block_len;
 	h->xstride = (size_t)h->cap_blocks * (L / 2) + 16;
@@ -253,7 +275,6 @@ extern "C" int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device, 
 		HIP_TRY(hipMemcpy(h->d_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
 	h->pushed.assign(S, 0);
-	*out = h;
 	return rtlfm_gpu_reset(h);
 }
 
@@ -280,7 +301,9 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 {
 	if (!h) return -EINVAL;
 	hipSetDevice(h->device);
-	hipStreamSynchronize(h->stream);
+	if (h->stream) hipStreamSynchronize(h->stream);
+	for (hipEvent_t e : {h->ev_wait, h->ev_release})
+		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->deepA, h->deepB, h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
@@ -338,6 +361,30 @@ extern "C" int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *s)
 	if (!h) return -EINVAL;
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	h->stream = s ? (hipStream_t)s : h->own_stream;
+	return 0;
+}
+
+// Cross-stream ordering without a host synchronisation.  NULL names the legacy default stream
+// (what torch's default stream is), which hipEventRecord / hipStreamWaitEvent accept as such.
+extern "C" int rtlfm_gpu_wait_for(rtlfm_gpu *h, void *producer_stream)
+{
+	if (!h) return -EINVAL;
+	if ((hipStream_t)producer_stream == h->stream) return 0;
+	HIP_TRY(hipSetDevice(h->device));
+	if (!h->ev_wait) HIP_TRY(hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(h->ev_wait, (hipStream_t)producer_stream));
+	HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_wait, 0));
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream)
+{
+	if (!h) return -EINVAL;
+	if ((hipStream_t)consumer_stream == h->stream) return 0;
+	HIP_TRY(hipSetDevice(h->device));
+	if (!h->ev_release) HIP_TRY(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(h->ev_release, h->stream));
+	HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_release, 0));
 	return 0;
 }
 
@@ -451,8 +498,11 @@ static void tail_route(rtlfm_gpu *h, const TailPlan &tp, int16_t *final_dst, siz
 	}
 }
 
+// Buffer extents: buffer b of a stream owns the decimated samples [dec_block_begin(b),
+// dec_block_begin(b + 1)) of the run — Nblk input samples per buffer through a boxcar D with the
+// carried prev_index; (Nblk, 1) describes a uniform count of Nblk per buffer.
 static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_stride, int T, bool varcnt,
-                    int nblocks, int16_t *final_dst, size_t final_stride, int32_t *d_out_len)
+                    int nblocks, int Nblk, int D, int16_t *final_dst, size_t final_stride, int32_t *d_out_len)
 {
 	const rtlfm_cfg &c = h->cfg;
 	const int S = h->nstreams;
@@ -460,7 +510,6 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[h->st_cur ^ 1];
 	int remaining_oop = tp.oop();
-	int per_block = T / nblocks;  // only used by stages that require a uniform count
 	int32_t *cnt = varcnt ? h->d_cnt : nullptr;
 	auto next_dst = [&](int16_t **d, size_t *ds) {
 		remaining_oop--;
@@ -468,12 +517,15 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		else { *d = (cur == h->resA) ? h->resB : h->resA; *ds = h->rstride; }
 	};
 	if (tp.post) {
+		// low_pass_simple: "length must be multiple of step" (src/rtl_fm.c:740) — validate_cfg only
+		// lets uniform per-buffer counts through
 		int16_t *d; size_t ds;
 		next_dst(&d, &ds);
 		int Tout = T / c.post_downsample;
 		k_post_downsample<<<grid_for((size_t)S * Tout), 256, 0, q>>>(cur, cur_stride, d, ds, Tout, S,
 		                                                           c.post_downsample);
-		cur = d; cur_stride = ds; T = Tout; per_block = T / nblocks;
+		cur = d; cur_stride = ds; T = Tout;
+		Nblk = T / nblocks; D = 1;
 	}
 	if (tp.deemph) {
 		DeemphStep st;
@@ -522,10 +574,10 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 	}
 	if (tp.adc) {
-		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, per_block, nblocks, h->d_sums);
-		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, per_block, nblocks, S, c.adc_block_const, sin,
+		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, sin, h->d_sums);
+		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, Nblk, D, nblocks, S, c.adc_block_const, sin,
 		                                           sout, h->d_adc_avg);
-		k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, per_block, nblocks, S,
+		k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, S, T, sin,
 		                                                  h->d_adc_avg);
 	}
 	if (tp.lpr) {
@@ -540,17 +592,24 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		return 0;
 	}
 	if (tp.arb) {
+		// arbitrary_resample per buffer on whatever result_len it has (src/rtl_fm.c:1168-1177, 1270)
 		int16_t *d; size_t ds;
 		next_dst(&d, &ds);
-		int len1 = per_block;
-		int len2 = (int)((long long)len1 * c.rate_out2 / c.rate_out);
-		if (len1 < len2)
-			k_arb_upsample<<<grid_for((size_t)S * nblocks * len2), 256, 0, q>>>(cur, cur_stride, d, ds, len1,
-			                                                                  len2, nblocks, S);
-		else
-			k_arb_downsample<<<grid_for((size_t)S * nblocks, 64), 64, 0, q>>>(cur, cur_stride, d, ds, len1,
-			                                                                len2, nblocks, S);
-		cur = d; cur_stride = ds; T = len2 * nblocks;
+		const int nlo = Nblk / D, nhi = (Nblk % D) ? nlo + 1 : nlo;
+		const int l2lo = (int)((long long)nlo * c.rate_out2 / c.rate_out);
+		const int l2hi = (int)((long long)nhi * c.rate_out2 / c.rate_out);
+		const bool any_up = nlo < l2lo || nhi < l2hi, any_down = !(nlo < l2lo) || !(nhi < l2hi);
+		if (any_up)
+			k_arb_upsample<<<grid_for((size_t)S * nblocks * l2hi), 256, 0, q>>>(
+			    cur, cur_stride, d, ds, Nblk, D, c.rate_out, c.rate_out2, l2hi, nblocks, S, sin, h->d_cnt2);
+		if (any_down)
+			k_arb_downsample<<<grid_for((size_t)S * nblocks, 64), 64, 0, q>>>(
+			    cur, cur_stride, d, ds, Nblk, D, c.rate_out, c.rate_out2, nblocks, S, sin, h->d_cnt2);
+		cur = d; cur_stride = ds;
+		if (cur != final_dst) return -EFAULT;  // routing bug
+		if (d_out_len)
+			HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt2, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+		return 0;
 	}
 	if (cur != final_dst) return -EFAULT;  // routing bug
 	if (d_out_len) {
@@ -656,7 +715,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 		}
 		return 0;
 	}
-	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, d_out, out_stride, d_out_len);
+	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, Nblk, D, d_out, out_stride, d_out_len);
 }
 
 static int fused_debug()
@@ -711,8 +770,8 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 		int r2 = report_clock_stamps(h);
 		if (r2 < 0) return r2;
 	}
-	const int T = nblocks * (int)((c.block_len / 2) >> c.downsample_passes);
-	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
+	const int Nblk = (int)((c.block_len / 2) >> c.downsample_passes);
+	return run_tail(h, tp, dd, dds, nblocks * Nblk, false, nblocks, Nblk, 1, d_out, out_stride, d_out_len);
 }
 
 // The fused front end in emit mode + staged kernels for what it does not do itself: with up to
@@ -781,7 +840,7 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 		if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T);
 		return 0;
 	}
-	return run_tail(h, tp, dd, dds, T, false, nblocks, d_out, out_stride, d_out_len);
+	return run_tail(h, tp, dd, dds, T, false, nblocks, Nblk, 1, d_out, out_stride, d_out_len);
 }
 
 // The boxcar (low_pass) front end in one launch; output counts may differ per buffer and
@@ -812,7 +871,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	const int Tin = nblocks * N0;
 	const bool varcnt = (N0 % D) != 0;
 	const int T = varcnt ? Tin / D + 1 : Tin / D;
-	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, d_out, out_stride, d_out_len);
+	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, N0, D, d_out, out_stride, d_out_len);
 }
 
 extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,

@@ -30,6 +30,7 @@ struct rtlpower_gpu {
 	rtlpower_cfg cfg;
 	int nstreams = 0, device = 0;
 	hipStream_t own_stream = nullptr, stream = nullptr;
+	hipEvent_t ev_wait = nullptr, ev_release = nullptr;
 	int N = 1, len_dec = 0, chunks = 0, dec_elems = 0;
 	bool decimates = false;
 	int32_t *d_window = nullptr;
@@ -214,6 +215,8 @@ static int validate(const rtlpower_cfg *c)
 	return 0;
 }
 
+static int power_create_body(rtlpower_gpu *h);
+
 extern "C" int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int device, rtlpower_gpu **out)
 {
 	if (!cfg || !out || nstreams < 1) return -EINVAL;
@@ -229,13 +232,27 @@ extern "C" int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int de
 	h->cfg = *cfg;
 	h->nstreams = nstreams;
 	h->device = device;
+	// every failure releases what was allocated so far; *out is written on success only
+	int r = power_create_body(h);
+	if (r < 0) {
+		rtlpower_gpu_destroy(h);
+		return r;
+	}
+	*out = h;
+	return 0;
+}
+
+static int power_create_body(rtlpower_gpu *h)
+{
+	const rtlpower_cfg *cfg = &h->cfg;
+	const int nstreams = h->nstreams;
 	h->N = 1 << cfg->bin_e;
 	const int ds = cfg->downsample;
 	h->decimates = (cfg->boxcar && ds > 1) || (!cfg->boxcar && cfg->downsample_passes > 0);
 	h->len_dec = (int)cfg->buf_len / ds;  // what remove_dc() and the chunk loop are given (:692-696)
 	if (cfg->bin_e > 0) {
 		h->chunks = (h->len_dec + 2 * h->N - 1) / (2 * h->N);
-		if ((long long)h->chunks * h->N > kMaxPoints) { delete h; return -ENOTSUP; }
+		if ((long long)h->chunks * h->N > kMaxPoints) return -ENOTSUP;
 		if (cfg->boxcar && ds > 1) h->dec_elems = 2 * (((int)cfg->buf_len / 2 + ds - 1) / ds);
 		else if (h->decimates) h->dec_elems = (int)cfg->buf_len >> cfg->downsample_passes;
 	}
@@ -268,7 +285,6 @@ extern "C" int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int de
 		HIP_TRY(hipMalloc(&h->d_tw, tw.size() * sizeof(uint32_t)));
 		HIP_TRY(hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
-	*out = h;
 	return rtlpower_gpu_clear(h);
 }
 
@@ -276,7 +292,9 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 {
 	if (!h) return -EINVAL;
 	(void)hipSetDevice(h->device);
-	(void)hipStreamSynchronize(h->stream);
+	if (h->stream) (void)hipStreamSynchronize(h->stream);
+	for (hipEvent_t e : {h->ev_wait, h->ev_release})
+		if (e) (void)hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	void *ptrs[] = {h->d_window, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
@@ -309,6 +327,29 @@ extern "C" int rtlpower_gpu_set_stream(rtlpower_gpu *h, void *s)
 	if (!h) return -EINVAL;
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	h->stream = s ? (hipStream_t)s : h->own_stream;
+	return 0;
+}
+
+// cross-stream ordering without a host synchronisation, as rtlfm_gpu_wait_for / _release_to
+extern "C" int rtlpower_gpu_wait_for(rtlpower_gpu *h, void *producer_stream)
+{
+	if (!h) return -EINVAL;
+	if ((hipStream_t)producer_stream == h->stream) return 0;
+	HIP_TRY(hipSetDevice(h->device));
+	if (!h->ev_wait) HIP_TRY(hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(h->ev_wait, (hipStream_t)producer_stream));
+	HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_wait, 0));
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream)
+{
+	if (!h) return -EINVAL;
+	if ((hipStream_t)consumer_stream == h->stream) return 0;
+	HIP_TRY(hipSetDevice(h->device));
+	if (!h->ev_release) HIP_TRY(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(h->ev_release, h->stream));
+	HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_release, 0));
 	return 0;
 }
 
@@ -447,8 +488,9 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	view.d_decA = view.d_decB = nullptr; view.dec_cap_reads = 0;
 	view.ev_pending.clear(); view.ev_free.clear(); view.timing = false;
 	int r = rtlpower_gpu_scan_device(&view, h->d_one, h->cfg.buf_len, 1);
-	HIP_TRY(hipStreamSynchronize(h->stream));
-	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }
+	const hipError_t e = hipStreamSynchronize(h->stream);
+	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }  // also when the sync failed
+	if (e != hipSuccess) return -EIO;
 	return r;
 }
 

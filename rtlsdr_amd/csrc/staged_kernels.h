@@ -746,17 +746,22 @@ k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
 
-// dc_block_audio_filter (src/rtl_fm.c:1028-1041).  Block sums in parallel ...
+// dc_block_audio_filter (src/rtl_fm.c:1028-1041) works on whatever result_len a buffer has.
+// Buffer b of a stream owns the decimated samples [dec_block_begin(b), dec_block_begin(b+1)) of
+// the run (N input samples per buffer, boxcar D with prev_index carried in; D == 1 describes a
+// uniform count N per buffer).  Block sums in parallel ...
 __global__ void __launch_bounds__(256)
-k_adc_sums(const int16_t *__restrict__ R, size_t rstride, int per_block, int nblocks,
-           long long *__restrict__ sums)
+k_adc_sums(const int16_t *__restrict__ R, size_t rstride, int N, int D, int nblocks,
+           const state_t *__restrict__ sin, long long *__restrict__ sums)
 {
 	const int sb = blockIdx.x;
 	const int b = sb % nblocks;
 	const size_t s = sb / nblocks;
-	const int16_t *r = R + s * rstride + (size_t)b * per_block;
+	const int p0 = D > 1 ? sin[s].prev_index : 0;
+	const int t0 = dec_block_begin(b, N, D, p0), t1 = dec_block_begin(b + 1, N, D, p0);
+	const int16_t *r = R + s * rstride + t0;
 	long long acc = 0;
-	for (int k = threadIdx.x; k < per_block; k += blockDim.x) acc += r[k];
+	for (int k = threadIdx.x; k < t1 - t0; k += blockDim.x) acc += r[k];
 	__shared__ long long red[256];
 	red[threadIdx.x] = acc;
 	__syncthreads();
@@ -767,14 +772,16 @@ k_adc_sums(const int16_t *__restrict__ R, size_t rstride, int per_block, int nbl
 	if (threadIdx.x == 0) sums[sb] = red[0];
 }
 // ... the smoothing recurrence sequentially per stream ...
-__global__ void k_adc_smooth(const long long *__restrict__ sums, int per_block, int nblocks, int nstreams,
+__global__ void k_adc_smooth(const long long *__restrict__ sums, int N, int D, int nblocks, int nstreams,
                              int k, const state_t *__restrict__ sin, state_t *__restrict__ sout,
                              int32_t *__restrict__ avg)
 {
 	RTLFM_GRID_STRIDE(s, nstreams) {
 		int prev = sin[s].dc_avg;
+		const int p0 = D > 1 ? sin[s].prev_index : 0;
 		for (int b = 0; b < nblocks; b++) {
-			int m = (int)(sums[s * nblocks + b] / per_block);
+			const int len = dec_block_begin(b + 1, N, D, p0) - dec_block_begin(b, N, D, p0);
+			int m = (int)(sums[s * nblocks + b] / len);
 			m = (m + prev * k) / (k + 1);
 			avg[s * nblocks + b] = m;
 			prev = m;
@@ -782,19 +789,20 @@ __global__ void k_adc_smooth(const long long *__restrict__ sums, int per_block, 
 		sout[s].dc_avg = prev;
 	}
 }
-// ... and the subtraction.
+// ... and the subtraction (T = upper bound of the per-stream count).
 __global__ void __launch_bounds__(256)
-k_adc_apply(int16_t *__restrict__ R, size_t rstride, int per_block, int nblocks, int nstreams,
-            const int32_t *__restrict__ avg)
+k_adc_apply(int16_t *__restrict__ R, size_t rstride, int N, int D, int nblocks, int nstreams, int T,
+            const state_t *__restrict__ sin, const int32_t *__restrict__ avg)
 {
-	const size_t total = (size_t)nstreams * nblocks * per_block;
+	const size_t total = (size_t)nstreams * T;
 	RTLFM_GRID_STRIDE(g, total) {
-		size_t sb = g / per_block;
-		int k = (int)(g % per_block);
-		size_t s = sb / nblocks;
-		int b = (int)(sb % nblocks);
-		int16_t *r = R + s * rstride + (size_t)b * per_block + k;
-		*r = (int16_t)(*r - avg[sb]);
+		const int t = (int)(g % T);
+		const size_t s = g / T;
+		const int p0 = D > 1 ? sin[s].prev_index : 0;
+		const int b = dec_block_of(t, N, D, p0);
+		if (b >= nblocks) continue;
+		int16_t *r = R + s * rstride + t;
+		*r = (int16_t)(*r - avg[s * nblocks + b]);
 	}
 }
 
@@ -864,33 +872,59 @@ k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restri
 	}
 }
 
+// Extents of buffer b for the per-buffer resampler arbitrary_resample(result, result, len1,
+// len1 * rate_out2 / rate_out) (the commented-out call, src/rtl_fm.c:1270): len1 is whatever
+// result_len the buffer has.  Behind a boxcar that does not divide the buffer len1 takes the two
+// values nlo = N / D and nlo + 1, so the start of buffer b's output in the concatenated result is
+// b * len2(nlo) + (#long buffers before b) * (len2(nlo + 1) - len2(nlo)).
+struct ArbExtent { int in0, len1, out0, len2; };
+__device__ __forceinline__ ArbExtent arb_extent(int b, int N, int D, int p0, int rate_out, int rate_out2)
+{
+	ArbExtent e;
+	e.in0 = dec_block_begin(b, N, D, p0);
+	e.len1 = dec_block_begin(b + 1, N, D, p0) - e.in0;
+	const int nlo = N / D;
+	const int l2lo = (int)((long long)nlo * rate_out2 / rate_out);
+	const int l2hi = (int)((long long)(nlo + 1) * rate_out2 / rate_out);
+	const int nlong = e.in0 - b * nlo;
+	e.out0 = b * l2lo + nlong * (l2hi - l2lo);
+	e.len2 = e.len1 == nlo ? l2lo : l2hi;
+	return e;
+}
+
 // arbitrary_upsample (src/rtl_fm.c:1114-1135), stateless per block, closed
 // form per output j.  The reference advances (i, tick) after each output:
 // tick += len1; if (tick > len2) {tick -= len2; i++}; clamp at the end.  Before
 // the clamp engages, after j outputs the total advance is j*len1 = (i-1)*len2 +
 // tick with 0 < tick <= len2 (tick == 0 only for j == 0).  The clamp sets
-// (i = len1-1, tick = len2) and is sticky.
+// (i = len1-1, tick = len2) and is sticky.  len2max = the larger of the two per-buffer lengths.
 __global__ void __launch_bounds__(256)
 k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
-               int len1, int len2, int nblocks, int nstreams)
+               int N, int D, int rate_out, int rate_out2, int len2max, int nblocks, int nstreams,
+               const state_t *__restrict__ sin, int32_t *__restrict__ cnt_out)
 {
-	const size_t total = (size_t)nstreams * nblocks * len2;
-	const bool small = (long long)len1 * len2 < (1ll << 31) && total < (1ull << 32);
+	const size_t total = (size_t)nstreams * nblocks * len2max;
+	const bool small = (long long)(N / D + 1) * len2max < (1ll << 31) && total < (1ull << 32);
 	RTLFM_GRID_STRIDE(g, total) {
 		int j, b;
 		size_t s;
 		if (small) {
-			const uint32_t g32 = (uint32_t)g, sb = g32 / (uint32_t)len2;
-			j = (int)(g32 - sb * (uint32_t)len2);
+			const uint32_t g32 = (uint32_t)g, sb = g32 / (uint32_t)len2max;
+			j = (int)(g32 - sb * (uint32_t)len2max);
 			s = sb / (uint32_t)nblocks;
 			b = (int)(sb - (uint32_t)s * (uint32_t)nblocks);
 		} else {
-			j = (int)(g % len2);
-			const size_t sb = g / len2;
+			j = (int)(g % len2max);
+			const size_t sb = g / len2max;
 			b = (int)(sb % nblocks);
 			s = sb / nblocks;
 		}
-		const int16_t *a = A + s * astride + (size_t)b * len1;
+		const int p0 = D > 1 ? sin[s].prev_index : 0;
+		const ArbExtent e = arb_extent(b, N, D, p0, rate_out, rate_out2);
+		if (b == nblocks - 1 && j == 0 && cnt_out) cnt_out[s] = e.out0 + e.len2;
+		if (j >= e.len2 || !(e.len1 < e.len2)) continue;  // len1 >= len2: arbitrary_downsample's buffer
+		const int len1 = e.len1, len2 = e.len2;
+		const int16_t *a = A + s * astride + e.in0;
 		int i, tick;
 		if (j == 0) {
 			i = 1; tick = 0;
@@ -908,21 +942,27 @@ k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restric
 		}
 		if (i >= len1) { i = len1 - 1; tick = len2; }
 		double frac = (double)tick / (double)len2;
-		B[s * bstride + (size_t)b * len2 + j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
+		B[s * bstride + (size_t)e.out0 + j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
 	}
 }
 
 // arbitrary_downsample (src/rtl_fm.c:1137-1166): the double remainder makes it
 // order-dependent, so one lane walks one (stream, block) in order.
 __global__ void k_arb_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B,
-                                 size_t bstride, int len1, int len2, int nblocks, int nstreams)
+                                 size_t bstride, int N, int D, int rate_out, int rate_out2, int nblocks,
+                                 int nstreams, const state_t *__restrict__ sin, int32_t *__restrict__ cnt_out)
 {
 	const size_t total = (size_t)nstreams * nblocks;
 	RTLFM_GRID_STRIDE(g, total) {
 		int b = (int)(g % nblocks);
 		size_t s = g / nblocks;
-		const int16_t *b1 = A + s * astride + (size_t)b * len1;
-		int16_t *b2 = B + s * bstride + (size_t)b * len2;
+		const int p0 = D > 1 ? sin[s].prev_index : 0;
+		const ArbExtent e = arb_extent(b, N, D, p0, rate_out, rate_out2);
+		if (b == nblocks - 1 && cnt_out) cnt_out[s] = e.out0 + e.len2;
+		if (e.len1 < e.len2) continue;  // arbitrary_upsample's buffer
+		const int len1 = e.len1, len2 = e.len2;
+		const int16_t *b1 = A + s * astride + e.in0;
+		int16_t *b2 = B + s * bstride + e.out0;
 		int src = 1, j = 0, tick = 0;
 		double carry = 0;
 		int16_t cur = 0;  // b2[j] while it is being accumulated

@@ -78,7 +78,13 @@ class GpuDemod:
 
     def run_torch(self, iq, out=None, out_len=None):
         """iq: torch uint8 [nstreams, nblocks*block_len] on this device.
-        Returns (out int16 [nstreams, cap], out_len int32 [nstreams])."""
+        Returns (out int16 [nstreams, cap], out_len int32 [nstreams]).
+
+        Stream contract: the library launches on the handle's own stream.  This method orders it
+        after torch's current stream (whatever produced ``iq`` and allocated / zeroed the outputs)
+        and makes torch's current stream wait for the library's kernels before it returns, so the
+        results can be used from torch without ``sync()`` and the caching allocator cannot hand
+        ``out`` to someone else while the kernels still write it.  ``run_device`` does neither."""
         import torch
         assert iq.dtype == torch.uint8 and iq.is_cuda and iq.dim() == 2 and iq.shape[0] == self.nstreams
         assert iq.stride(1) == 1
@@ -89,7 +95,10 @@ class GpuDemod:
             out = torch.empty((self.nstreams, cap), dtype=torch.int16, device=iq.device)
         if out_len is None:
             out_len = torch.zeros(self.nstreams, dtype=torch.int32, device=iq.device)
+        ts = torch.cuda.current_stream(iq.device).cuda_stream or None
+        check(self.lib.rtlfm_gpu_wait_for(self._h, ts), "rtlfm_gpu_wait_for")
         self.run_device(iq.data_ptr(), iq.stride(0), nb, out.data_ptr(), out.stride(0), out_len.data_ptr())
+        check(self.lib.rtlfm_gpu_release_to(self._h, ts), "rtlfm_gpu_release_to")
         return out, out_len
 
     # -- state & plumbing ------------------------------------------------------

@@ -49,9 +49,15 @@ class GpuPower:
               "rtlpower_gpu_scan_device")
 
     def scan_torch(self, iq):
-        """iq: torch uint8 [nstreams, nreads*buf_len] on the device."""
+        """iq: torch uint8 [nstreams, nreads*buf_len] on the device.  Ordered after torch's current
+        stream (the producer of ``iq``), and torch's current stream waits for the scan, so ``iq``
+        may be freed or overwritten from torch right away."""
+        import torch
         nreads = iq.shape[1] // int(self.cfg.buf_len)
+        ts = torch.cuda.current_stream(iq.device).cuda_stream or None
+        check(self.lib.rtlpower_gpu_wait_for(self._h, ts), "rtlpower_gpu_wait_for")
         self.scan_device(iq.data_ptr(), iq.stride(0), nreads)
+        check(self.lib.rtlpower_gpu_release_to(self._h, ts), "rtlpower_gpu_release_to")
 
     def fetch(self, stream: int = 0):
         n = 1 << self.cfg.bin_e

@@ -49,6 +49,20 @@ CASES = [
     ("box7_std_lpr", dict(downsample=7, rate_out=48000, rate_out2=11025,
                           resampler=RESAMPLE_LOW_PASS_REAL), WB),
     ("box256_std", dict(downsample=256), WB),
+    # per-buffer stages behind a boxcar that does not divide the buffer (the reference's own default
+    # plans: 8192 % 42, % 84, % 6, % 334 != 0), SURVEY.md §8 a14-a18
+    ("box42_dc", dict(downsample=42, rate_out=24000, dc_block_audio=1), dict(fs=1.008e6, dev_hz=2.5e3)),  # rtl_fm -s 24k -E dc
+    ("box84_am_dc", dict(mode=MODE_AM, downsample=84, rate_out=12000, output_scale=3, dc_block_audio=1),
+     dict(fs=1.008e6, dev_hz=2.5e3)),  # rtl_fm -M am -s 12k -E dc
+    ("box6_wbfm_dc", dict(downsample=6, custom_atan=ATAN_FAST, deemph=1, deemph_a=13, rate_out=170000,
+                          rate_out2=32000, resampler=RESAMPLE_LOW_PASS_REAL, dc_block_audio=1),
+     dict(fs=1.02e6, dev_hz=75e3)),  # rtl_fm -M wbfm -E dc
+    ("box334_usb", dict(mode=MODE_USB, downsample=334, rate_out=3000, output_scale=1), dict(fs=1.002e6, dev_hz=1e3)),  # -M usb -s 3k
+    ("box42_dc_arb_up32000", dict(downsample=42, rate_out=24000, dc_block_audio=1, rate_out2=32000,
+                                  resampler=RESAMPLE_ARBITRARY), dict(fs=1.008e6, dev_hz=2.5e3)),
+    ("box10_deemph_arb_down96000", dict(downsample=10, custom_atan=ATAN_FAST, deemph=1, deemph_a=19, rate_out=240000,
+                                        rate_out2=96000, resampler=RESAMPLE_ARBITRARY), WB),
+    ("box1000_std_squelch", dict(downsample=1000, rate_out=1000, squelch_level=50), dict(fs=1.0e6, dev_hz=200.0)),
 ]
 
 

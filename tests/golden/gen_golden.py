@@ -31,7 +31,9 @@ from rtlsdr_amd import synth  # noqa: E402
 SHAPES_MAIN = [(16384, 3)]
 SHAPES_SMALL = [(2048, 5)]
 BIG = {"c2_p4_std": [(262144, 2)], "c3_p6_fir9_deemph": [(262144, 2)]}
-MAIN = {"c1_boxcar10_fast", "c2_p4_std", "c2_p4_fir9_std", "c3_p6_fir9_deemph",
+MAIN = {"box42_dc", "box84_am_dc", "box6_wbfm_dc", "box334_usb", "box42_dc_arb_up32000",
+        "box10_deemph_arb_down96000",
+        "c1_boxcar10_fast", "c2_p4_std", "c2_p4_fir9_std", "c3_p6_fir9_deemph",
         "c3_p6_fir9_deemph_up22050", "wbfm_preset", "c2_p4_lut", "c2_p4_fast_a40"}
 
 
@@ -39,7 +41,16 @@ def main():
     po.build()
     assert po.have_reference(), "oracle/_ref not built (no /root/reference?)"
     manifest = {}
+    # --only name[,name...]: add fixtures for these cases to the existing manifest (the others stay
+    # byte-for-byte what earlier rounds committed)
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
     for name, ov, sig in CASES:
+        if only is not None and name not in only:
+            continue
         shapes = (SHAPES_MAIN if name in MAIN else SHAPES_SMALL) + BIG.get(name, [])
         for L, nb in shapes:
             cfg = make_cfg(ov, L)
@@ -58,7 +69,7 @@ def main():
                                 out_sha256=hashlib.sha256(out.tobytes()).hexdigest())
             print(fn, out.size)
     # full-scale random bytes: integer stages only (raw mode = decimator output)
-    for passes in (1, 3, 6, 7):
+    for passes in (1, 3, 6, 7) if only is None else ():
         ov = dict(mode=4, downsample=1 << passes, downsample_passes=passes, comp_fir_size=9)
         L, nb = 4096, 4
         cfg = make_cfg(ov, L)
@@ -74,6 +85,10 @@ def main():
                             cfg=cfg.as_dict(), out_len=int(out.size),
                             out_sha256=hashlib.sha256(out.tobytes()).hexdigest())
         print(fn, out.size)
+    if only is not None:
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     # planner known answers from the reference's static optimal_settings()
     ref = po.Reference()
     plan = []

@@ -9,7 +9,7 @@ import pytest
 
 from rtlsdr_amd import build as hipbuild
 from rtlsdr_amd import synth
-from rtlsdr_amd.capi import (ATAN_FAST, ATAN_STD, MODE_AM, MODE_FM, RESAMPLE_LOW_PASS_REAL, RtlfmCfg)
+from rtlsdr_amd.capi import (ATAN_FAST, ATAN_STD, MODE_AM, MODE_FM, MODE_USB, RESAMPLE_LOW_PASS_REAL, RtlfmCfg)
 
 pytestmark = pytest.mark.gpu
 
@@ -20,6 +20,12 @@ CASES = [
     (["-s", "16k", "-F", "9", "-E", "deemp", "-W", "128"], (16000, 1000000, 1, dict(rate_out=16000, comp_fir_size=9, deemph=1, block_len=65536)), 1.024e6),
     (["-M", "wbfm"], (170000, 1000000, 0, dict(rate_out=170000, rate_out2=32000, custom_atan=ATAN_FAST, deemph=1, resampler=RESAMPLE_LOW_PASS_REAL)), 1.02e6),
     (["-M", "am", "-s", "24k", "-F", "9", "-E", "dc"], (24000, 1000000, 1, dict(mode=MODE_AM, rate_out=24000, comp_fir_size=9, dc_block_audio=1)), 1.536e6),
+    # the reference's default plans: a boxcar that does not divide the 8192-sample buffer (/42, /84, /6, /334)
+    # in front of the per-buffer stages
+    (["-s", "24k", "-E", "dc"], (24000, 1000000, 0, dict(rate_out=24000, dc_block_audio=1)), 1.008e6),
+    (["-M", "am", "-s", "12k", "-E", "dc"], (12000, 1000000, 0, dict(mode=MODE_AM, rate_out=12000, dc_block_audio=1)), 1.008e6),
+    (["-M", "wbfm", "-E", "dc"], (170000, 1000000, 0, dict(rate_out=170000, rate_out2=32000, custom_atan=ATAN_FAST, deemph=1, resampler=RESAMPLE_LOW_PASS_REAL, dc_block_audio=1)), 1.02e6),
+    (["-M", "usb", "-s", "3k"], (3000, 1000000, 0, dict(mode=MODE_USB, rate_out=3000)), 1.002e6),
 ]
 
 

@@ -100,7 +100,7 @@ def _random_ref_cfg(rng):
         p_ = int(rng.integers(1, 9))
         ov.update(downsample=1 << p_, downsample_passes=p_, comp_fir_size=int(rng.choice([0, 9])))
     else:
-        ov.update(downsample=int(rng.choice([1, 2, 3, 5, 6, 10, 16, 25, 64, 100, 255, 256])), downsample_passes=0)
+        ov.update(downsample=int(rng.choice([1, 2, 3, 5, 6, 10, 16, 25, 42, 64, 84, 100, 255, 256, 334, 500])), downsample_passes=0)
     ov["custom_atan"] = int(rng.integers(0, 3))
     ov["offset_tuning"] = int(rng.random() < 0.25)
     ov["output_scale"] = int(rng.choice([1, 1, 2, 5]))
@@ -137,13 +137,13 @@ def test_oracle_random_configurations_vs_live_reference(oracle_lib, seed):
             L *= 2
     nb = int(rng.integers(2, 6))
     cfg = make_cfg(ov, L)
-    # stages that need the same count in every buffer are defined only when the boxcar divides it
+    # low_pass_simple is only defined for "length multiple of step" (src/rtl_fm.c:740): past that
+    # the reference sums stale samples beyond result_len.  Every other per-buffer stage works on
+    # whatever count the buffer has.
     per = (L // 2) // ov["downsample"] if ov["downsample_passes"] == 0 else (L // 2) >> ov["downsample_passes"]
     uneven = ov["downsample_passes"] == 0 and (L // 2) % ov["downsample"]
-    if uneven and (ov.get("post_downsample", 1) > 1 or ov.get("dc_block_audio") or ov.get("resampler") == 1 and ov.get("rate_out2", 0) > 0):
-        pytest.skip("per-buffer stage behind a boxcar that does not divide the buffer")
-    if ov.get("post_downsample", 1) > 1 and per % ov["post_downsample"]:
-        pytest.skip("post_downsample does not divide the buffer's output")
+    if ov.get("post_downsample", 1) > 1 and (uneven or per % ov["post_downsample"]):
+        pytest.skip("post_downsample does not divide the buffer's output: outside low_pass_simple's domain")
     amp = 55.0
     if ov["custom_atan"] == 1 and ov["mode"] == 0:
         gain = ov["downsample"] if ov["downsample_passes"] == 0 else 1 << ov["downsample_passes"]

@@ -399,7 +399,8 @@ def _random_cfg(rng):
         p_ = int(rng.integers(1, 8))
         ov.update(downsample=1 << p_, downsample_passes=p_, comp_fir_size=int(rng.choice([0, 9])))
     else:
-        ov.update(downsample=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 25, 32, 50, 64, 128, 255, 256])),
+        ov.update(downsample=int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 25, 32, 42, 50, 64, 84, 128, 255, 256,
+                                             334, 1000])),
                   downsample_passes=0)
     ov["custom_atan"] = int(rng.integers(0, 3))
     ov["offset_tuning"] = int(rng.random() < 0.25)
@@ -423,6 +424,21 @@ def _random_cfg(rng):
     return ov
 
 
+def _skip_only_outside_reference_domain(oracle_lib, cfg, L, err):
+    """rtlfm_gpu_create may only reject what the reference itself cannot run: the oracle (pinned to
+    the reference) must refuse the same configuration, or the rejection is a -EDOM / -EINVAL the
+    header documents as outside the reference's domain."""
+    iq = synth.fm_iq_u8(1, L // 2 * 2, seed=1)
+    try:
+        oracle_lib.run_batch(cfg, iq, nthreads=1)
+    except RuntimeError:
+        pytest.skip(f"outside the reference's domain (oracle refuses it too): {err}")
+    import errno
+    if err.code in (-errno.EDOM, -errno.EINVAL):
+        pytest.skip(f"outside the reference's domain: {err}")
+    raise AssertionError(f"the library rejects a configuration the reference runs: {err}")
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_configurations_vs_oracle(oracle_lib, seed):
     """Seeded random configurations through the automatic path selection (fused fifth_order /
@@ -438,7 +454,7 @@ def test_random_configurations_vs_oracle(oracle_lib, seed):
     try:
         GpuDemod(cfg, ns, 0).close()
     except capi.RtlfmError as e:
-        pytest.skip(f"configuration rejected by rtlfm_gpu_create: {e}")
+        _skip_only_outside_reference_domain(oracle_lib, cfg, L, e)
     amp = 25.0 if ov["custom_atan"] == 1 and ov["mode"] == capi.MODE_FM else 55.0
     if ov["custom_atan"] == 1 and ov["downsample_passes"] == 0:
         amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
@@ -604,7 +620,7 @@ def test_callback_path_random_configurations(oracle_lib, seed):
     try:
         GpuDemod(cfg, ns, 0).close()
     except capi.RtlfmError as e:
-        pytest.skip(f"configuration rejected by rtlfm_gpu_create: {e}")
+        _skip_only_outside_reference_domain(oracle_lib, cfg, L, e)
     amp = 25.0 if ov["custom_atan"] == 1 and ov["mode"] == capi.MODE_FM else 55.0
     if ov["custom_atan"] == 1 and ov["downsample_passes"] == 0:
         amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
