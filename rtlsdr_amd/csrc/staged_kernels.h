@@ -322,15 +322,19 @@ k_squelch_rms(const uint32_t *__restrict__ X, size_t xstride, int N, int D, int 
 	}
 	if (threadIdx.x == 0) {
 		p = rp[0]; t = rt[0];
-		int sr;
+		double r;
 		if (omit_dc_fix) {
 			int num = len / step;
-			sr = (int)sqrt((double)p / num);
+			r = sqrt((double)p / num);
 		} else {
 			double dc = (double)(int32_t)((uint32_t)t * (uint32_t)step) / (double)len;
 			double err = t * 2 * dc - dc * dc * len;
-			sr = (int)sqrt((p - err) / len);
+			r = sqrt((p - err) / len);
 		}
+		// the uint32 sum of squares wraps for large samples, p - err can go negative and the
+		// reference's (int)sqrt() of it is x86's "integer indefinite" INT_MIN, which the squelch
+		// skips (sr >= 0, src/rtl_fm.c:1206); v_cvt_i32_f64 would turn the NaN into 0
+		const int sr = r == r ? (int)r : INT32_MIN;
 		mute[sb] = (sr >= 0 && sr < level) ? 1 : (sr >= 0 ? 0 : 2);
 	}
 }
