@@ -248,6 +248,246 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// The same front end with the window sums taken as differences of a prefix sum: a boxcar is
+// P(hi) - P(lo), so the cost of a tile no longer depends on D (the window walk above is O(D/2)
+// LDS gathers and dot products per output and per component, 1619 VALU instructions per tile
+// at /6).  Per 8 KiB tile:
+//   1. the coalesced (non-temporal) loads are staged through LDS as S = raw ^ 0x7f and read back
+//      lane-contiguous: lane l owns dwords [32l, 32l + 32) = samples [64l, 64l + 64).  Rows are
+//      36 dwords apart, which makes both the 16-byte stores (eight consecutive lanes fill one row)
+//      and the 16-byte read-backs (eight lanes, eight rows) cover all 32 banks exactly once;
+//   2. a running sum along the lane's 32 dwords: two v_dot4_i32_i8 per dword whose +-1 taps carry
+//      the (-j)^n rotation and whose third operand is the sum so far - the chain IS the prefix.
+//      Before each dword the pair (I, Q) is packed to 16 + 16 bits with one v_perm: the reference
+//      stores the sums as int16 (src/rtl_fm.c:473-474), and truncation is a ring homomorphism, so
+//      every later add / subtract may wrap in 16-bit lanes (v_pk_add_u16 / v_pk_sub_u16);
+//   3. an exclusive wave scan (DPP row_shr / row_bcast) of the 64 lane totals in 32 bits, added to
+//      the lane's packed prefixes, which go back to the lane's own LDS row: P2[d] = sum of the
+//      rotated samples [0, 2d) of the tile;
+//   4. output e ends at sample n = (e + 1) D - phase: one LDS read of P2[n >> 1]; an odd n (odd
+//      D, or an odd phase injected through the state) adds the dword's first sample from a
+//      compact byte-pair copy of the tile.  The window's other end is the neighbouring lane's
+//      value (DPP wave_shr:1), the previous output for the discriminator likewise, so there is
+//      no LDS store -> load dependency between the rounds;
+//   5. the unfinished window: tile total - P(last boundary), exact in 16 bits for D <= 256.
+struct ScanLds {
+	static constexpr int atan = 0;                   // 17 doubles
+	static constexpr int rows = 36;                  // S, then P2: 64 rows of 32 dwords, 36 apart; + P2[2048]
+	static constexpr int row_stride = 36;
+	static constexpr int first = rows + 65 * row_stride;  // byte pairs of each dword's first sample: 64 rows of 16 dwords, 20 apart
+	static constexpr int first_stride = 20;
+	static constexpr int pcm = first + 64 * first_stride;
+	__host__ __device__ static int total(int out_cap) { return pcm + (out_cap + 3) / 2; }
+};
+
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+	return x;
+}
+
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) + fused::as_s2(b)); }
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) - fused::as_s2(b)); }
+
+#ifndef RTLFM_BOXSCAN_WAVES_PER_SIMD
+#define RTLFM_BOXSCAN_WAVES_PER_SIMD 2
+#endif
+
+template <bool STD>
+__global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_scan(const Params p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+	const int lane = threadIdx.x;
+	const int wave = blockIdx.x;
+	const int seg = wave % p.segs;
+	const int s = wave / p.segs;
+	if (s >= p.nstreams) return;
+	const int tpb = (int)(p.block_len / kTileBytes);
+	const int b0 = seg * p.blocks_per_seg;
+	int b1 = b0 + p.blocks_per_seg;
+	if (b1 > p.nblocks) b1 = p.nblocks;
+	if (b0 >= b1) return;
+	const bool from_state = (b0 == 0);
+	const bool writes_state = (b1 == p.nblocks);
+	const state_t *sin = p.sin + s;
+	state_t *sout = p.sout + s;
+	const int D = p.D;
+	uint16_t *pcm = reinterpret_cast<uint16_t *>(lds + ScanLds::pcm);
+
+	if (writes_state) {
+		const uint32_t *a = reinterpret_cast<const uint32_t *>(sin);
+		uint32_t *b = reinterpret_cast<uint32_t *>(sout);
+		for (int k = lane; k < (int)(sizeof(state_t) / 4); k += 64) b[k] = a[k];
+	}
+	if (lane < 17) reinterpret_cast<double *>(lds + ScanLds::atan)[lane] = k_atan_nodes[lane];
+	const int p0 = sin->prev_index;
+	const int gt_first = b0 * tpb;
+	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
+	const int gt_end = b1 * tpb;
+	int ph, kb;
+	{
+		const long long n = (long long)p0 + (long long)gt_begin * kTileSamples;
+		ph = (int)(n % D);
+		kb = (int)(n / D);
+	}
+	// 4096 is even, so the parity of the phase is that of p0 when D is even: wave-uniform for the run
+	const bool need_odd = ((D | 0) & 1) || (ph & 1) || ((p.r4096 & 1) != 0);
+	// the unfinished window carried into the tile (now_r, now_j) and the last complete output (I, Q packed)
+	int carry_r = from_state ? sin->now_r : 0, carry_j = from_state ? sin->now_j : 0;
+	uint32_t last_out = from_state ? pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j) : 0u;
+	__builtin_amdgcn_wave_barrier();
+	const fused::AtanNodesLds nodes{reinterpret_cast<const double *>(lds + ScanLds::atan)};
+
+	const int tI_even = p.rotate ? (int)0xFF0000FFu : (int)0x00FF00FFu;
+	const int tQ_even = p.rotate ? (int)0x0001FF00u : (int)0xFF00FF00u;
+	const int tI_odd = p.rotate ? (int)0x01000001u : tI_even;
+	const int tQ_odd = p.rotate ? (int)0x00FF0100u : tQ_even;
+
+	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
+	int16_t *out_base = p.out + (size_t)s * p.out_stride;
+	uint4 cur[8];
+	auto load_from = [&](const uint8_t *tb) {
+#pragma unroll
+		for (int k = 0; k < 8; k++) cur[k] = fused::load_stream16(tb + k * 1024 + lane * 16);
+	};
+	load_from(stream_base + (size_t)gt_begin * kTileBytes);
+
+	int flush_n = 0, flush_kb = 0;
+	auto flush = [&]() {
+		for (int e = lane; e < flush_n; e += 64) out_base[(size_t)flush_kb + e] = (int16_t)pcm[e];
+	};
+	uint32_t *row = lds + ScanLds::rows + ScanLds::row_stride * lane;  // this lane's 32 dwords
+
+	for (int gt = gt_begin; gt < gt_end; gt++) {
+		const bool more = gt + 1 < gt_end;
+		const bool bs = (gt % tpb) == 0;
+		const bool emit = gt >= gt_first;
+		const int wrap = (ph + p.r4096 >= D) ? 1 : 0;
+		const int Et = p.q4096 + wrap;
+		const int ph_next = ph + p.r4096 - (wrap ? D : 0);
+
+		// ---- 1. stage S: chunk c = 64k + lane -> row c >> 3, 16-byte slot c & 7
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const int c = 64 * k + lane;
+			uint4 v = cur[k];
+			v.x ^= 0x7f7f7f7fu; v.y ^= 0x7f7f7f7fu; v.z ^= 0x7f7f7f7fu; v.w ^= 0x7f7f7f7fu;
+			*reinterpret_cast<uint4 *>(lds + ScanLds::rows + ScanLds::row_stride * (c >> 3) + 4 * (c & 7)) = v;
+		}
+		__builtin_amdgcn_wave_barrier();
+		flush();
+		load_from(more ? stream_base + (size_t)(gt + 1) * kTileBytes : p.dummy_tile);  // unconditional (fused_kernel.h)
+
+		// ---- 2. the lane's running sum = exclusive prefix before each of its dwords
+		uint32_t pk[32];
+		int accI = 0, accQ = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(row + 4 * j);
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+			if (need_odd) {
+				// bytes 0, 1 of every dword (its first sample), two dwords per dword
+				const uint32_t f0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u);
+				const uint32_t f1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+				*reinterpret_cast<uint2 *>(lds + ScanLds::first + ScanLds::first_stride * lane + 2 * j) = make_uint2(f0, f1);
+			}
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				pk[4 * j + q] = __builtin_amdgcn_perm((uint32_t)accQ, (uint32_t)accI, 0x05040100u);
+				accI = __builtin_amdgcn_sdot4((int)w[q], (q & 1) ? tI_odd : tI_even, accI, false);
+				accQ = __builtin_amdgcn_sdot4((int)w[q], (q & 1) ? tQ_odd : tQ_even, accQ, false);
+			}
+		}
+		// ---- 3. exclusive scan of the lane totals, prefixes back to the lane's row
+		const int incI = wave_inclusive_scan(accI), incQ = wave_inclusive_scan(accQ);
+		const uint32_t off = __builtin_amdgcn_perm((uint32_t)(incQ - accQ), (uint32_t)(incI - accI), 0x05040100u);
+		const int totI = __builtin_amdgcn_readlane(incI, 63), totQ = __builtin_amdgcn_readlane(incQ, 63);
+		const uint32_t tot = pack_iq((int16_t)totI, (int16_t)totQ);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			uint4 v;
+			v.x = pk_add16(pk[4 * j], off); v.y = pk_add16(pk[4 * j + 1], off);
+			v.z = pk_add16(pk[4 * j + 2], off); v.w = pk_add16(pk[4 * j + 3], off);
+			*reinterpret_cast<uint4 *>(row + 4 * j) = v;
+		}
+		if (lane == 0) lds[ScanLds::rows + ScanLds::row_stride * 64] = tot;  // P2[2048]
+		__builtin_amdgcn_wave_barrier();
+
+		// ---- 4. outputs e = 64 r + lane: P(n_e) - P(n_{e-1}), discriminator
+		const int rounds = (Et + 63) / 64;
+		// what lane 0 of round 0 sees as its predecessors: -(carried partial sum) so that
+		// out[0] = carry + P(n_0), and the last output of the previous tile
+		uint32_t edgeP = pk_sub16(0u, pack_iq((int16_t)carry_r, (int16_t)carry_j));
+		uint32_t edgeZ = last_out;
+		uint32_t Plast = 0;  // P(n) of the last complete output
+		for (int r = 0; r < rounds; r++) {
+			const int e = r * 64 + lane;
+			int n = (e + 1) * D - ph;
+			if (n > kTileSamples) n = kTileSamples;  // lanes past Et
+			const int d = n >> 1;
+			uint32_t Pv = lds[ScanLds::rows + d + 4 * (d >> 5)];
+			if (need_odd) {
+				const uint32_t fp = reinterpret_cast<const uint16_t *>(lds + ScanLds::first)[d + ((d >> 5) << 3)];
+				// (S_a0 | S_b0 << 8) -> sign-extended 16-bit lanes; S = -(u - 127): the first sample of an
+				// even dword (n % 4 == 0) is (a, b) = -S, of an odd one (n % 4 == 2) (-a, -b) = +S
+				const uint32_t hi8 = __builtin_amdgcn_perm(0u, fp, 0x010c000cu);  // bytes: 0, a0, 0, b0
+				uint32_t fs = fused::as_u32(fused::as_s2(hi8) >> 8);
+				const bool plus = p.rotate && (d & 1);
+				fs = plus ? fs : pk_sub16(0u, fs);
+				Pv = (n & 1) ? pk_add16(Pv, fs) : Pv;
+			}
+			const uint32_t prevP = (uint32_t)__builtin_amdgcn_update_dpp((int)edgeP, (int)Pv, 0x138, 0xf, 0xf, false);  // wave_shr:1
+			const uint32_t z = pk_sub16(Pv, prevP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
+			const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp((int)edgeZ, (int)z, 0x138, 0xf, 0xf, false);
+			edgeP = (uint32_t)__builtin_amdgcn_readlane((int)Pv, 63);
+			edgeZ = (uint32_t)__builtin_amdgcn_readlane((int)z, 63);
+			if (r == rounds - 1) {
+				const int ll = (Et - 1) & 63;
+				Plast = (uint32_t)__builtin_amdgcn_readlane((int)Pv, ll);
+				last_out = (uint32_t)__builtin_amdgcn_readlane((int)z, ll);
+			}
+			if (e < Et) {
+				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
+				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
+				const int cr = fused::dot2_first(z, b);
+				const int cj = fused::dot2_first(z, bx);
+				int v;
+				if (!STD && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
+				else if (STD || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
+				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
+				else v = lut_atan2_q14_direct(cj, cr, nodes);
+				pcm[e] = (uint16_t)(int16_t)v;
+			}
+		}
+		// ---- 5. the window the tile leaves unfinished: fewer than D <= 256 samples, exact in 16 bits
+		{
+			const iq16 part = unpack_iq(pk_sub16(tot, Plast));
+			carry_r = part.i; carry_j = part.q;
+		}
+		__builtin_amdgcn_wave_barrier();
+		flush_n = emit ? Et : 0;
+		flush_kb = kb;
+		kb += Et;
+		ph = ph_next;
+	}
+	flush();
+	if (writes_state && lane == 0) {
+		sout->prev_index = ph;
+		sout->now_r = carry_r;
+		sout->now_j = carry_j;
+		const iq16 w = unpack_iq(last_out);
+		if (STD || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
+		p.cnt[s] = kb;
+	}
+}
+
 inline bool supported(const rtlfm_cfg &c)
 {
 	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
@@ -281,11 +521,17 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	segs = (nblocks + bps - 1) / bps;
 	p.segs = segs; p.blocks_per_seg = bps;
 	const int waves = nstreams * segs;
-	const size_t lds_bytes = (size_t)Lds::total(p.out_cap) * 4;
-	if (c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM)
-		hipLaunchKernelGGL((k_boxcar_fused<true>), dim3(waves), dim3(64), lds_bytes, q, p);
-	else
-		hipLaunchKernelGGL((k_boxcar_fused<false>), dim3(waves), dim3(64), lds_bytes, q, p);
+	static const bool walk = getenv("RTLFM_BOXCAR_WALK") != nullptr;  // the O(D) window walk, for A/B measurements
+	const bool std_fm = c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM;
+	if (walk) {
+		const size_t lds_bytes = (size_t)Lds::total(p.out_cap) * 4;
+		if (std_fm) hipLaunchKernelGGL((k_boxcar_fused<true>), dim3(waves), dim3(64), lds_bytes, q, p);
+		else hipLaunchKernelGGL((k_boxcar_fused<false>), dim3(waves), dim3(64), lds_bytes, q, p);
+	} else {
+		const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap) * 4;
+		if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<true>), dim3(waves), dim3(64), lds_bytes, q, p);
+		else hipLaunchKernelGGL((k_boxcar_scan<false>), dim3(waves), dim3(64), lds_bytes, q, p);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 
