@@ -55,6 +55,8 @@ struct Params {
 	int out_cap;          // 4096 / D + 2
 	int segs, blocks_per_seg;
 	const uint8_t *dummy_tile;  // what the reload reads after a segment's last tile (fused_kernel.h)
+	int has_first;              // k_boxcar_scan: the LDS copy of each dword's first sample exists (odd D)
+	int R;                      // k_boxcar_scan: outputs per lane and tile, ceil((4096 / D + 1) / 64)
 };
 
 // LDS layout in dwords
@@ -273,12 +275,16 @@ __global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
 //   5. the unfinished window: tile total - P(last boundary), exact in 16 bits for D <= 256.
 struct ScanLds {
 	static constexpr int atan = 0;                   // 17 doubles
+	static constexpr int scratch = 34;               // boundary and value of the tile's last complete output
 	static constexpr int rows = 36;                  // S, then P2: 64 rows of 32 dwords, 36 apart; + P2[2048]
 	static constexpr int row_stride = 36;
 	static constexpr int first = rows + 65 * row_stride;  // byte pairs of each dword's first sample: 64 rows of 16 dwords, 20 apart
 	static constexpr int first_stride = 20;
-	static constexpr int pcm = first + 64 * first_stride;
-	__host__ __device__ static int total(int out_cap) { return pcm + (out_cap + 3) / 2; }
+	// the byte-pair copy is only allocated for odd D.  With an even D the window ends are all even or
+	// all odd for the whole run (4096 and the buffer are even), and odd only if an odd prev_index was
+	// injected through rtlfm_gpu_state_set: that run fetches the bytes from the input itself.
+	__host__ __device__ static int pcm(bool has_first) { return has_first ? first + 64 * first_stride : first; }
+	__host__ __device__ static int total(int out_cap, bool has_first) { return pcm(has_first) + (out_cap + 16) / 2; }
 };
 
 // inclusive scan over the 64 lanes of a wave
@@ -293,11 +299,37 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 	return x;
 }
 
+// One dword of the running sum: pk = the sums BEFORE this dword packed to 16 + 16 bits (the
+// exclusive prefix), then both components advanced by the dword's two rotated samples.
+// Inline assembly because (a) hipcc only emits the accumulate-in-place v_dot4c here and copies the
+// old sums first (two v_mov and wait states per dword), and (b) on gfx950 a VALU instruction that
+// is not the same dot opcode must stay three instructions behind the dot whose result it reads —
+// the hazard recogniser does not look into inline assembly, so the order is fixed here: the v_perm
+// reads sums that were written by the previous block's dots, three instructions back.  The dots
+// themselves read the previous sums as their accumulate operand, which forwards without a wait.
+__device__ __forceinline__ void chain_step(uint32_t w, int tapI, int tapQ, int &accI, int &accQ, uint32_t &pk)
+{
+	int ni, nq;
+	uint32_t k;
+	asm("v_dot4_i32_i8 %0, %3, %4, %6\n\t"
+	    "v_dot4_i32_i8 %1, %3, %5, %7\n\t"
+	    "v_perm_b32 %2, %7, %6, %8"
+	    : "=&v"(ni), "=&v"(nq), "=&v"(k)
+	    : "v"(w), "s"(tapI), "s"(tapQ), "v"(accI), "v"(accQ), "s"(0x05040100u));
+	accI = ni; accQ = nq; pk = k;
+}
+// after the last dword the totals go into DPP instructions: three wait states for the dot result
+// plus the two a DPP source needs
+__device__ __forceinline__ void chain_settle(int &accI, int &accQ)
+{
+	asm volatile("s_nop 4" : "+v"(accI), "+v"(accQ));
+}
+
 __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) + fused::as_s2(b)); }
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) - fused::as_s2(b)); }
 
 #ifndef RTLFM_BOXSCAN_WAVES_PER_SIMD
-#define RTLFM_BOXSCAN_WAVES_PER_SIMD 2
+#define RTLFM_BOXSCAN_WAVES_PER_SIMD 3
 #endif
 
 template <bool STD>
@@ -319,7 +351,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	const state_t *sin = p.sin + s;
 	state_t *sout = p.sout + s;
 	const int D = p.D;
-	uint16_t *pcm = reinterpret_cast<uint16_t *>(lds + ScanLds::pcm);
+	const int pcm_at = ScanLds::pcm(p.has_first != 0);
+	uint16_t *pcm = reinterpret_cast<uint16_t *>(lds + pcm_at);
 
 	if (writes_state) {
 		const uint32_t *a = reinterpret_cast<const uint32_t *>(sin);
@@ -338,7 +371,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		kb = (int)(n / D);
 	}
 	// 4096 is even, so the parity of the phase is that of p0 when D is even: wave-uniform for the run
-	const bool need_odd = ((D | 0) & 1) || (ph & 1) || ((p.r4096 & 1) != 0);
+	const bool need_odd = (D & 1) || (ph & 1);
+	const bool first_in_lds = need_odd && p.has_first;
 	// the unfinished window carried into the tile (now_r, now_j) and the last complete output (I, Q packed)
 	int carry_r = from_state ? sin->now_r : 0, carry_j = from_state ? sin->now_j : 0;
 	uint32_t last_out = from_state ? pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j) : 0u;
@@ -359,9 +393,24 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	};
 	load_from(stream_base + (size_t)gt_begin * kTileBytes);
 
+	// The PCM of a tile waits in LDS at index ((al + kb) & 7) + e, al = the row's element offset
+	// inside its 16-byte line: LDS group j of eight then is one aligned 16-byte piece of d_out and
+	// leaves as one dwordx4 per lane (all groups read first, then stored); the partial groups at
+	// both ends go element by element.
+	const int al = (int)(((uintptr_t)out_base >> 1) & 7);
 	int flush_n = 0, flush_kb = 0;
 	auto flush = [&]() {
-		for (int e = lane; e < flush_n; e += 64) out_base[(size_t)flush_kb + e] = (int16_t)pcm[e];
+		if (flush_n <= 0 || (RTLFM_ABLATE & 2)) return;
+		const int a = (al + flush_kb) & 7, last = a + flush_n;
+		int16_t *g16 = out_base + ((ptrdiff_t)((RTLFM_ABLATE & 8) ? (flush_kb & 7) : flush_kb) - a);  // & 8: analysis build, every tile to the same lines
+		typedef uint4 __attribute__((may_alias)) u128_alias;  // the PCM is written as uint16
+		const u128_alias *pcm128 = reinterpret_cast<const u128_alias *>(lds + pcm_at);
+		const int j0 = (a + 7) >> 3, j1 = last >> 3;
+		for (int j = j0 + lane; j < j1; j += 64) reinterpret_cast<uint4 *>(g16)[j] = pcm128[j];
+		const int lead_end = 8 * j0 < last ? 8 * j0 : last;
+		if (lane < 8 && a + lane < lead_end) g16[a + lane] = (int16_t)pcm[a + lane];
+		const int t = 8 * j1 + (lane - 8);
+		if (lane >= 8 && lane < 16 && j1 >= j0 && t < last) g16[t] = (int16_t)pcm[t];
 	};
 	uint32_t *row = lds + ScanLds::rows + ScanLds::row_stride * lane;  // this lane's 32 dwords
 
@@ -392,7 +441,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		for (int j = 0; j < 8; j++) {
 			const uint4 v = *reinterpret_cast<const uint4 *>(row + 4 * j);
 			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-			if (need_odd) {
+			if (first_in_lds) {
 				// bytes 0, 1 of every dword (its first sample), two dwords per dword
 				const uint32_t f0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u);
 				const uint32_t f1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
@@ -400,11 +449,10 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
-				pk[4 * j + q] = __builtin_amdgcn_perm((uint32_t)accQ, (uint32_t)accI, 0x05040100u);
-				accI = __builtin_amdgcn_sdot4((int)w[q], (q & 1) ? tI_odd : tI_even, accI, false);
-				accQ = __builtin_amdgcn_sdot4((int)w[q], (q & 1) ? tQ_odd : tQ_even, accQ, false);
+				chain_step(w[q], (q & 1) ? tI_odd : tI_even, (q & 1) ? tQ_odd : tQ_even, accI, accQ, pk[4 * j + q]);
 			}
 		}
+		chain_settle(accI, accQ);
 		// ---- 3. exclusive scan of the lane totals, prefixes back to the lane's row
 		const int incI = wave_inclusive_scan(accI), incQ = wave_inclusive_scan(accQ);
 		const uint32_t off = __builtin_amdgcn_perm((uint32_t)(incQ - accQ), (uint32_t)(incI - accI), 0x05040100u);
@@ -420,21 +468,22 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		if (lane == 0) lds[ScanLds::rows + ScanLds::row_stride * 64] = tot;  // P2[2048]
 		__builtin_amdgcn_wave_barrier();
 
-		// ---- 4. outputs e = 64 r + lane: P(n_e) - P(n_{e-1}), discriminator
-		const int rounds = (Et + 63) / 64;
-		// what lane 0 of round 0 sees as its predecessors: -(carried partial sum) so that
-		// out[0] = carry + P(n_0), and the last output of the previous tile
-		uint32_t edgeP = pk_sub16(0u, pack_iq((int16_t)carry_r, (int16_t)carry_j));
-		uint32_t edgeZ = last_out;
-		uint32_t Plast = 0;  // P(n) of the last complete output
-		for (int r = 0; r < rounds; r++) {
-			const int e = r * 64 + lane;
+		// ---- 4. lane l takes the R consecutive outputs e = l R .. l R + R - 1: the window's other end
+		// P(n_{e-1}) and the previous output are the lane's own values of the iteration before, and for
+		// its first output two more look-ups, so nothing is exchanged between lanes and the look-up of
+		// output e + 1 is in flight while output e goes through the discriminator.
+		// P(n_{-1}) = -(carried partial sum), so that out[0] = carry + P(n_0); z_{-1} = the last output
+		// of the previous tile.
+		const uint32_t edgeP = pk_sub16(0u, pack_iq((int16_t)carry_r, (int16_t)carry_j));
+		auto P_at = [&](int e) -> uint32_t {  // P(n_e) for e >= 0
 			int n = (e + 1) * D - ph;
-			if (n > kTileSamples) n = kTileSamples;  // lanes past Et
+			if (n > kTileSamples) n = kTileSamples;  // outputs past Et
 			const int d = n >> 1;
 			uint32_t Pv = lds[ScanLds::rows + d + 4 * (d >> 5)];
 			if (need_odd) {
-				const uint32_t fp = reinterpret_cast<const uint16_t *>(lds + ScanLds::first)[d + ((d >> 5) << 3)];
+				uint32_t fp;
+				if (first_in_lds) fp = reinterpret_cast<const uint16_t *>(lds + ScanLds::first)[d + ((d >> 5) << 3)];
+				else fp = (uint32_t)*reinterpret_cast<const uint16_t *>(stream_base + (size_t)gt * kTileBytes + 4 * (d < kTileDwords ? d : 0)) ^ 0x7f7fu;
 				// (S_a0 | S_b0 << 8) -> sign-extended 16-bit lanes; S = -(u - 127): the first sample of an
 				// even dword (n % 4 == 0) is (a, b) = -S, of an odd one (n % 4 == 2) (-a, -b) = +S
 				const uint32_t hi8 = __builtin_amdgcn_perm(0u, fp, 0x010c000cu);  // bytes: 0, a0, 0, b0
@@ -443,29 +492,43 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				fs = plus ? fs : pk_sub16(0u, fs);
 				Pv = (n & 1) ? pk_add16(Pv, fs) : Pv;
 			}
-			const uint32_t prevP = (uint32_t)__builtin_amdgcn_update_dpp((int)edgeP, (int)Pv, 0x138, 0xf, 0xf, false);  // wave_shr:1
-			const uint32_t z = pk_sub16(Pv, prevP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
-			const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp((int)edgeZ, (int)z, 0x138, 0xf, 0xf, false);
-			edgeP = (uint32_t)__builtin_amdgcn_readlane((int)Pv, 63);
-			edgeZ = (uint32_t)__builtin_amdgcn_readlane((int)z, 63);
-			if (r == rounds - 1) {
-				const int ll = (Et - 1) & 63;
-				Plast = (uint32_t)__builtin_amdgcn_readlane((int)Pv, ll);
-				last_out = (uint32_t)__builtin_amdgcn_readlane((int)z, ll);
-			}
+			return Pv;
+		};
+		const int R = (RTLFM_ABLATE & 4) ? 0 : p.R;
+		const int e0 = lane * R;
+		uint32_t prevP, b;
+		{
+			const uint32_t a1 = P_at(e0 > 0 ? e0 - 1 : 0), a2 = P_at(e0 > 1 ? e0 - 2 : 0);
+			prevP = e0 > 0 ? a1 : edgeP;
+			b = e0 > 0 ? pk_sub16(a1, e0 > 1 ? a2 : edgeP) : last_out;
+		}
+		uint32_t curP = P_at(e0);
+		for (int r = 0; r < R; r++) {
+			const int e = e0 + r;
+			const uint32_t nxtP = P_at(e + 1);
+			const uint32_t z = pk_sub16(curP, prevP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
 			if (e < Et) {
 				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
 				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
 				const int cr = fused::dot2_first(z, b);
 				const int cj = fused::dot2_first(z, bx);
 				int v;
-				if (!STD && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
+				if (RTLFM_ABLATE & 1) v = cj ^ cr;  // analysis builds only (tools/ablate.sh)
+				else if (!STD && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
 				else if (STD || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
 				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
-				pcm[e] = (uint16_t)(int16_t)v;
+				pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v;
+				if (e == Et - 1) {  // the last complete output: its boundary and its value
+					lds[ScanLds::scratch] = curP;
+					lds[ScanLds::scratch + 1] = z;
+				}
 			}
+			prevP = curP; b = z; curP = nxtP;
 		}
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t Plast = lds[ScanLds::scratch];
+		last_out = lds[ScanLds::scratch + 1];
 		// ---- 5. the window the tile leaves unfinished: fewer than D <= 256 samples, exact in 16 bits
 		{
 			const iq16 part = unpack_iq(pk_sub16(tot, Plast));
@@ -528,7 +591,9 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 		if (std_fm) hipLaunchKernelGGL((k_boxcar_fused<true>), dim3(waves), dim3(64), lds_bytes, q, p);
 		else hipLaunchKernelGGL((k_boxcar_fused<false>), dim3(waves), dim3(64), lds_bytes, q, p);
 	} else {
-		const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap) * 4;
+		p.has_first = (p.D & 1) ? 1 : 0;
+		p.R = (p.q4096 + 1 + 63) / 64;
+		const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0) * 4;
 		if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<true>), dim3(waves), dim3(64), lds_bytes, q, p);
 		else hipLaunchKernelGGL((k_boxcar_scan<false>), dim3(waves), dim3(64), lds_bytes, q, p);
 	}

@@ -689,3 +689,37 @@ def test_atan2_q14_against_libm_and_oracle(oracle_lib):
     host = np.trunc(np.arctan2(yx[:, 0].astype(np.float64), yx[:, 1].astype(np.float64)) / 3.14159 * 16384.0).astype(np.int32)
     assert int((a != b).sum()) == 0, f"atan2_q14 vs device libm: {(a != b).sum()} of {n} differ"
     assert int((a != host).sum()) == 0, f"atan2_q14 vs glibc chain: {(a != host).sum()} of {n} differ"
+
+
+@pytest.mark.parametrize("D,atan", [(10, 0), (6, 1), (16, 2), (7, 0), (255, 1), (2, 0), (3, 1)])
+def test_boxcar_injected_phase_and_partial_sum(oracle_lib, D, atan):
+    """low_pass (src/rtl_fm.c:461-481) carries (now_r, now_j, prev_index) between buffers.  A state
+    injected through rtlfm_gpu_state_set may hold any phase — with an even D an odd prev_index makes
+    every window of the run end on an odd sample, which the fused boxcar front end only meets this
+    way — and any partial sum; full-scale bytes make the int16 store wrap."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, nb, ns = 16384, 4, 6
+    ov = dict(downsample=D, custom_atan=atan, rate_out=int(2.4e6 / D))
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=5150 + D, amplitude=20.0 if atan == 1 else 60.0)
+    iq[ns - 1] = synth.random_u8(1, L * nb, seed=D)[0] if atan != 1 else iq[ns - 1]
+    st0 = oracle_lib.new_states(ns)
+    for s in range(ns):
+        st0[s].prev_index = (2 * s + 1) % D
+        st0[s].now_r = 37 * s - 90
+        st0[s].now_j = -11 * s + 40
+        st0[s].pre_r = 100 - s
+        st0[s].pre_j = 7 * s
+    st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
+    for path in (0, 1):
+        with GpuDemod(cfg, ns, 0) as g:
+            g.set_path(path)
+            for s in range(ns):
+                g.state_set(s, st_copy[s])
+            o, n = g.run_torch(torch.from_numpy(iq).cuda()); g.sync()
+            o = o.cpu().numpy(); n = n.cpu().numpy()
+            assert np.array_equal(n, want_len)
+            for s in range(ns):
+                assert_parity(o[s, :n[s]], want[s, :want_len[s]], cfg, f"D={D} path={path} stream {s}")
+                assert gu.state_dict(g.state_get(s), False) == gu.state_dict(wst[s], False)

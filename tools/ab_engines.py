@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--block-len", type=int, default=262144)
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--fir9", action="store_true")
+    ap.add_argument("--boxcar", type=int, default=0, help="D > 0: the low_pass boxcar front end instead of fifth_order passes")
     ap.add_argument("--atan", choices=["std", "fast", "lut"], default="std")
     ap.add_argument("--rounds", type=int, default=60)
     ap.add_argument("--burst", type=int, default=5, help="launches per engine per round")
@@ -36,6 +37,8 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     D = 1 << a.passes
+    if a.boxcar:
+        a.passes, a.fir9, D = 0, False, a.boxcar
     cfg = RtlfmCfg.default(downsample=D, downsample_passes=a.passes, rate_out=int(2.4e6 / D),
                            comp_fir_size=9 if a.fir9 else 0,
                            custom_atan={"std": ATAN_STD, "fast": ATAN_FAST, "lut": ATAN_LUT}[a.atan],
