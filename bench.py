@@ -1,27 +1,47 @@
 #!/usr/bin/env python3
 """bench.py — IQ Msamples/s demodulated on MI355X, with roofline and CPU baseline.
 
-One "step" is one pass of the hot path (u8 IQ -> rotate -> fifth_order x passes
--> FM discriminant -> int16 PCM, reference src/rtl_fm.c:1326-1338 + 1179-1272)
-over one batch of synthetic input that is already resident in HBM.
+One "step" is one pass of the hot path (u8 IQ -> rotate -> decimate -> discriminator [-> audio
+tail] -> int16 PCM, reference src/rtl_fm.c:1326-1338 + 1179-1272; for `--workload c4` rtl_power's
+scanner(), src/rtl_power.c:642-720) over one batch of synthetic input that is already resident
+in HBM.
 
-Default workload = BASELINE.json configs[1]: 256 batched 2.4 MS/s WBFM streams,
-`-M fm -s 150k -m 1.3M -F 0` (4 fifth_order passes, /16, polar_discriminant),
-64 callback buffers of 262144 B per stream per step (4 GiB of IQ per GPU).
-
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--workload c2] --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Streams are independent: rank r owns its own `--streams` streams (weak
-scaling), there is no data-path collective; RCCL is used only for the barrier
-and the max-over-ranks of the elapsed time.
+Workloads (BASELINE.json `configs`; the default line is configs[1]):
+
+    c2      256 streams x 64 buffers x 262144 B @2.4 MS/s, -F 0 (4x fifth_order, /16), -A std   [default]
+    ns4096  north_star's target shape: 4096 streams x 4 buffers x 262144 B through the same /16 FM path
+    c1      config 0's chain batched: low_pass boxcar /10 + -A fast, 256 x 64 x 262144 B @2.4 MS/s
+    wbfm    rtl_fm -M wbfm: boxcar /6, -A fast, deemph, low_pass_real 170k -> 32k, 1024 x 16 x 262144 B
+    c3      4096 NBFM streams @1.024 MS/s: 6x fifth_order + FIR9 (/64), deemph, arbitrary_resample -> 22050
+    c4      rtl_power: 1024 streams x 64 reads x 32768 B, hamming window + 16k-bin fix_fft + integrate
+
+Streams are independent: rank r owns its own streams (weak scaling), there is no data-path
+collective; RCCL is used only for the barrier and the max-over-ranks of the elapsed time.
+`python bench.py --gpus N` outside torchrun starts the N ranks itself.
+
+Besides the contract fields the line carries
+  roofline.sustained   the same step repeated for >= --sustain seconds (the short K-step figure is
+                       taken right after the warm-up; the GPU sits at its 1.4 kW cap on this path
+                       and the clock settles over seconds)
+  roofline.traffic     HBM bytes per launch of the dominant kernel from two rocprofv3 --pmc passes
+                       (FETCH_SIZE, WRITE_SIZE; separate runs, no tracing) made by this very
+                       invocation on this box before the timed run (N = 1; --pmc 0 skips them)
+  roofline.shader_mhz  mean shader clock of the waves of a launch, stamped in the kernel
+  cpu_baseline         the reference's own code (oracle/_ref) or the oracle port on the host cores
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,30 +49,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
+# name -> argument defaults (explicit flags win)
+WORKLOADS = {
+    "c2": dict(streams=256, blocks=64, block_len=262144, passes=4, boxcar=0, fir9=0, atan="std", fs=2.4e6, tail=""),
+    "ns4096": dict(streams=4096, blocks=4, block_len=262144, passes=4, boxcar=0, fir9=0, atan="std", fs=2.4e6, tail=""),
+    "c1": dict(streams=256, blocks=64, block_len=262144, passes=0, boxcar=10, fir9=0, atan="fast", fs=2.4e6, tail=""),
+    "wbfm": dict(streams=1024, blocks=16, block_len=262144, passes=0, boxcar=6, fir9=0, atan="fast", fs=1.02e6, tail="wbfm"),
+    "c3": dict(streams=4096, blocks=4, block_len=262144, passes=6, boxcar=0, fir9=1, atan="std", fs=1.024e6, tail="c3"),
+    "c4": dict(streams=1024, blocks=64, block_len=32768, passes=0, boxcar=0, fir9=0, atan="std", fs=2.048e6, tail="power"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # a launch is ~0.9 ms; after idle the GPU needs ~50 of them to reach its steady clock
-    # (30 timed launches behind 5 warm-ups measure the ramp: 0.91 ms against 0.83 ms)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--blocks", type=int, default=64, help="callback buffers per stream per step")
-    ap.add_argument("--block-len", type=int, default=262144)
-    ap.add_argument("--passes", type=int, default=4)
-    ap.add_argument("--boxcar", type=int, default=0,
-                    help="D > 0: the reference's default low_pass boxcar /D instead of fifth_order passes "
-                         "(config 1 / -M wbfm shaped work; not the default line)")
-    ap.add_argument("--fir9", type=int, default=0)
-    ap.add_argument("--atan", choices=["std", "fast", "lut"], default="std")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU")
+    ap.add_argument("--blocks", type=int, default=None, help="callback buffers (c4: reads) per stream per step")
+    ap.add_argument("--block-len", type=int, default=None)
+    ap.add_argument("--passes", type=int, default=None)
+    ap.add_argument("--boxcar", type=int, default=None,
+                    help="D > 0: the reference's default low_pass boxcar /D instead of fifth_order passes")
+    ap.add_argument("--fir9", type=int, default=None)
+    ap.add_argument("--atan", choices=["std", "fast", "lut"], default=None)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 staged, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=1, help="have the cpu_baseline leg compare a slice of the GPU output with the CPU path")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the sustained leg after the K timed steps (0: skip)")
+    ap.add_argument("--pmc", type=int, default=-1, help="rocprofv3 PMC passes for roofline.traffic: 1 on, 0 off, -1 on for N = 1 when rocprofv3 exists")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scatter", action="store_true",
                     help="N > 1: also time shard.scatter_streams (root GPU -> its owner GPUs) of one step's IQ over RCCL")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.boxcar is not None and a.boxcar > 0 and a.passes is None:
+        a.passes = 0
+    if a.passes is not None and a.passes > 0 and a.boxcar is None:
+        a.boxcar = 0
+    for k, v in WORKLOADS[a.workload].items():
+        if getattr(a, k, None) is None:
+            setattr(a, k, v)
+    if a.boxcar:
+        a.passes, a.fir9 = 0, 0
+    return a
 
 
 def launch_ranks(a) -> int:
@@ -64,7 +106,6 @@ def launch_ranks(a) -> int:
     The JSON line is printed by rank 0 of the child job; this process only relays its exit code.
     """
     import socket
-    import subprocess
 
     import torch
     have = torch.cuda.device_count()
@@ -87,6 +128,70 @@ def launch_ranks(a) -> int:
     return subprocess.call(cmd, env=env)
 
 
+# ---------------------------------------------------------------- PMC passes ----
+
+def dominant_kernel(a) -> str:
+    if a.tail == "power":
+        return "k_power_scan"
+    return "k_boxcar_scan" if a.boxcar else "k_fused"
+
+
+def pmc_traffic(a):
+    """HBM bytes per launch of the dominant kernel, measured now, on this box: two child runs of this
+    script under `rocprofv3 --pmc` (one counter per run, no tracing domains, as MI355X_MICROARCH.md
+    prescribes), started before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB at
+    the L2's memory side; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane
+    streaming loads at 64 bytes, so it is doubled (same guide)."""
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None
+    import csv
+    pat = dominant_kernel(a)
+    base = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--pmc", "0", "--gpus", "1", "--steps", "3",
+            "--warmup", "2", "--sustain", "0", "--no-cpu-baseline", "--check", "0", "--workload", a.workload,
+            "--streams", str(a.streams), "--blocks", str(a.blocks), "--block-len", str(a.block_len),
+            "--path", str(a.path), "--atan", a.atan]
+    base += ["--boxcar", str(a.boxcar)] if a.boxcar else ["--passes", str(a.passes), "--fir9", str(a.fir9)]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="rtlfm_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + base
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                print(f"bench.py: rocprofv3 --pmc {ctr} did not finish in 240 s; roofline.traffic left null", file=sys.stderr)
+                return None
+            print(f"bench.py: rocprofv3 --pmc {ctr} pass took {time.perf_counter() - t0:.0f} s", file=sys.stderr)
+            if r.returncode != 0:
+                print(f"bench.py: rocprofv3 --pmc {ctr} failed ({r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if pat in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            per.setdefault(row["Dispatch_Id"], 0.0)
+                            per[row["Dispatch_Id"]] += float(row["Counter_Value"])
+            if not per:
+                return None
+            big = [v for v in per.values() if v >= 0.5 * max(per.values())]  # the parity-gate sized launches are left out
+            out[ctr] = sum(big) / len(big)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_b, write_b = 2.0 * out["FETCH_SIZE"] * 1024.0, out["WRITE_SIZE"] * 1024.0
+    return {"bytes": int(fetch_b + write_b), "fetch_bytes": int(fetch_b), "write_bytes": int(write_b),
+            "kernel": pat, "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this invocation on this box; "
+                                  "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B), KiB -> bytes"}
+
+
+# --------------------------------------------------------------- CPU baseline ----
+
 def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
     """CPU baseline on the GPU box's host cores, bounded to roughly `seconds`.
 
@@ -106,8 +211,9 @@ def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
         gcfg, giq, gout, glen = gate
         want, wl, _ = po.run_batch(gcfg, giq, nthreads=4)
         assert (glen == wl).all(), "parity gate: output counts differ"
-        d = np.abs(gout[:, :wl[0]].astype(np.int32) - want[:, :wl[0]].astype(np.int32))
-        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, f"parity gate failed: max {d.max()}, {(d != 0).sum()} differ"
+        for s in range(len(wl)):
+            d = np.abs(gout[s, :wl[s]].astype(np.int32) - want[s, :wl[s]].astype(np.int32))
+            assert d.max() <= 1 and (d != 0).mean() <= 1e-4, f"parity gate failed: max {d.max()}, {(d != 0).sum()} differ"
     cores = os.cpu_count() or 1
     ns, nbytes = iq_host_sample.shape
     L = int(cfg.block_len)
@@ -154,6 +260,32 @@ def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
     }
 
 
+def cpu_baseline_power(cfg, sample, seconds, gate=None):
+    """rtl_power's scanner() on the host cores: the oracle port (pinned function by function to
+    the reference's rtl_power.c compiled in place), one pthread per stream, bounded."""
+    import numpy as np
+    from oracle import pyoracle as po
+    if gate is not None:
+        giq, gavg, gsamples = gate
+        want, wn = po.power_scan_batch(cfg, giq, nthreads=4)
+        assert np.array_equal(wn, gsamples) and np.array_equal(want, gavg), "parity gate failed (rtl_power)"
+    cs = sample.shape[0]
+    t1 = time.perf_counter()
+    po.power_scan_batch(cfg, sample, nthreads=cs)
+    one = max(time.perf_counter() - t1, 1e-3)
+    reps = max(1, int(seconds / one))
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        po.power_scan_batch(cfg, sample, nthreads=cs)
+    dt = time.perf_counter() - t1
+    L = int(cfg.buf_len)
+    nreads = sample.shape[1] // L
+    samples = reps * cs * nreads * (L // 2)
+    return {"value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "cores": cs, "kind": "port",
+            "sample": f"oracle port of scanner() (src/rtl_power.c:642-720): {cs} pthreads x 1 stream x {nreads} reads x {L} B "
+                      f"x {reps} reps ({samples / 1e6:.0f} Msamples in {dt:.1f} s)"}
+
+
 def time_scatter(dist, rank, world, dev, streams_per_rank, bytes_per_stream, reps=3):
     """The one optional exchange of the path: all IQ of a step lands on rank 0's
     GPU and every rank receives its contiguous stream range (shard.scatter_streams: isend/recv
@@ -188,30 +320,168 @@ def time_scatter(dist, rank, world, dev, streams_per_rank, bytes_per_stream, rep
             "what": f"root -> {world - 1} peers, {per} streams x {bytes_per_stream} B each, {dist.get_backend()}"}
 
 
-def measured_traffic(workload_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes (profiles/pmc_latest.json: FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950, + WRITE_SIZE), when they were taken on this workload."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            d = json.load(f)
-        if d.get("workload_key") == workload_key:
-            return d["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+# ------------------------------------------------------------------- workloads ----
+
+class FmJob:
+    """rtl_fm's chain on S streams x NB buffers per step."""
+
+    def __init__(self, a, dev, local_rank, rank):
+        import torch
+        from rtlsdr_amd import synth
+        from rtlsdr_amd.capi import (ATAN_FAST, ATAN_LUT, ATAN_STD, RESAMPLE_ARBITRARY, RESAMPLE_LOW_PASS_REAL,
+                                     RtlfmCfg, load)
+        from rtlsdr_amd.demod import GpuDemod
+        self.a, self.torch = a, torch
+        lib = load()
+        atan = {"std": ATAN_STD, "fast": ATAN_FAST, "lut": ATAN_LUT}[a.atan]
+        D = a.boxcar if a.boxcar else 1 << a.passes
+        self.D = D
+        rate_out = int(a.fs / D)
+        kw = dict(downsample=D, downsample_passes=a.passes, comp_fir_size=9 if a.fir9 else 0, custom_atan=atan,
+                  rate_out=rate_out, block_len=a.block_len, max_blocks=a.blocks)
+        self.out_ratio = 1.0
+        if a.tail == "c3":
+            kw.update(rate_out=16000, deemph=1, deemph_a=lib.rtlfm_deemph_a(16000, 75), rate_out2=22050,
+                      resampler=RESAMPLE_ARBITRARY)
+            self.out_ratio = 176.0 / 128.0  # per 262144-B buffer: 2048 -> 2822 (SURVEY §8 a18)
+        elif a.tail == "wbfm":
+            kw.update(rate_out=170000, deemph=1, deemph_a=lib.rtlfm_deemph_a(170000, 75), rate_out2=32000,
+                      resampler=RESAMPLE_LOW_PASS_REAL)
+            self.out_ratio = 32000.0 / 170000.0
+        self.cfg = RtlfmCfg.default(**kw)
+        S, NB, L = a.streams, a.blocks, a.block_len
+        self.samples = S * NB * L // 2
+        amp = 40.0 if a.atan == "fast" else 60.0  # -A fast overflows above |z| ~ 724 (SURVEY §8 a10)
+        if a.atan == "fast" and a.boxcar:
+            amp = min(40.0, 500.0 / a.boxcar)
+        self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=75e3 if a.fs > 2e6 or a.tail == "wbfm" else 5e3,
+                                       amplitude=amp, first_stream=rank * S)
+        self.g = GpuDemod(self.cfg, S, local_rank)
+        self.g.set_path(a.path)
+        cap = self.g.result_cap(NB)
+        self.out = torch.empty((S, cap), dtype=torch.int16, device=dev)
+        self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.local_rank = local_rank
+        # SURVEY §8d: u8 I + u8 Q in, int16 PCM out at 1/D (x the resampling ratio)
+        self.alg_bytes_per_sample = 2.0 + 2.0 / D * self.out_ratio
+
+    def step(self):
+        self.g.run_device(self.iq.data_ptr(), self.iq.stride(0), self.a.blocks, self.out.data_ptr(), self.out.stride(0),
+                          self.out_len.data_ptr())
+
+    def sync(self):
+        self.g.sync()
+
+    def gate(self):
+        from rtlsdr_amd.capi import RtlfmCfg
+        from rtlsdr_amd.demod import GpuDemod
+        a = self.a
+        cs, cb = min(a.streams, 8), min(a.blocks, 2)
+        ccfg = RtlfmCfg.from_buffer_copy(bytes(self.cfg))
+        ccfg.max_blocks = cb
+        sub = self.iq[:cs, :cb * a.block_len].contiguous()
+        with GpuDemod(ccfg, cs, self.local_rank) as gc:
+            gc.set_path(a.path)
+            o, n = gc.run_torch(sub)
+            gc.sync()
+        return (ccfg, sub.cpu().numpy(), o.cpu().numpy(), n.cpu().numpy())
+
+    def cpu_baseline(self, seconds, gate):
+        cs = min(self.a.streams, os.cpu_count() or 1)
+        sample = self.iq[:cs, :min(self.a.blocks, 2) * self.a.block_len].contiguous().cpu().numpy()
+        return cpu_baseline(self.cfg, sample, seconds, gate)
+
+    def describe(self):
+        a, D = self.a, self.D
+        front = f"low_pass boxcar /{D}" if a.boxcar else f"{a.passes}x fifth_order (/{D})" + (" + FIR9" if a.fir9 else "")
+        tail = {"c3": " + deemph + arbitrary_resample 16k -> 22050", "wbfm": " + deemph + low_pass_real 170k -> 32k"}.get(a.tail, "")
+        return (f"rtl_fm -A {a.atan}: {a.streams} streams/GPU x {a.blocks} buffers x {a.block_len} B u8 IQ @{a.fs / 1e6:g} MS/s, "
+                f"{front} + polar discriminant{tail} -> int16 PCM")
+
+    def kernel_name(self):
+        return ("k_boxcar_scan (convert+rotate+low_pass+discriminant)" if self.a.boxcar
+                else "k_fused (convert+rotate+fifth_order[+fir9]+discriminant)")
+
+    def close(self):
+        self.g.close()
+
+
+class PowerJob:
+    """rtl_power's scanner() on S tuning states x NB reads per step (config 4)."""
+
+    def __init__(self, a, dev, local_rank, rank):
+        import torch
+        from rtlsdr_amd import synth
+        from rtlsdr_amd.capi import RtlpowerCfg
+        from rtlsdr_amd.power import GpuPower
+        self.a, self.torch = a, torch
+        self.bin_e = 14
+        L = a.block_len
+        assert L >= (2 << self.bin_e), "config 4 reads hold one 16384-point frame"
+        self.cfg = RtlpowerCfg.default(bin_e=self.bin_e, window=1, buf_len=L)
+        S, NB = a.streams, a.blocks
+        self.samples = S * NB * L // 2
+        self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=50e3, first_stream=rank * S)
+        self.g = GpuPower(self.cfg, S, local_rank)
+        self.local_rank = local_rank
+        # 2 B read per complex sample + the int64 accumulators written back once per launch (SURVEY §8d)
+        self.alg_bytes_per_sample = 2.0 + 8.0 * S * (1 << self.bin_e) / self.samples
+        self.D = 1
+
+    def step(self):
+        self.g.scan_device(self.iq.data_ptr(), self.iq.stride(0), self.a.blocks)
+
+    def sync(self):
+        self.g.sync()
+
+    def gate(self):
+        import numpy as np
+        from rtlsdr_amd.power import GpuPower
+        cs = min(self.a.streams, 4)
+        sub = self.iq[:cs, :2 * self.a.block_len].contiguous()
+        with GpuPower(self.cfg, cs, self.local_rank) as gp:
+            gp.scan_torch(sub)
+            gp.sync()
+            got = [gp.fetch(s) for s in range(cs)]
+        return (sub.cpu().numpy(), np.stack([g[0] for g in got]), np.array([g[1] for g in got], dtype=np.int32))
+
+    def cpu_baseline(self, seconds, gate):
+        cs = min(self.a.streams, os.cpu_count() or 1)
+        sample = self.iq[:cs, :2 * self.a.block_len].contiguous().cpu().numpy()
+        return cpu_baseline_power(self.cfg, sample, seconds, gate)
+
+    def describe(self):
+        a = self.a
+        return (f"rtl_power -w hamming: {a.streams} streams/GPU x {a.blocks} reads x {a.block_len} B u8 IQ @{a.fs / 1e6:g} MS/s, "
+                f"2^{self.bin_e}-bin fix_fft + |X|^2 integrate -> int64 avg[]")
+
+    def kernel_name(self):
+        return "k_power_scan_big<14> (convert+remove_dc+window+fix_fft+integrate)"
+
+    def close(self):
+        self.g.close()
 
 
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
-    import numpy as np
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # Before this process touches the GPU: build (hipcc / gcc children) and the PMC child runs.
+    traffic = None
+    if not a.pmc_child:
+        import __graft_entry__ as ge
+        if rank == 0:
+            ge.build()
+        under_profiler = any("ROCPROF" in k for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not under_profiler)
+        if want_pmc and rank == 0 and world == 1:
+            traffic = pmc_traffic(a)
+
+    import torch
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -229,40 +499,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        dist.barrier()  # rank 0 has built the library
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if dist:
-        dist.barrier()
-    from rtlsdr_amd import synth
-    from rtlsdr_amd.capi import ATAN_FAST, ATAN_LUT, ATAN_STD, RtlfmCfg
-    from rtlsdr_amd.demod import GpuDemod
-
-    atan = {"std": ATAN_STD, "fast": ATAN_FAST, "lut": ATAN_LUT}[a.atan]
-    if a.boxcar:
-        a.passes, a.fir9 = 0, 0
-    D = a.boxcar if a.boxcar else 1 << a.passes
-    fs = 2.4e6
-    cfg = RtlfmCfg.default(downsample=D, downsample_passes=a.passes, comp_fir_size=9 if a.fir9 else 0,
-                           custom_atan=atan, rate_out=int(fs / D), block_len=a.block_len,
-                           max_blocks=a.blocks)
-    S, NB, L = a.streams, a.blocks, a.block_len
-    nsamp = NB * L // 2
-    amp = 40.0 if a.atan == "fast" else 60.0  # -A fast overflows above |z| ~ 724
-    iq = synth.fm_iq_u8_torch(S, nsamp, dev, fs=fs, dev_hz=75e3, amplitude=amp,
-                              first_stream=rank * S)
-    g = GpuDemod(cfg, S, local_rank)
-    g.set_path(a.path)
-    cap = g.result_cap(NB)
-    out = torch.empty((S, cap), dtype=torch.int16, device=dev)
-    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
-
-    def step():
-        g.run_device(iq.data_ptr(), iq.stride(0), NB, out.data_ptr(), out.stride(0), out_len.data_ptr())
+    job = (PowerJob if a.tail == "power" else FmJob)(a, dev, local_rank, rank)
+    step = job.step
 
     def fence():
-        g.sync()
+        job.sync()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -272,31 +515,49 @@ def main():
     # the cpu_baseline leg below compares it with the CPU path's output for the same bytes
     gate = None
     if a.check and rank == 0 and not a.no_cpu_baseline and world == 1:
-        cs, cb = min(S, 8), min(NB, 2)
-        ccfg = RtlfmCfg.from_buffer_copy(bytes(cfg)); ccfg.max_blocks = cb
-        sub = iq[:cs, :cb * L].contiguous()
-        with GpuDemod(ccfg, cs, local_rank) as gc:
-            gc.set_path(a.path)
-            o, n = gc.run_torch(sub); gc.sync()
-        gate = (ccfg, sub.cpu().numpy(), o.cpu().numpy(), n.cpu().numpy())
+        gate = job.gate()
 
     # Untimed: after idle the GPU needs ~50 launches (~50 ms) to reach its steady clock.  If the
     # caller asks for fewer warm-up steps than that, the difference is run first and reported
     # as config.prewarm_steps, so that the K timed steps always measure the steady state.
-    prewarm = max(0, 100 - a.warmup)
+    prewarm = 0 if a.pmc_child else max(0, 100 - a.warmup)
     for _ in range(prewarm + a.warmup):
         step()
     fence()
-    g.timing_enable(True)
-    g.timing_read()
+    job.g.timing_enable(True)
+    job.g.timing_read()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    front_ms, launches = g.timing_read()
-    g.timing_enable(False)
-    path_used = g.last_path
+    front_ms, launches = job.g.timing_read()
+    path_used = getattr(job.g, "last_path", 2)
+
+    # the sustained leg: the same step for >= a.sustain seconds (HIP events per launch, wall clock over all)
+    sustained = None
+    if a.sustain > 0:
+        n_s = max(a.steps, int(a.sustain / max(elapsed / a.steps, 1e-6)) + 1)
+        job.g.timing_read()
+        t1 = time.perf_counter()
+        for _ in range(n_s):
+            step()
+        job.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        s_ms, s_n = job.g.timing_read()
+        sustained = (n_s, dt, s_ms / max(s_n, 1))
+    job.g.timing_enable(False)
+
+    # the in-kernel clock stamps of one more launch, right behind the sustained leg (fused fifth_order path)
+    clock = None
+    if hasattr(job.g, "clock_probe") and not a.pmc_child:
+        job.g.clock_probe(True)
+        for _ in range(3):
+            step()
+        clock = job.g.clock_read()
+        job.g.clock_probe(False)
+
     n_devices, scatter = 1, None
     if dist:
         cdev = dev if dist.get_backend() == "nccl" else "cpu"
@@ -309,14 +570,46 @@ def main():
         dist.all_reduce(seen, op=dist.ReduceOp.MAX)
         n_devices = int(seen.sum().item())
         if a.scatter:
-            scatter = time_scatter(dist, rank, world, dev, S, NB * L)
+            scatter = time_scatter(dist, rank, world, dev, a.streams, a.blocks * a.block_len)
 
     if rank == 0:
-        samples_per_step = world * S * nsamp
-        value = samples_per_step * a.steps / elapsed / 1e6
-        alg_bytes_per_sample = 2.0 + 2.0 / D  # u8 I + u8 Q in, int16 PCM out at 1/D
+        alg_bytes = job.alg_bytes_per_sample * job.samples  # per launch of the dominant kernel
+        value = world * job.samples * a.steps / elapsed / 1e6
         launch_ms = front_ms / max(launches, 1)
-        achieved = alg_bytes_per_sample * S * nsamp / (launch_ms * 1e-3) / 1e9 if launches else None
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9 if launches else None
+        roof = {
+            "bound": "hbm",
+            "achieved": round(achieved, 1) if achieved else None,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+            "traffic": traffic["bytes"] if traffic else None,
+            "kernel": job.kernel_name(),
+            "launch_ms": round(launch_ms, 4),
+            "algorithmic_bytes_per_sample": round(job.alg_bytes_per_sample, 5),
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+        }
+        if traffic:
+            roof["traffic_detail"] = traffic
+            roof["traffic_over_algorithmic"] = round(traffic["bytes"] / alg_bytes, 4)
+        if a.tail in ("c3", "wbfm"):
+            # the whole step (front end + audio tail kernels), wall clock
+            roof["step_frac"] = round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        if a.tail == "power":
+            roof["note"] = ("not HBM-bound: ~250 integer operations per 2-byte sample in LDS-resident radix-2 stages "
+                            "(SURVEY §8d); see DESIGN.md §4.5 for the VALU/LDS ceiling from the PMC passes")
+        if sustained:
+            n_s, dt, s_launch = sustained
+            roof["sustained"] = {
+                "seconds": round(dt, 2), "steps": n_s, "ms_per_step": round(dt / n_s * 1e3, 4),
+                "launch_ms": round(s_launch, 4),
+                "achieved": round(alg_bytes / (s_launch * 1e-3) / 1e9, 1),
+                "frac": round(alg_bytes / (s_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "value": round(world * job.samples * n_s / dt / 1e6, 1),
+            }
+        if clock:
+            roof["shader_mhz"] = round(clock[0], 0)
+            roof["kernel_span_ms"] = round(clock[1], 4)
         res = {
             "metric": "IQ Msamples/s demodulated (whole node)",
             "value": round(value, 1),
@@ -328,43 +621,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int16/int32 fixed point (fp64 atan2)",
+            "dtype": "int16/int32 fixed point (fp64 atan2)" if a.tail != "power" else "int16 fixed point (int64 accumulate)",
             "data": "synthetic",
             "config": {
-                "workload": f"rtl_fm -M fm -s {int(fs / D)} " + ("" if a.boxcar else f"-F {9 if a.fir9 else 0} ")
-                            + f"-A {a.atan}: {S} streams/GPU x {NB} buffers x {L} B u8 IQ @2.4 MS/s, "
-                            + (f"low_pass boxcar /{D}" if a.boxcar else f"{a.passes}x fifth_order (/{D})")
-                            + " + polar discriminant -> int16 PCM",
-                "streams_per_gpu": S, "buffers_per_step": NB, "block_len": L, "passes": a.passes,
+                "workload": f"{a.workload}: " + job.describe(),
+                "streams_per_gpu": a.streams, "buffers_per_step": a.blocks, "block_len": a.block_len, "passes": a.passes,
                 "path": {1: "staged", 2: "fused"}.get(path_used, str(path_used)),
-                "parallelism": f"streams sharded {S}/GPU over {n_devices} GPU(s), {world} rank(s), no data-path collective",
+                "parallelism": f"streams sharded {a.streams}/GPU over {n_devices} GPU(s), {world} rank(s), no data-path collective",
                 "ranks": world,
                 "requested_gpus": int(os.environ.get("RTLFM_BENCH_REQUESTED_GPUS", a.gpus)),
                 "prewarm_steps": prewarm,
+                "device": torch.cuda.get_device_name(local_rank),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1) if achieved else None,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": measured_traffic(f"S{S}_NB{NB}_L{L}_P{a.passes}_F{a.fir9}_{a.atan}"),
-                "kernel": "decimating front end (convert+rotate+fifth_order[+fir9+discriminant])",
-                "launch_ms": round(launch_ms, 4),
-                "algorithmic_bytes_per_sample": alg_bytes_per_sample,
-            },
+            "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
-            cs = min(S, os.cpu_count() or 1)
-            sample = iq[:cs, :min(NB, 2) * L].contiguous().cpu().numpy()
-            res["cpu_baseline"] = cpu_baseline(cfg, sample, a.cpu_seconds, gate)
+            res["cpu_baseline"] = job.cpu_baseline(a.cpu_seconds, gate)
             res["cpu_baseline"]["parity_checked"] = gate is not None
         else:
             res["cpu_baseline"] = None
         if scatter:
             res["scatter"] = scatter
         print(json.dumps(res))
-    g.close()
+    job.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

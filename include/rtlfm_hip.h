@@ -219,6 +219,17 @@ int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on);
 int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches);
 
 /*
+ * In-kernel clock probe of the fused fifth_order front end: with probe(1) every wave of a launch
+ * records the shader clock counter and the 100 MHz real-time counter at its first and last
+ * instruction; read() synchronises and returns the mean shader clock (MHz) the waves of the LAST
+ * launch ran at and the span from the first wave's start to the last wave's end (ms), or -ENODATA.
+ * (The package runs at its power cap on this path: the clock, not the instruction count, is what
+ * moves between boxes and over a run.)
+ */
+int rtlfm_gpu_clock_probe(rtlfm_gpu *h, int on);
+int rtlfm_gpu_clock_read(rtlfm_gpu *h, double *shader_mhz, double *span_ms);
+
+/*
  * Diagnostic: evaluates the kernels' atan2 -> Q14 routine (the arithmetic of
  * polar_discriminant, src/rtl_fm.c:842-849) and the device math library's
  * atan2 chain on n host pairs yx[2k] = y, yx[2k+1] = x.  Either output may be

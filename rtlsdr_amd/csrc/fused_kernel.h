@@ -930,6 +930,7 @@ struct Workspace {
 	uint32_t *mfma_taps[2] = {nullptr, nullptr};  // [rotate]
 	uint8_t *dummy_tile = nullptr;
 	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = automatic (see launch)
+	bool want_stamps = false;                     // rtlfm_gpu_clock_probe(): every wave leaves its clock stamps
 	void release()
 	{
 		if (stamps) hipFree(stamps);
@@ -1026,6 +1027,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	}
 	// enough waves to fill 256 CUs several times over; a segment is a run of whole buffers
 	if (const char *e = getenv("RTLFM_FUSED_DEBUG")) p.debug = atoi(e);
+	if (ws.want_stamps) p.debug |= 2;
 	int target_waves = 8192;
 	if (const char *e = getenv("RTLFM_FUSED_WAVES")) target_waves = atoi(e);
 	int segs = (target_waves + nstreams - 1) / nstreams;

@@ -553,17 +553,24 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				h->deemph_chunks = mc;
 			}
 			const int mcs = mc;
+			const bool dbg_sync = getenv("RTLFM_TAIL_SYNC") != nullptr;
 			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
 			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
 			const size_t per_wave = 64 / lpc;
 			const unsigned ga = (unsigned)(((size_t)S * mcs + per_wave - 1) / per_wave), gc = (unsigned)(((size_t)S * mcs + 63) / 64);
+#define RTLFM_DBG_SYNC(what) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(q); fprintf(stderr, "rtlfm_hip[tail]: %s done (%s)\n", what, hipGetErrorString(e_)); } } while (0)
 #define RTLFM_DEEMPH_SCAN(M)                                                                                        \
 	do {                                                                                                            \
+		RTLFM_DBG_SYNC("before deemph scan");                                                                          \
 		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
+		RTLFM_DBG_SYNC("a1");                                                                                          \
 		k_deemph_scan_a2<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
+		RTLFM_DBG_SYNC("a2");                                                                                          \
 		k_deemph_scan_b<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
 		                                       h->d_deemph_inc, sin, sout);                                         \
+		RTLFM_DBG_SYNC("b");                                                                                           \
 		k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);         \
+		RTLFM_DBG_SYNC("c");                                                                                           \
 	} while (0)
 			if (pow2) RTLFM_DEEMPH_SCAN(2);
 			else if (magic) RTLFM_DEEMPH_SCAN(1);
@@ -724,10 +731,12 @@ static int fused_debug()
 	return e ? atoi(e) : 0;
 }
 
-// diagnostic: shader clock held during the last fused launch (s_memtime vs the 100 MHz s_memrealtime)
-static int report_clock_stamps(rtlfm_gpu *h)
+// shader clock held during the last fused fifth_order launch: every wave stamps s_memtime (shader
+// clock) and s_memrealtime (100 MHz) at its first and last instruction
+static int read_clock_stamps(rtlfm_gpu *h, double *mhz, double *span_ms, int *waves)
 {
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	if (!h->fws.stamps || h->fws.stamp_waves <= 0) return -ENODATA;
 	std::vector<unsigned long long> st((size_t)h->fws.stamp_waves * 4);
 	HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
 	double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
@@ -737,8 +746,32 @@ static int report_clock_stamps(rtlfm_gpu *h)
 		if (st[w * 4 + 2] < t0) t0 = st[w * 4 + 2];
 		if (st[w * 4 + 3] > t1) t1 = st[w * 4 + 3];
 	}
-	fprintf(stderr, "rtlfm_hip[debug]: mean shader clock %.0f MHz over %d waves, kernel span %.3f ms\n", sum / n, n, (t1 - t0) / 1e5);
+	if (!n) return -ENODATA;
+	if (mhz) *mhz = sum / n;
+	if (span_ms) *span_ms = (double)(t1 - t0) / 1e5;
+	if (waves) *waves = n;
 	return 0;
+}
+static int report_clock_stamps(rtlfm_gpu *h)
+{
+	double mhz = 0, span = 0; int n = 0;
+	int r = read_clock_stamps(h, &mhz, &span, &n);
+	if (r < 0) return r == -ENODATA ? 0 : r;
+	fprintf(stderr, "rtlfm_hip[debug]: mean shader clock %.0f MHz over %d waves, kernel span %.3f ms\n", mhz, n, span);
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_clock_probe(rtlfm_gpu *h, int on)
+{
+	if (!h) return -EINVAL;
+	h->fws.want_stamps = on != 0;
+	return 0;
+}
+extern "C" int rtlfm_gpu_clock_read(rtlfm_gpu *h, double *shader_mhz, double *span_ms)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	return read_clock_stamps(h, shader_mhz, span_ms, nullptr);
 }
 
 static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
@@ -1088,6 +1121,7 @@ extern "C" const char *rtlfm_gpu_strerror(int err)
 	case -E2BIG: return "more blocks than cfg.max_blocks";
 	case -ENOBUFS: return "output buffer too small";
 	case -EIO: return "HIP runtime error";
+	case -ENODATA: return "no clock stamps recorded (rtlfm_gpu_clock_probe, fused fifth_order path only)";
 	default: return strerror(-err);
 	}
 }

@@ -129,6 +129,17 @@ class GpuDemod:
     def timing_enable(self, on: bool = True):
         check(self.lib.rtlfm_gpu_timing_enable(self._h, int(on)), "rtlfm_gpu_timing_enable")
 
+    def clock_probe(self, on: bool = True):
+        check(self.lib.rtlfm_gpu_clock_probe(self._h, int(on)), "rtlfm_gpu_clock_probe")
+
+    def clock_read(self):
+        """(mean shader MHz, span ms) of the last fused fifth_order launch, or None."""
+        mhz, span = C.c_double(), C.c_double()
+        r = self.lib.rtlfm_gpu_clock_read(self._h, C.byref(mhz), C.byref(span))
+        if r < 0:
+            return None
+        return mhz.value, span.value
+
     def timing_read(self):
         ms = C.c_double()
         n = C.c_int()
