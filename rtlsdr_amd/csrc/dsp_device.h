@@ -123,13 +123,6 @@ struct AtanNodesConst {
 	__device__ __forceinline__ double operator()(int i) const { return k_atan_nodes[i]; }
 };
 
-__device__ __forceinline__ double fma3(double a, double b, double c)
-{
-	double r;
-	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-	return r;
-}
-
 template <class Nodes>
 __device__ __forceinline__ int atan2_q14(int y, int x, Nodes nodes)
 {
@@ -153,12 +146,10 @@ __device__ __forceinline__ int atan2_q14(int y, int x, Nodes nodes)
 #endif
 	const double t = num * r;
 	const double t2 = t * t;
-	// Horner in the three-address VOP3 form: left to itself hipcc picks v_fmac_f64 (dst == addend)
-	// and pays a v_mov_b64 per step to keep the coefficient registers alive
-	double p = fma3(t2, RTLFM_ATAN_K7, RTLFM_ATAN_K5);
-	p = fma3(t2, p, RTLFM_ATAN_K3);
-	p = fma3(t2, p, RTLFM_ATAN_K);
-	const double w = fma3(t, p, nodes(i));  // K*atan(mn/mx) in [0, 4096.004]
+	double p = __builtin_fma(t2, RTLFM_ATAN_K7, RTLFM_ATAN_K5);
+	p = __builtin_fma(t2, p, RTLFM_ATAN_K3);
+	p = __builtin_fma(t2, p, RTLFM_ATAN_K);
+	const double w = __builtin_fma(t, p, nodes(i));  // K*atan(mn/mx) in [0, 4096.004]
 	const bool swap = ay > ax, neg = x < 0;
 	// x>=0: swap ? H - w : w ;  x<0: swap ? H + w : PIK - w
 	const double base = neg ? (swap ? RTLFM_ATAN_H : RTLFM_ATAN_PIK) : (swap ? RTLFM_ATAN_H : 0.0);

@@ -47,20 +47,33 @@ struct rtlfm_gpu {
 
 	// device memory
 	uint32_t *bufA = nullptr, *bufB = nullptr;
-	int16_t *resA = nullptr, *resB = nullptr;
+	// demodulated samples on their way through the audio tail: [step parity][ping / pong], tstride
+	// int16 per stream.  Two sets, because the tail of step k runs on its own stream while the front
+	// end of step k + 1 already fills the other set.
+	int16_t *res[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+	size_t tstride = 0;
 	int16_t *d_result = nullptr;      // run()/fetch() result, rstride
 	int32_t *d_result_len = nullptr;  // [nstreams]
-	int32_t *d_cnt = nullptr, *d_cnt2 = nullptr;
+	int32_t *d_cnt[2] = {nullptr, nullptr}, *d_cnt2 = nullptr;  // d_cnt: per step parity
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
 	int deemph_chunks = 0;
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
 	size_t deep_stride = 0;
-	state_t *st[2] = {nullptr, nullptr};
+	// Carried state, three copies in rotation: step k reads st[cur] and writes st[(cur + 1) % 3].
+	// The tail of step k (own stream) still reads st[cur] / writes the tail's fields of the next copy
+	// while the front end of step k + 1 reads that copy and writes the third one.
+	state_t *st[3] = {nullptr, nullptr, nullptr};
 	int st_cur = 0;
+	unsigned step = 0;                      // parity selects res[] / d_cnt[] / the events
+	hipStream_t tail_stream = nullptr;
+	hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+	bool tail_pending[2] = {false, false};  // ev_tail[p] has been recorded and not yet waited for
+	bool tail_overlap = true;
 	int32_t *d_lut = nullptr;
 	int32_t *d_mute = nullptr;        // [nstreams*cap_blocks]
-	long long *d_sums = nullptr;      // [nstreams*cap_blocks*2]
+	long long *d_sums = nullptr;      // [nstreams*cap_blocks*2]  dc_block_raw (front end's stream)
+	long long *d_adc_sums = nullptr;  // [nstreams*cap_blocks]    dc_block_audio (the tail's stream)
 	int2 *d_rdc_avg = nullptr;        // [nstreams*cap_blocks]
 	int32_t *d_adc_avg = nullptr;
 	uint8_t *d_in = nullptr;          // push() landing zone
@@ -215,6 +228,14 @@ static void init_states_host(std::vector<state_t> &v)
 
 static int create_body(rtlfm_gpu *h);
 
+// everything the handle has launched: the front end's stream, then the audio tail's
+static hipError_t sync_all(rtlfm_gpu *h)
+{
+	hipError_t e = hipStreamSynchronize(h->stream);
+	if (e != hipSuccess) return e;
+	return h->tail_stream ? hipStreamSynchronize(h->tail_stream) : hipSuccess;
+}
+
 extern "C" int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device, rtlfm_gpu **out)
 {
 	if (!cfg || !out || nstreams < 1) return -EINVAL;
@@ -256,13 +277,27 @@ static int create_body(rtlfm_gpu *h)
 	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
 	h->stream = h->own_stream;
 	const size_t S = (size_t)nstreams;
-	HIP_TRY(hipMalloc(&h->st[0], S * sizeof(state_t)));
-	HIP_TRY(hipMalloc(&h->st[1], S * sizeof(state_t)));
-	HIP_TRY(hipMalloc(&h->d_cnt, S * sizeof(int32_t)));
+	for (int k = 0; k < 3; k++) HIP_TRY(hipMalloc(&h->st[k], S * sizeof(state_t)));
+	for (int k = 0; k < 2; k++) {
+		HIP_TRY(hipMalloc(&h->d_cnt[k], S * sizeof(int32_t)));
+		HIP_TRY(hipEventCreateWithFlags(&h->ev_front[k], hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&h->ev_tail[k], hipEventDisableTiming));
+	}
+	HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+	h->tail_overlap = !getenv("RTLFM_TAIL_SERIAL");
+	{
+		// what mode_demod() can leave per stream and run: the decimated count (+1 per buffer behind a
+		// boxcar that does not divide it); every later stage but the last one only shrinks it
+		const size_t n0 = L / 2;
+		const size_t per = cfg->downsample_passes > 0 ? n0 >> cfg->downsample_passes
+		                                              : (cfg->downsample > 1 ? n0 / cfg->downsample + 1 : n0);
+		h->tstride = ((size_t)h->cap_blocks * per + 64 + 7) & ~(size_t)7;
+	}
 	HIP_TRY(hipMalloc(&h->d_cnt2, S * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_result_len, S * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_mute, S * h->cap_blocks * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_sums, S * h->cap_blocks * 2 * sizeof(long long)));
+	HIP_TRY(hipMalloc(&h->d_adc_sums, S * h->cap_blocks * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_rdc_avg, S * h->cap_blocks * sizeof(int2)));
 	HIP_TRY(hipMalloc(&h->d_adc_avg, S * h->cap_blocks * sizeof(int32_t)));
 	if (cfg->custom_atan == RTLFM_ATAN_LUT) {
@@ -290,9 +325,9 @@ static int ensure_work_buffers(rtlfm_gpu *h)
 static int ensure_res_buffers(rtlfm_gpu *h)
 {
 	const size_t S = (size_t)h->nstreams;
-	if (!h->resA) {
-		HIP_TRY(hipMalloc(&h->resA, S * h->rstride * sizeof(int16_t)));
-		HIP_TRY(hipMalloc(&h->resB, S * h->rstride * sizeof(int16_t)));
+	if (!h->res[0][0]) {
+		for (int p = 0; p < 2; p++)
+			for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc(&h->res[p][k], S * h->tstride * sizeof(int16_t)));
 	}
 	return 0;
 }
@@ -302,17 +337,20 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	if (!h) return -EINVAL;
 	hipSetDevice(h->device);
 	if (h->stream) hipStreamSynchronize(h->stream);
-	for (hipEvent_t e : {h->ev_wait, h->ev_release})
+	if (h->tail_stream) hipStreamSynchronize(h->tail_stream);
+	for (hipEvent_t e : {h->ev_wait, h->ev_release, h->ev_front[0], h->ev_front[1], h->ev_tail[0], h->ev_tail[1]})
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->deepA, h->deepB, h->bufA, h->bufB, h->resA, h->resB, h->d_result, h->d_result_len, h->d_cnt, h->d_cnt2,
-	                h->st[0], h->st[1], h->d_lut, h->d_mute, h->d_sums, h->d_rdc_avg, h->d_adc_avg, h->d_in};
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	                h->d_result, h->d_result_len, h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
+	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg, h->d_in};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	h->fws.release();
 	if (h->h_stage) hipHostFree(h->h_stage);
 	if (h->own_stream) hipStreamDestroy(h->own_stream);
+	if (h->tail_stream) hipStreamDestroy(h->tail_stream);
 	delete h;
 	return 0;
 }
@@ -323,7 +361,7 @@ extern "C" int rtlfm_gpu_reset(rtlfm_gpu *h)
 	HIP_TRY(hipSetDevice(h->device));
 	std::vector<state_t> init((size_t)h->nstreams);
 	init_states_host(init);
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	HIP_TRY(hipMemcpy(h->st[h->st_cur], init.data(), init.size() * sizeof(state_t), hipMemcpyHostToDevice));
 	std::lock_guard<std::mutex> g(h->push_mu);
 	std::fill(h->pushed.begin(), h->pushed.end(), 0);
@@ -334,7 +372,7 @@ extern "C" int rtlfm_gpu_state_get(rtlfm_gpu *h, int stream, rtlfm_stream_state 
 {
 	if (!h || !st || stream < 0 || stream >= h->nstreams) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	HIP_TRY(hipMemcpy(st, h->st[h->st_cur] + stream, sizeof(*st), hipMemcpyDeviceToHost));
 	return 0;
 }
@@ -343,7 +381,7 @@ extern "C" int rtlfm_gpu_state_set(rtlfm_gpu *h, int stream, const rtlfm_stream_
 {
 	if (!h || !st || stream < 0 || stream >= h->nstreams) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	HIP_TRY(hipMemcpy(h->st[h->st_cur] + stream, st, sizeof(*st), hipMemcpyHostToDevice));
 	return 0;
 }
@@ -352,14 +390,14 @@ extern "C" int rtlfm_gpu_sync(rtlfm_gpu *h)
 {
 	if (!h) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	return 0;
 }
 
 extern "C" int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *s)
 {
 	if (!h) return -EINVAL;
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	h->stream = s ? (hipStream_t)s : h->own_stream;
 	return 0;
 }
@@ -385,6 +423,8 @@ extern "C" int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream)
 	if (!h->ev_release) HIP_TRY(hipEventCreateWithFlags(&h->ev_release, hipEventDisableTiming));
 	HIP_TRY(hipEventRecord(h->ev_release, h->stream));
 	HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_release, 0));
+	for (int p = 0; p < 2; p++)  // and for the audio tails still running on their own stream
+		if (h->tail_pending[p]) HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_tail[p], 0));
 	return 0;
 }
 
@@ -412,7 +452,7 @@ extern "C" int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launch
 {
 	if (!h) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	if (h->fws.stamps && (fused_debug() & 16)) {
 		int r2 = report_clock_stamps(h);
 		if (r2 < 0) return r2;
@@ -493,8 +533,8 @@ static void tail_route(rtlfm_gpu *h, const TailPlan &tp, int16_t *final_dst, siz
 		*demod_dst = final_dst;
 		*demod_stride = final_stride;
 	} else {
-		*demod_dst = h->resA;
-		*demod_stride = h->rstride;
+		*demod_dst = h->res[h->step & 1][0];
+		*demod_stride = h->tstride;
 	}
 }
 
@@ -506,15 +546,30 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 {
 	const rtlfm_cfg &c = h->cfg;
 	const int S = h->nstreams;
-	hipStream_t q = h->stream;
+	const int par = (int)(h->step & 1);
 	const state_t *sin = h->st[h->st_cur];
-	state_t *sout = h->st[h->st_cur ^ 1];
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	int remaining_oop = tp.oop();
-	int32_t *cnt = varcnt ? h->d_cnt : nullptr;
+	int32_t *cnt = varcnt ? h->d_cnt[par] : nullptr;
+	// The tail runs behind the front end on a stream of its own, so that the front end of the next
+	// step (a different res[] set, d_cnt[] and state copy, see struct rtlfm_gpu) overlaps it: at
+	// config 3 the tail is a quarter of the step but 3 % of the bytes.  rtlfm_gpu_run_device() makes
+	// the step after next wait for it before it reuses this parity's buffers.
+	hipStream_t q = h->stream;
+	const bool own_stream = tp.any() && h->tail_overlap;
+	if (own_stream) {
+		HIP_TRY(hipEventRecord(h->ev_front[par], h->stream));
+		HIP_TRY(hipStreamWaitEvent(h->tail_stream, h->ev_front[par], 0));
+		q = h->tail_stream;
+	}
+	struct Done {  // whatever path leaves: mark the end of this step's tail
+		rtlfm_gpu *h; int par; bool on;
+		~Done() { if (on && hipEventRecord(h->ev_tail[par], h->tail_stream) == hipSuccess) h->tail_pending[par] = true; }
+	} done{h, par, own_stream};
 	auto next_dst = [&](int16_t **d, size_t *ds) {
 		remaining_oop--;
 		if (remaining_oop == 0) { *d = final_dst; *ds = final_stride; }
-		else { *d = (cur == h->resA) ? h->resB : h->resA; *ds = h->rstride; }
+		else { *d = (cur == h->res[par][0]) ? h->res[par][1] : h->res[par][0]; *ds = h->tstride; }
 	};
 	if (tp.post) {
 		// low_pass_simple: "length must be multiple of step" (src/rtl_fm.c:740) — validate_cfg only
@@ -581,8 +636,8 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 	}
 	if (tp.adc) {
-		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, sin, h->d_sums);
-		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, Nblk, D, nblocks, S, c.adc_block_const, sin,
+		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, sin, h->d_adc_sums);
+		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_adc_sums, Nblk, D, nblocks, S, c.adc_block_const, sin,
 		                                           sout, h->d_adc_avg);
 		k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, S, T, sin,
 		                                                  h->d_adc_avg);
@@ -621,7 +676,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	if (cur != final_dst) return -EFAULT;  // routing bug
 	if (d_out_len) {
 		if (varcnt)
-			HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+			HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt[par], S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
 		else
 			k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, T);
 	}
@@ -639,7 +694,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	int r = ensure_work_buffers(h);
 	if (r < 0) return r;
 	const state_t *sin = h->st[h->st_cur];
-	state_t *sout = h->st[h->st_cur ^ 1];
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	std::pair<hipEvent_t, hipEvent_t> ev;
 
 	r = timing_begin(h, ev);
@@ -681,7 +736,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 		int Tin = nblocks * N0;
 		int maxout = Tin / D + 1;
 		k_boxcar<<<grid_for((size_t)S * (maxout + 1)), 256, 0, q>>>(cur, oth, h->xstride, Tin, S, D, sin, sout,
-		                                                          h->d_cnt);
+		                                                          h->d_cnt[h->step & 1]);
 		std::swap(cur, oth);
 		varcnt = (N0 % D) != 0;
 		T = varcnt ? maxout : Tin / D;
@@ -704,7 +759,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	}
 	int16_t *dd; size_t dds;
 	tail_route(h, tp, d_out, out_stride, &dd, &dds);
-	const int32_t *cnt = varcnt ? h->d_cnt : nullptr;
+	const int32_t *cnt = varcnt ? h->d_cnt[h->step & 1] : nullptr;
 	if (c.mode == RTLFM_MODE_FM)
 		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, dd, dds, T, S, Nblk, D,
 		                                                 c.custom_atan, h->d_lut, cnt, sin, sout);
@@ -714,7 +769,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	if (c.mode == RTLFM_MODE_RAW) {
 		if (d_out_len) {
 			if (varcnt) {
-				HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+				HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt[h->step & 1], S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
 				k_scale_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2, 1);
 			} else {
 				k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T);
@@ -735,7 +790,7 @@ static int fused_debug()
 // clock) and s_memrealtime (100 MHz) at its first and last instruction
 static int read_clock_stamps(rtlfm_gpu *h, double *mhz, double *span_ms, int *waves)
 {
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	if (!h->fws.stamps || h->fws.stamp_waves <= 0) return -ENODATA;
 	std::vector<unsigned long long> st((size_t)h->fws.stamp_waves * 4);
 	HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
@@ -781,7 +836,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	const int S = h->nstreams;
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
-	state_t *sout = h->st[h->st_cur ^ 1];
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
 		int r = ensure_res_buffers(h);
@@ -822,7 +877,7 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	const int level = c.downsample_passes < fused::kMaxP ? c.downsample_passes : fused::kMaxP;
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
-	state_t *sout = h->st[h->st_cur ^ 1];
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	if (!h->deepA) {
 		h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
 		HIP_TRY(hipMalloc(&h->deepA, (size_t)S * h->deep_stride * sizeof(uint32_t)));
@@ -885,7 +940,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	const int S = h->nstreams;
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
-	state_t *sout = h->st[h->st_cur ^ 1];
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
 		int r = ensure_res_buffers(h);
@@ -896,7 +951,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
-	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt, sin, sout, q);
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt[h->step & 1], sin, sout, q);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -922,11 +977,20 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	const bool can_box = boxfused::supported(h->cfg);
 	const bool can_deep = fused::supported_emit(h->cfg);
 	int r;
+	{
+		// this step reuses the res[] / d_cnt[] set and the state copy the step before last handed to
+		// its audio tail
+		const int par = (int)(h->step & 1);
+		if (h->tail_pending[par]) {
+			HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_tail[par], 0));
+			h->tail_pending[par] = false;
+		}
+	}
 	if (h->path == 2 && !can_fuse && !can_box && !can_deep) return -ENOTSUP;
 	// state is double-buffered: kernels read st[cur], write st[cur^1].  The staged kernels each
 	// update their own fields, so the record is copied first; the fused kernels copy it themselves.
 	if (!(h->path != 1 && (can_fuse || can_box || can_deep)))
-		HIP_TRY(hipMemcpyAsync(h->st[h->st_cur ^ 1], h->st[h->st_cur], S * sizeof(state_t),
+		HIP_TRY(hipMemcpyAsync(h->st[(h->st_cur + 1) % 3], h->st[h->st_cur], S * sizeof(state_t),
 		                       hipMemcpyDeviceToDevice, h->stream));
 	if (h->path != 1 && can_box) {
 		r = run_boxfused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
@@ -943,7 +1007,8 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	}
 	if (r < 0) return r;
 	HIP_TRY(hipGetLastError());
-	h->st_cur ^= 1;
+	h->st_cur = (h->st_cur + 1) % 3;
+	h->step++;
 	return 0;
 }
 
@@ -998,7 +1063,7 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 			HIP_TRY(hipMemcpy2DAsync(h->d_in, stride, h->h_stage, stride, (size_t)nb * h->cfg.block_len,
 			                         h->nstreams, hipMemcpyHostToDevice, h->stream));
 		}
-		HIP_TRY(hipStreamSynchronize(h->stream));
+		HIP_TRY(sync_all(h));
 		std::fill(h->pushed.begin(), h->pushed.end(), 0);
 	}
 	h->last_run_blocks = nb;
@@ -1010,7 +1075,7 @@ extern "C" int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, 
 	if (!h || !out || !n || stream < 0 || stream >= h->nstreams) return -EINVAL;
 	if (!h->d_result) return -EAGAIN;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(sync_all(h));
 	int32_t len = 0;
 	HIP_TRY(hipMemcpy(&len, h->d_result_len + stream, sizeof(len), hipMemcpyDeviceToHost));
 	*n = len;
