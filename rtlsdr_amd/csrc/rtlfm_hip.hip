@@ -661,12 +661,13 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		const int l2lo = (int)((long long)nlo * c.rate_out2 / c.rate_out);
 		const int l2hi = (int)((long long)nhi * c.rate_out2 / c.rate_out);
 		const bool any_up = nlo < l2lo || nhi < l2hi, any_down = !(nlo < l2lo) || !(nhi < l2hi);
+		const ArbPlan ap{Nblk, D, nlo, l2lo, (int)((long long)(nlo + 1) * c.rate_out2 / c.rate_out)};
 		if (any_up)
 			k_arb_upsample<<<grid_for((size_t)S * nblocks * l2hi), 256, 0, q>>>(
-			    cur, cur_stride, d, ds, Nblk, D, c.rate_out, c.rate_out2, l2hi, nblocks, S, sin, h->d_cnt2);
+			    cur, cur_stride, d, ds, ap, l2hi, nblocks, S, sin, h->d_cnt2);
 		if (any_down)
 			k_arb_downsample<<<grid_for((size_t)S * nblocks, 64), 64, 0, q>>>(
-			    cur, cur_stride, d, ds, Nblk, D, c.rate_out, c.rate_out2, nblocks, S, sin, h->d_cnt2);
+			    cur, cur_stride, d, ds, ap, nblocks, S, sin, h->d_cnt2);
 		cur = d; cur_stride = ds;
 		if (cur != final_dst) return -EFAULT;  // routing bug
 		if (d_out_len)

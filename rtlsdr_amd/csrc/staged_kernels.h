@@ -828,6 +828,10 @@ __device__ __forceinline__ long long floor_div_pos(long long a, int b)
 	return q;
 }
 
+// One thread per output m: the number of inputs consumed when output m - 1 left costs one division;
+// from there the thread walks the reference's own phase accumulator (prev_lpr_index += slow, emit
+// when it reaches fast) until its output leaves - or the inputs run out, which makes it the thread
+// that keeps the state.  Neighbouring threads read neighbouring inputs.
 __global__ void __launch_bounds__(256)
 k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
                 int T, const int32_t *__restrict__ n_in, int nstreams, int fast, int slow,
@@ -853,25 +857,28 @@ k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restri
 		// p0 < fast and n * slow < 2^31 * 2^20: everything below stays under 2^52 for any run the
 		// library accepts (p0 comes from the carried state: outside [0, fast) only if injected)
 		const bool fits = p0 >= 0 && p0 < fast;
-		const int E = fits ? (int)floor_div_pos(p0 + (long long)n * slow, fast) : (int)((p0 + (long long)n * slow) / fast);
+		long long k = 0;  // inputs consumed once output m - 1 is out
+		if (m > 0) {
+			const long long need = (long long)m * fast - p0;
+			k = fits ? floor_div_pos(need + slow - 1, slow) : (need + slow - 1) / slow;
+			if (k > n) continue;  // output m - 1 does not exist
+		}
+		long long ph = p0 + k * slow - (long long)m * fast;  // the accumulator's phase before input k
+		uint32_t acc = m == 0 ? (uint32_t)sin[s].now_lpr : 0u;
 		const int16_t *a = A + s * astride;
-		// first input index NOT yet consumed by outputs 0..m-1
-		auto end_of = [&](int mm) -> long long {  // inputs consumed once output mm is out
-			long long need = ((long long)mm + 1) * fast - p0;
-			return fits ? floor_div_pos(need + slow - 1, slow) : (need + slow - 1) / slow;
-		};
-		if (m < E) {
-			long long lo = m == 0 ? 0 : end_of(m - 1), hi = end_of(m);
-			uint32_t acc = m == 0 ? (uint32_t)sin[s].now_lpr : 0u;
-			for (long long k = lo; k < hi; k++) acc += (uint32_t)(int)a[k];
+		bool out = false;
+		while (k < n) {
+			acc += (uint32_t)(int)a[k++];
+			ph += slow;
+			if (ph >= fast) { out = true; break; }
+		}
+		if (out) {
 			B[s * bstride + m] = (int16_t)((int)acc / div);
-		} else if (m == E) {
-			long long lo = E == 0 ? 0 : end_of(E - 1);
-			uint32_t acc = E == 0 ? (uint32_t)sin[s].now_lpr : 0u;
-			for (long long k = lo; k < n; k++) acc += (uint32_t)(int)a[k];
+		} else {
+			// the inputs ran out before output m: it is what stays in the accumulator
 			sout[s].now_lpr = (int)acc;
-			sout[s].prev_lpr_index = (int)(p0 + (long long)n * slow - (long long)E * fast);
-			cnt_out[s] = E;
+			sout[s].prev_lpr_index = (int)ph;
+			cnt_out[s] = m;
 		}
 	}
 }
@@ -882,17 +889,19 @@ k_low_pass_real(const int16_t *__restrict__ A, size_t astride, int16_t *__restri
 // values nlo = N / D and nlo + 1, so the start of buffer b's output in the concatenated result is
 // b * len2(nlo) + (#long buffers before b) * (len2(nlo + 1) - len2(nlo)).
 struct ArbExtent { int in0, len1, out0, len2; };
-__device__ __forceinline__ ArbExtent arb_extent(int b, int N, int D, int p0, int rate_out, int rate_out2)
+struct ArbPlan { int N, D, nlo, l2lo, l2hi; };  // nlo = N / D, l2lo = len2(nlo), l2hi = len2(nlo + 1): from the host
+__device__ __forceinline__ ArbExtent arb_extent(int b, const ArbPlan &a, int p0)
 {
 	ArbExtent e;
-	e.in0 = dec_block_begin(b, N, D, p0);
-	e.len1 = dec_block_begin(b + 1, N, D, p0) - e.in0;
-	const int nlo = N / D;
-	const int l2lo = (int)((long long)nlo * rate_out2 / rate_out);
-	const int l2hi = (int)((long long)(nlo + 1) * rate_out2 / rate_out);
-	const int nlong = e.in0 - b * nlo;
-	e.out0 = b * l2lo + nlong * (l2hi - l2lo);
-	e.len2 = e.len1 == nlo ? l2lo : l2hi;
+	if (a.D == 1) {  // uniform count: no boxcar phase, no division
+		e.in0 = b * a.N; e.len1 = a.N; e.out0 = b * a.l2lo; e.len2 = a.l2lo;
+		return e;
+	}
+	e.in0 = dec_block_begin(b, a.N, a.D, p0);
+	e.len1 = dec_block_begin(b + 1, a.N, a.D, p0) - e.in0;
+	const int nlong = e.in0 - b * a.nlo;
+	e.out0 = b * a.l2lo + nlong * (a.l2hi - a.l2lo);
+	e.len2 = e.len1 == a.nlo ? a.l2lo : a.l2hi;
 	return e;
 }
 
@@ -904,11 +913,11 @@ __device__ __forceinline__ ArbExtent arb_extent(int b, int N, int D, int p0, int
 // (i = len1-1, tick = len2) and is sticky.  len2max = the larger of the two per-buffer lengths.
 __global__ void __launch_bounds__(256)
 k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride,
-               int N, int D, int rate_out, int rate_out2, int len2max, int nblocks, int nstreams,
+               ArbPlan ap, int len2max, int nblocks, int nstreams,
                const state_t *__restrict__ sin, int32_t *__restrict__ cnt_out)
 {
 	const size_t total = (size_t)nstreams * nblocks * len2max;
-	const bool small = (long long)(N / D + 1) * len2max < (1ll << 31) && total < (1ull << 32);
+	const bool small = (long long)(ap.nlo + 1) * len2max < (1ll << 31) && total < (1ull << 32);
 	RTLFM_GRID_STRIDE(g, total) {
 		int j, b;
 		size_t s;
@@ -923,8 +932,8 @@ k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restric
 			b = (int)(sb % nblocks);
 			s = sb / nblocks;
 		}
-		const int p0 = D > 1 ? sin[s].prev_index : 0;
-		const ArbExtent e = arb_extent(b, N, D, p0, rate_out, rate_out2);
+		const int p0 = ap.D > 1 ? sin[s].prev_index : 0;
+		const ArbExtent e = arb_extent(b, ap, p0);
 		if (b == nblocks - 1 && j == 0 && cnt_out) cnt_out[s] = e.out0 + e.len2;
 		if (j >= e.len2 || !(e.len1 < e.len2)) continue;  // len1 >= len2: arbitrary_downsample's buffer
 		const int len1 = e.len1, len2 = e.len2;
@@ -953,15 +962,15 @@ k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restric
 // arbitrary_downsample (src/rtl_fm.c:1137-1166): the double remainder makes it
 // order-dependent, so one lane walks one (stream, block) in order.
 __global__ void k_arb_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B,
-                                 size_t bstride, int N, int D, int rate_out, int rate_out2, int nblocks,
+                                 size_t bstride, ArbPlan ap, int nblocks,
                                  int nstreams, const state_t *__restrict__ sin, int32_t *__restrict__ cnt_out)
 {
 	const size_t total = (size_t)nstreams * nblocks;
 	RTLFM_GRID_STRIDE(g, total) {
 		int b = (int)(g % nblocks);
 		size_t s = g / nblocks;
-		const int p0 = D > 1 ? sin[s].prev_index : 0;
-		const ArbExtent e = arb_extent(b, N, D, p0, rate_out, rate_out2);
+		const int p0 = ap.D > 1 ? sin[s].prev_index : 0;
+		const ArbExtent e = arb_extent(b, ap, p0);
 		if (b == nblocks - 1 && cnt_out) cnt_out[s] = e.out0 + e.len2;
 		if (e.len1 < e.len2) continue;  // arbitrary_upsample's buffer
 		const int len1 = e.len1, len2 = e.len2;
