@@ -1,8 +1,11 @@
 // power_kernels.h — rtl_power's scanner() DSP (reference src/rtl_power.c:642-720)
 // on gfx950.
 //
-// One workgroup of 1024 threads owns one stream (one tuning_state) and walks
-// its reads in order.  Per read, the whole decimated buffer (<= 16384 complex
+// A workgroup of 1024 threads walks a run of reads of one stream (one tuning_state).  The reads
+// of a stream are independent of each other (every stage is stateless per read) and avg[] += /
+// MAX is associative, so a stream's reads are split over `groups` workgroups — with many streams
+// one group each, with the tool's real shape (one stream) enough groups to fill the GPU — and
+// every group adds its int64 sums with one atomic per bin.  Per read, the whole decimated buffer (<= 16384 complex
 // samples, packed int16 I,Q per dword = 64 KiB) lives in LDS next to the
 // 3N/4-entry sine table (<= 24 KiB):
 //   A. sums of I and Q for remove_dc (:581-596; the sum over N/2 values is divided
@@ -49,6 +52,7 @@ struct ScanParams {
 	const uint32_t *tw;      // [N] per-stage twiddles, see make_twiddles() in rtlpower_hip.hip
 	long long *avg;          // [stream][N]
 	int32_t *samples;        // [stream]
+	int groups;              // workgroups per stream: group g takes reads [g, g + 1) * nreads / groups
 };
 
 // FIX_MPY, src/rtl_power.c:263-269
@@ -129,14 +133,16 @@ __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 	__shared__ long long red[2][kThreads / 64];
 	__shared__ int ave[2];
 	const int t = threadIdx.x;
-	const size_t s = blockIdx.x;
+	const size_t s = blockIdx.x / p.groups;
+	const int grp = (int)(blockIdx.x % p.groups);
+	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
 	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
 	const int A = N >= kThreads ? N / kThreads : 1;  // accumulators per thread
 	long long acc[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) acc[k] = 0;
 
-	for (int r = 0; r < p.nreads; r++) {
+	for (int r = r_begin; r < r_end; r++) {
 		const uint8_t *raw = p.iq8 ? p.iq8 + s * p.stride8 + (size_t)r * p.buf_len : nullptr;
 		const int16_t *dec = p.dec ? p.dec + s * p.dec_stream_stride + (size_t)r * p.dec_read_stride : nullptr;
 		// ---- A: remove_dc sums over the elements below len_dec --------------------
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 			}
 		}
 	}
-	if (t == 0) p.samples[s] += p.ds * p.chunks * p.nreads;  // :717
+	if (t == 0) atomicAdd(p.samples + s, p.ds * p.chunks * (r_end - r_begin));  // :717
 }
 
 // The same scan specialised for the large-FFT, undecimated case (BASELINE config 4:
@@ -236,7 +242,10 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	__shared__ long long red[2][kThreads / 64];
 	__shared__ int ave[2];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const size_t s = blockIdx.x;
+	const size_t s = blockIdx.x / p.groups;
+	const int grp = (int)(blockIdx.x % p.groups);
+	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
+	if (r_begin >= r_end) return;
 	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
 	const int j0 = (lane << (E - 6)) | (wave << (E - 10));
 	int w[P];
@@ -251,9 +260,9 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	const uint8_t *base = p.iq8 + s * p.stride8 + 2 * (size_t)j0;
 	uint4 cur[V], nxt[V];
 #pragma unroll
-	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base)[v];
+	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base + (size_t)r_begin * p.buf_len)[v];
 
-	for (int r = 0; r < p.nreads; r++) {
+	for (int r = r_begin; r < r_end; r++) {
 		// ---- A: remove_dc sums (all 2N elements are below len_dec here) ------------
 		int si = 0, sq = 0;
 #pragma unroll
@@ -290,7 +299,7 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 			pts[skew((int)(__brev((unsigned)(j0 + k)) >> (32 - E)))] = pack_iq(vi, vq);
 		}
 		// the next read's bytes travel while this one is transformed
-		if (r + 1 < p.nreads) {
+		if (r + 1 < r_end) {
 #pragma unroll
 			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
 		}
@@ -320,7 +329,7 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 		if (p.peak_hold) atomicMax(p.avg + s * N + bin, acc[a]);
 		else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + bin), (unsigned long long)acc[a]);
 	}
-	if (t == 0) p.samples[s] += p.ds * p.nreads;
+	if (t == 0) atomicAdd(p.samples + s, p.ds * (r_end - r_begin));
 }
 
 // rms_power(), src/rtl_power.c:410-436 (bin_e == 0): one workgroup per stream

@@ -462,9 +462,20 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
 		attr_big = true;
 	}
-	if (big && c.bin_e == 14) hipLaunchKernelGGL(k_power_scan_big<14>, dim3(S), dim3(kThreads), lds, q, p);
-	else if (big) hipLaunchKernelGGL(k_power_scan_big<13>, dim3(S), dim3(kThreads), lds, q, p);
-	else hipLaunchKernelGGL(k_power_scan, dim3(S), dim3(kThreads), lds, q, p);
+	// enough workgroups for the 256 CUs (a large-FFT workgroup fills a CU's LDS, the small ones share):
+	// a stream's reads are split when there are few streams (power_kernels.h)
+	{
+		const int want = 512;
+		int groups = (want + S - 1) / S;
+		if (groups > nreads) groups = nreads;
+		if (groups < 1) groups = 1;
+		if (const char *e = getenv("RTLPOWER_GROUPS")) groups = atoi(e) > 0 ? (atoi(e) < nreads ? atoi(e) : nreads) : groups;
+		p.groups = groups;
+	}
+	const unsigned grid = (unsigned)S * (unsigned)p.groups;
+	if (big && c.bin_e == 14) hipLaunchKernelGGL(k_power_scan_big<14>, dim3(grid), dim3(kThreads), lds, q, p);
+	else if (big) hipLaunchKernelGGL(k_power_scan_big<13>, dim3(grid), dim3(kThreads), lds, q, p);
+	else hipLaunchKernelGGL(k_power_scan, dim3(grid), dim3(kThreads), lds, q, p);
 	HIP_TRY(hipGetLastError());
 	if (h->timing) {
 		HIP_TRY(hipEventRecord(ev.second, q));

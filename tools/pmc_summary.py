@@ -3,7 +3,7 @@
 (largest dispatches only, so the small parity-gate launch is left out)."""
 import csv, glob, os, sys, collections
 root = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "k_fused"
+pat = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("PMC_KERNEL", "k_fused")
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
