@@ -149,17 +149,24 @@ int rtlfm_gpu_create(const rtlfm_cfg *cfg, int nstreams, int device,
 int rtlfm_gpu_destroy(rtlfm_gpu *h);
 
 /*
- * The rtlsdr_read_async callback body: append one buffer of interleaved u8
- * I,Q for `stream`.  `iq` is owned by the caller and may be reused as soon as
- * this returns (the driver resubmits it, src/librtlsdr.c:2705-2707): the bytes
- * are copied into a pinned staging ring.  len must equal cfg.block_len.
- * Safe to call from the thread that runs rtlsdr_read_async, concurrently for
- * different streams.  -ENOSPC when max_blocks are already queued.
+ * The rtlsdr_read_async callback body (rtlsdr_callback, src/rtl_fm.c:1274-1344): append one buffer
+ * of interleaved u8 I,Q for `stream`.  `iq` is owned by the caller and may be reused as soon as
+ * this returns (the driver resubmits it, src/librtlsdr.c:2705-2707): the bytes are copied into a
+ * pinned staging ring.  len is the transfer's actual_length (include/rtl-sdr.h:472): at most
+ * cfg.block_len, a multiple of 512; short buffers are demodulated as the reference would (every
+ * stage sees that buffer's own length).
+ * Callable from the thread that runs rtlsdr_read_async, concurrently for different streams and
+ * concurrently with rtlfm_gpu_run(): the ring has two halves, and a callback never waits for a
+ * transfer or a kernel.  -ENOSPC when max_blocks buffers are already queued for the stream.
  */
 int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint32_t len);
 
-/* full_demod() for every queued block of every stream (all streams must
- * have the same number queued, else -EAGAIN).  Asynchronous. */
+/*
+ * full_demod() for every queued buffer of every stream (all streams must have the same number
+ * queued, else -EAGAIN and nothing changes).  Asynchronous: hands the filled half of the ring to
+ * the GPU (async H2D on a copy stream, kernels behind it) and returns; callbacks go on filling the
+ * other half, the next run's transfer overlaps this run's kernels.  One caller at a time.
+ */
 int rtlfm_gpu_run(rtlfm_gpu *h);
 
 /*
@@ -177,8 +184,13 @@ int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq,
                          size_t out_stride, int32_t *d_out_len);
 
 /* Copy out what the last rtlfm_gpu_run() produced for `stream` (what the
- * reference fwrite()s, src/rtl_fm.c:1400).  Blocks until the run is done. */
+ * reference fwrite()s, src/rtl_fm.c:1400).  Blocks until the run is done; the first fetch after a
+ * run brings every stream's result over in one transfer, the others are host copies.  Results of a
+ * run stay valid until the second run after it. */
 int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n);
+/* The same for all streams at once: stream s gets lens[s] samples at out + s * out_stride (int16
+ * elements; rtlfm_result_cap() * max_blocks is always enough).  One device-to-host transfer. */
+int rtlfm_gpu_fetch_all(rtlfm_gpu *h, int16_t *out, size_t out_stride, int32_t *lens);
 
 int rtlfm_gpu_state_get(rtlfm_gpu *h, int stream, rtlfm_stream_state *st);
 int rtlfm_gpu_state_set(rtlfm_gpu *h, int stream, const rtlfm_stream_state *st);

@@ -75,7 +75,8 @@ struct App {
 void on_buffer(unsigned char *buf, uint32_t len, void *ctx)
 {
 	App *a = static_cast<App *>(ctx);
-	if (len != a->cfg.block_len) return;  // a short tail at end of file cannot form a buffer
+	len -= len % 512;  // actual_length comes in whole USB packets; a file's last bytes may not
+	if (len == 0) return;
 	for (;;) {
 		int r = rtlfm_gpu_push(a->gpu, 0, buf, len);
 		if (r == 0) break;

@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "../../include/rtlfm_hip.h"
@@ -52,8 +55,6 @@ struct rtlfm_gpu {
 	// end of step k + 1 already fills the other set.
 	int16_t *res[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 	size_t tstride = 0;
-	int16_t *d_result = nullptr;      // run()/fetch() result, rstride
-	int32_t *d_result_len = nullptr;  // [nstreams]
 	int32_t *d_cnt[2] = {nullptr, nullptr}, *d_cnt2 = nullptr;  // d_cnt: per step parity
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
@@ -76,11 +77,8 @@ struct rtlfm_gpu {
 	long long *d_adc_sums = nullptr;  // [nstreams*cap_blocks]    dc_block_audio (the tail's stream)
 	int2 *d_rdc_avg = nullptr;        // [nstreams*cap_blocks]
 	int32_t *d_adc_avg = nullptr;
-	uint8_t *d_in = nullptr;          // push() landing zone
-	uint8_t *h_stage = nullptr;       // pinned
-	std::vector<int> pushed;
-	std::mutex push_mu;
-	int last_run_blocks = 0;
+	struct Ingest *ing = nullptr;     // the callback side (push / run / fetch), allocated on first use
+	bool no_deemph_scan = false;      // stream-range views (ragged runs) keep to the sequential filter
 	fused::Workspace fws;
 
 	// timing of the decimating front end
@@ -227,6 +225,8 @@ static void init_states_host(std::vector<state_t> &v)
 }
 
 static int create_body(rtlfm_gpu *h);
+static void ingest_destroy(rtlfm_gpu *h);
+static void ingest_reset(rtlfm_gpu *h);
 
 // everything the handle has launched: the front end's stream, then the audio tail's
 static hipError_t sync_all(rtlfm_gpu *h)
@@ -294,7 +294,6 @@ static int create_body(rtlfm_gpu *h)
 		h->tstride = ((size_t)h->cap_blocks * per + 64 + 7) & ~(size_t)7;
 	}
 	HIP_TRY(hipMalloc(&h->d_cnt2, S * sizeof(int32_t)));
-	HIP_TRY(hipMalloc(&h->d_result_len, S * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_mute, S * h->cap_blocks * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_sums, S * h->cap_blocks * 2 * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_adc_sums, S * h->cap_blocks * sizeof(long long)));
@@ -309,7 +308,6 @@ static int create_body(rtlfm_gpu *h)
 		HIP_TRY(hipMalloc(&h->d_lut, lut.size() * sizeof(int32_t)));
 		HIP_TRY(hipMemcpy(h->d_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
-	h->pushed.assign(S, 0);
 	return rtlfm_gpu_reset(h);
 }
 
@@ -320,6 +318,17 @@ static int ensure_work_buffers(rtlfm_gpu *h)
 		HIP_TRY(hipMalloc(&h->bufA, S * h->xstride * sizeof(uint32_t)));
 		HIP_TRY(hipMalloc(&h->bufB, S * h->xstride * sizeof(uint32_t)));
 	}
+	return 0;
+}
+// the /2^level IQ the fused front end emits for the staged kernels (run_fused_emit)
+static int ensure_deep_buffers(rtlfm_gpu *h)
+{
+	if (h->deepA || !fused::supported_emit(h->cfg)) return 0;
+	const int N0 = (int)(h->cfg.block_len / 2);
+	const int level = h->cfg.downsample_passes < fused::kMaxP ? h->cfg.downsample_passes : fused::kMaxP;
+	h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
+	HIP_TRY(hipMalloc(&h->deepA, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc(&h->deepB, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
 	return 0;
 }
 static int ensure_res_buffers(rtlfm_gpu *h)
@@ -343,12 +352,12 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
-	                h->d_result, h->d_result_len, h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
-	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg, h->d_in};
+	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
+	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	h->fws.release();
-	if (h->h_stage) hipHostFree(h->h_stage);
+	ingest_destroy(h);
 	if (h->own_stream) hipStreamDestroy(h->own_stream);
 	if (h->tail_stream) hipStreamDestroy(h->tail_stream);
 	delete h;
@@ -363,8 +372,7 @@ extern "C" int rtlfm_gpu_reset(rtlfm_gpu *h)
 	init_states_host(init);
 	HIP_TRY(sync_all(h));
 	HIP_TRY(hipMemcpy(h->st[h->st_cur], init.data(), init.size() * sizeof(state_t), hipMemcpyHostToDevice));
-	std::lock_guard<std::mutex> g(h->push_mu);
-	std::fill(h->pushed.begin(), h->pushed.end(), 0);
+	ingest_reset(h);
 	return 0;
 }
 
@@ -593,7 +601,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		const unsigned grid = (unsigned)((S + 63) / 64);
 		// few, long streams: parallel over time (staged_kernels.h, k_deemph_scan_*); the interval
 		// of candidate states must fit a wave (2a + 2 <= kDeemphGap)
-		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap &&
+		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan &&
 		                  !getenv("RTLFM_DEEMPH_SEQUENTIAL");
 		if (scan) {
 			// chunk length: each of the passes A1 and C is one chunk long in time; a chunk must be
@@ -879,10 +887,9 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
-	if (!h->deepA) {
-		h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
-		HIP_TRY(hipMalloc(&h->deepA, (size_t)S * h->deep_stride * sizeof(uint32_t)));
-		HIP_TRY(hipMalloc(&h->deepB, (size_t)S * h->deep_stride * sizeof(uint32_t)));
+	{
+		int r0 = ensure_deep_buffers(h);
+		if (r0 < 0) return r0;
 	}
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
@@ -1014,76 +1021,325 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 }
 
 // --------------------------------------------- callback-side: push / fetch ----
+//
+// What sits behind rtlsdr_read_async's callback (include/rtl-sdr.h:472).  librtlsdr owns the
+// callback's buffer and resubmits it to USB the moment the callback returns
+// (src/librtlsdr.c:2705-2707), so push() copies — into a pinned staging ring of two halves:
+//
+//   callbacks --memcpy--> h_stage[fill]      (shared lock: any number of streams at once, a slot
+//                                             per (stream, buffer), per-stream atomic counters)
+//   rtlfm_gpu_run(): flips `fill` (exclusive lock held only for the count check and the flip),
+//                    then h_stage[f] --async H2D, copy stream--> d_in[f] --kernels--> d_result[f]
+//
+// so callbacks never wait for a transfer or a kernel: while run k's H2D and kernels are in
+// flight the callbacks fill the other half, and run k + 1's H2D overlaps run k's kernels.  A half
+// is handed back to the callbacks when its H2D has completed (event), d_in[f] is overwritten when
+// the kernels that read it are done (event), results are double-buffered likewise: those of a run
+// stay valid until the second run after it.
+//
+// len is the transfer's actual_length and may be short (src/rtl_fm.c:1326-1341 uses len
+// throughout).  Full buffers take the batched path; a run that holds a short buffer goes buffer
+// by buffer, each contiguous range of streams with the same length through a view of the handle
+// configured for that length (the chain's carried state makes this exact, and rare).
+struct Ingest {
+	uint8_t *h_stage[2] = {nullptr, nullptr};   // pinned, [stream][cap_blocks][block_len]
+	uint8_t *d_in[2] = {nullptr, nullptr};
+	std::vector<uint32_t> h_len[2];             // bytes in each slot
+	std::unique_ptr<std::atomic<int>[]> pushed[2];
+	int fill = 0;                               // guarded by mu (shared: read, exclusive: flip)
+	std::shared_mutex mu;
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr};
+	bool h2d_pending[2] = {false, false}, run_pending[2] = {false, false};
+	int16_t *d_result[2] = {nullptr, nullptr};  // ostride int16 per stream
+	int32_t *d_result_len[2] = {nullptr, nullptr};
+	size_t ostride = 0;
+	int last = -1;                              // half of the last run
+	int16_t *h_result = nullptr;                // pinned mirror of the last run's results (per-stream fetch)
+	int32_t *h_result_len = nullptr;
+	bool mirror_valid = false;
+	int16_t *d_tmp = nullptr;                   // ragged runs: one buffer's results before they are appended
+	int32_t *d_tmp_len = nullptr;
+};
 
-static int ensure_push_buffers(rtlfm_gpu *h)
+static std::mutex g_ingest_alloc_mu;
+
+static void ingest_free(Ingest *in)
 {
-	if (h->h_stage) return 0;
-	const size_t bytes = (size_t)h->nstreams * h->cap_blocks * h->cfg.block_len;
+	if (!in) return;
+	if (in->copy_stream) { hipStreamSynchronize(in->copy_stream); hipStreamDestroy(in->copy_stream); }
+	for (int k = 0; k < 2; k++) {
+		if (in->h_stage[k]) hipHostFree(in->h_stage[k]);
+		for (void *p : {(void *)in->d_in[k], (void *)in->d_result[k], (void *)in->d_result_len[k]})
+			if (p) hipFree(p);
+		for (hipEvent_t e : {in->ev_h2d[k], in->ev_run[k]})
+			if (e) hipEventDestroy(e);
+	}
+	if (in->h_result) hipHostFree(in->h_result);
+	if (in->h_result_len) hipHostFree(in->h_result_len);
+	if (in->d_tmp) hipFree(in->d_tmp);
+	if (in->d_tmp_len) hipFree(in->d_tmp_len);
+	delete in;
+}
+
+static int ingest_build(rtlfm_gpu *h, Ingest *in)
+{
+	const size_t S = (size_t)h->nstreams;
+	const size_t bytes = S * h->cap_blocks * h->cfg.block_len;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(hipHostMalloc(&h->h_stage, bytes, hipHostMallocDefault));
-	HIP_TRY(hipMalloc(&h->d_in, bytes));
-	HIP_TRY(hipMalloc(&h->d_result, (size_t)h->nstreams * h->rstride * sizeof(int16_t)));
+	in->ostride = ((size_t)rtlfm_result_cap(&h->cfg) * h->cap_blocks + 16 + 7) & ~(size_t)7;
+	HIP_TRY(hipStreamCreateWithFlags(&in->copy_stream, hipStreamNonBlocking));
+	for (int k = 0; k < 2; k++) {
+		HIP_TRY(hipHostMalloc(&in->h_stage[k], bytes, hipHostMallocDefault));
+		HIP_TRY(hipMalloc(&in->d_in[k], bytes));
+		HIP_TRY(hipMalloc(&in->d_result[k], S * in->ostride * sizeof(int16_t)));
+		HIP_TRY(hipMalloc(&in->d_result_len[k], S * sizeof(int32_t)));
+		HIP_TRY(hipEventCreateWithFlags(&in->ev_h2d[k], hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&in->ev_run[k], hipEventDisableTiming));
+		in->h_len[k].assign(S * h->cap_blocks, 0);
+		in->pushed[k].reset(new std::atomic<int>[S]);
+		for (size_t s = 0; s < S; s++) in->pushed[k][s].store(0);
+	}
 	return 0;
+}
+
+// the ring is built by whoever comes first (callbacks of many streams may arrive at once) and
+// published only when it is complete
+static int ingest_ensure(rtlfm_gpu *h)
+{
+	if (__atomic_load_n(&h->ing, __ATOMIC_ACQUIRE)) return 0;
+	std::lock_guard<std::mutex> g(g_ingest_alloc_mu);
+	if (h->ing) return 0;
+	Ingest *in = new Ingest();
+	int r = ingest_build(h, in);
+	if (r < 0) {
+		ingest_free(in);
+		return r;
+	}
+	__atomic_store_n(&h->ing, in, __ATOMIC_RELEASE);
+	return 0;
+}
+
+static void ingest_destroy(rtlfm_gpu *h)
+{
+	ingest_free(h->ing);
+	h->ing = nullptr;
+}
+
+static void ingest_reset(rtlfm_gpu *h)
+{
+	Ingest *in = h->ing;
+	if (!in) return;
+	std::unique_lock<std::shared_mutex> g(in->mu);
+	for (int k = 0; k < 2; k++)
+		for (int s = 0; s < h->nstreams; s++) in->pushed[k][s].store(0);
+	in->last = -1;
+	in->mirror_valid = false;
 }
 
 extern "C" int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint32_t len)
 {
 	if (!h || !iq || stream < 0 || stream >= h->nstreams) return -EINVAL;
-	if (len != h->cfg.block_len) return -EINVAL;
-	// The copy happens under the lock: rtlfm_gpu_run() on another thread must see
-	// either the whole buffer or none of it.  The caller's buffer goes back to the
-	// USB queue the moment we return (src/librtlsdr.c:2705-2707).
-	std::lock_guard<std::mutex> g(h->push_mu);
-	int r = ensure_push_buffers(h);
+	// actual_length of a bulk transfer: whole 512-byte USB packets, at most the buffer
+	if (len == 0 || len > h->cfg.block_len || len % 512) return -EINVAL;
+	int r = ingest_ensure(h);
 	if (r < 0) return r;
-	if (h->pushed[stream] >= h->cap_blocks) return -ENOSPC;
-	const int slot = h->pushed[stream]++;
-	memcpy(h->h_stage + ((size_t)stream * h->cap_blocks + slot) * len, iq, len);
+	Ingest *in = h->ing;
+	// shared: pushes of different streams run side by side; rtlfm_gpu_run() takes the lock
+	// exclusively only to flip the halves, so it sees every buffer whole or not at all
+	std::shared_lock<std::shared_mutex> g(in->mu);
+	const int f = in->fill;
+	const int slot = in->pushed[f][stream].fetch_add(1, std::memory_order_acq_rel);
+	if (slot >= h->cap_blocks) {
+		in->pushed[f][stream].fetch_sub(1, std::memory_order_acq_rel);
+		return -ENOSPC;
+	}
+	const size_t at = (size_t)stream * h->cap_blocks + slot;
+	memcpy(in->h_stage[f] + at * h->cfg.block_len, iq, len);
+	in->h_len[f][at] = len;
+	return 0;
+}
+
+// results of one buffer (tmp, tmp_len per stream) appended behind what the run has so far
+__global__ void k_append_results(int16_t *dst, size_t dstride, int32_t *dst_len, const int16_t *src, size_t sstride,
+                                 const int32_t *src_len, int s0, int ns, int cap)
+{
+	const int s = s0 + (int)blockIdx.x;
+	if (s >= s0 + ns) return;
+	const int n = src_len[s], at = dst_len[s];
+	for (int k = threadIdx.x; k < n && at + k < cap; k += blockDim.x) dst[s * dstride + at + k] = src[s * sstride + k];
+	__syncthreads();
+	if (threadIdx.x == 0) dst_len[s] = at + n;
+}
+
+// A view of the handle on streams [s0, s0 + ns) with another buffer length: same device buffers,
+// per-stream pointers shifted, everything on the handle's stream (no tail overlap, no timing).
+static rtlfm_gpu make_view(rtlfm_gpu *h, int s0, int ns, uint32_t block_len)
+{
+	rtlfm_gpu v = *h;
+	v.nstreams = ns;
+	v.cfg.block_len = block_len;
+	v.ing = nullptr;
+	v.tail_overlap = false;
+	v.timing = false;
+	v.no_deemph_scan = true;
+	v.ev_pending.clear(); v.ev_free.clear();
+	const size_t cb = (size_t)h->cap_blocks;
+	for (int k = 0; k < 3; k++) v.st[k] = h->st[k] + s0;
+	for (int k = 0; k < 2; k++) {
+		v.d_cnt[k] = h->d_cnt[k] + s0;
+		for (int j = 0; j < 2; j++) v.res[k][j] = h->res[k][j] ? h->res[k][j] + (size_t)s0 * h->tstride : nullptr;
+	}
+	v.d_cnt2 = h->d_cnt2 + s0;
+	v.d_mute = h->d_mute + s0 * cb;
+	v.d_sums = h->d_sums + s0 * cb * 2;
+	v.d_adc_sums = h->d_adc_sums + s0 * cb;
+	v.d_rdc_avg = h->d_rdc_avg + s0 * cb;
+	v.d_adc_avg = h->d_adc_avg + s0 * cb;
+	if (h->bufA) { v.bufA = h->bufA + (size_t)s0 * h->xstride; v.bufB = h->bufB + (size_t)s0 * h->xstride; }
+	if (h->deepA) { v.deepA = h->deepA + (size_t)s0 * h->deep_stride; v.deepB = h->deepB + (size_t)s0 * h->deep_stride; }
+	return v;
+}
+
+// a run that holds short buffers: buffer by buffer, ranges of streams with equal length
+static int run_ragged(rtlfm_gpu *h, Ingest *in, int f, int nb)
+{
+	const int S = h->nstreams;
+	const size_t stride = (size_t)h->cap_blocks * h->cfg.block_len;
+	int r;
+	// views must not allocate: everything any path may need exists before the first one is made
+	if ((r = ensure_work_buffers(h)) < 0 || (r = ensure_res_buffers(h)) < 0 || (r = ensure_deep_buffers(h)) < 0) return r;
+	if (fused::ensure_dummy_tile(h->fws)) return -ENOMEM;
+	if (!in->d_tmp) {
+		HIP_TRY(hipMalloc(&in->d_tmp, (size_t)S * in->ostride * sizeof(int16_t)));
+		HIP_TRY(hipMalloc(&in->d_tmp_len, (size_t)S * sizeof(int32_t)));
+	}
+	HIP_TRY(hipMemsetAsync(in->d_result_len[f], 0, (size_t)S * sizeof(int32_t), h->stream));
+	for (int j = 0; j < nb; j++) {
+		// every range of this buffer reads st[cur] and writes the next copy; the rotation advances once
+		const int cur = h->st_cur;
+		const unsigned step = h->step;
+		for (int s0 = 0; s0 < S;) {
+			const uint32_t len = in->h_len[f][(size_t)s0 * h->cap_blocks + j];
+			int s1 = s0 + 1;
+			while (s1 < S && in->h_len[f][(size_t)s1 * h->cap_blocks + j] == len) s1++;
+			rtlfm_cfg c = h->cfg;
+			c.block_len = len;
+			c.max_blocks = 1;
+			if ((r = validate_cfg(&c)) < 0) return r;
+			rtlfm_gpu v = make_view(h, s0, s1 - s0, len);
+			v.st_cur = cur;
+			v.step = step;
+			r = rtlfm_gpu_run_device(&v, in->d_in[f] + (size_t)s0 * stride + (size_t)j * h->cfg.block_len, stride, 1,
+			                         in->d_tmp + (size_t)s0 * in->ostride, in->ostride, in->d_tmp_len + s0);
+			h->fws = v.fws;  // lazily created tap tables / probe buffers belong to the handle
+			h->last_path = v.last_path;
+			if (r < 0) return r;
+			s0 = s1;
+		}
+		h->st_cur = (cur + 1) % 3;
+		h->step = step + 1;
+		k_append_results<<<S, 256, 0, h->stream>>>(in->d_result[f], in->ostride, in->d_result_len[f], in->d_tmp, in->ostride,
+		                                          in->d_tmp_len, 0, S, (int)in->ostride);
+	}
+	HIP_TRY(hipGetLastError());
 	return 0;
 }
 
 extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 {
 	if (!h) return -EINVAL;
-	int nb;
-	const size_t stride = (size_t)h->cap_blocks * h->cfg.block_len;
+	int r = ingest_ensure(h);
+	if (r < 0) return r;
+	Ingest *in = h->ing;
+	HIP_TRY(hipSetDevice(h->device));
+	const int S = h->nstreams;
+	const uint32_t L = h->cfg.block_len;
+	const size_t stride = (size_t)h->cap_blocks * L;
+	int f, nb;
+	bool ragged = false;
 	{
-		// take the queued buffers: the staging ring is copied to HBM before the lock
-		// is released, so callbacks may refill it while the kernels run
-		std::lock_guard<std::mutex> g(h->push_mu);
-		int r = ensure_push_buffers(h);
-		if (r < 0) return r;
-		nb = h->pushed[0];
-		for (int v : h->pushed)
-			if (v != nb) return -EAGAIN;
-		if (nb == 0) return -EAGAIN;
-		HIP_TRY(hipSetDevice(h->device));
-		if (nb == h->cap_blocks) {
-			HIP_TRY(hipMemcpyAsync(h->d_in, h->h_stage, stride * h->nstreams, hipMemcpyHostToDevice, h->stream));
-		} else {
-			HIP_TRY(hipMemcpy2DAsync(h->d_in, stride, h->h_stage, stride, (size_t)nb * h->cfg.block_len,
-			                         h->nstreams, hipMemcpyHostToDevice, h->stream));
+		// the half the callbacks will fill next must have left for the GPU (its H2D done); waited
+		// for before the lock, so that callbacks are never held up by a transfer
+		const int other_guess = in->fill ^ 1;
+		if (in->h2d_pending[other_guess]) {
+			HIP_TRY(hipEventSynchronize(in->ev_h2d[other_guess]));
+			in->h2d_pending[other_guess] = false;
 		}
-		HIP_TRY(sync_all(h));
-		std::fill(h->pushed.begin(), h->pushed.end(), 0);
+		std::unique_lock<std::shared_mutex> g(in->mu);
+		f = in->fill;
+		nb = in->pushed[f][0].load();
+		for (int s = 1; s < S; s++)
+			if (in->pushed[f][s].load() != nb) return -EAGAIN;
+		if (nb == 0) return -EAGAIN;
+		for (int s = 0; s < S && !ragged; s++)
+			for (int j = 0; j < nb; j++)
+				if (in->h_len[f][(size_t)s * h->cap_blocks + j] != L) { ragged = true; break; }
+		for (int s = 0; s < S; s++) in->pushed[f ^ 1][s].store(0);
+		in->fill = f ^ 1;
 	}
-	h->last_run_blocks = nb;
-	return rtlfm_gpu_run_device(h, h->d_in, stride, nb, h->d_result, h->rstride, h->d_result_len);
+	// d_in[f] is free once the kernels of the run that read it are done
+	if (in->run_pending[f]) {
+		HIP_TRY(hipStreamWaitEvent(in->copy_stream, in->ev_run[f], 0));
+		in->run_pending[f] = false;
+	}
+	if (nb == h->cap_blocks)
+		HIP_TRY(hipMemcpyAsync(in->d_in[f], in->h_stage[f], stride * S, hipMemcpyHostToDevice, in->copy_stream));
+	else
+		HIP_TRY(hipMemcpy2DAsync(in->d_in[f], stride, in->h_stage[f], stride, (size_t)nb * L, S, hipMemcpyHostToDevice,
+		                         in->copy_stream));
+	HIP_TRY(hipEventRecord(in->ev_h2d[f], in->copy_stream));
+	in->h2d_pending[f] = true;
+	HIP_TRY(hipStreamWaitEvent(h->stream, in->ev_h2d[f], 0));
+	if (ragged) r = run_ragged(h, in, f, nb);
+	else r = rtlfm_gpu_run_device(h, in->d_in[f], stride, nb, in->d_result[f], in->ostride, in->d_result_len[f]);
+	if (r < 0) return r;
+	HIP_TRY(hipEventRecord(in->ev_run[f], h->stream));
+	in->run_pending[f] = true;
+	in->last = f;
+	in->mirror_valid = false;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_fetch_all(rtlfm_gpu *h, int16_t *out, size_t out_stride, int32_t *lens)
+{
+	if (!h || !out || !lens) return -EINVAL;
+	Ingest *in = h->ing;
+	if (!in || in->last < 0) return -EAGAIN;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(sync_all(h));
+	const int f = in->last;
+	const int S = h->nstreams;
+	HIP_TRY(hipMemcpy(lens, in->d_result_len[f], (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost));
+	int mx = 0;
+	for (int s = 0; s < S; s++) mx = lens[s] > mx ? lens[s] : mx;
+	if ((size_t)mx > out_stride) return -ENOBUFS;
+	if (mx > 0)
+		HIP_TRY(hipMemcpy2D(out, out_stride * sizeof(int16_t), in->d_result[f], in->ostride * sizeof(int16_t),
+		                    (size_t)mx * sizeof(int16_t), S, hipMemcpyDeviceToHost));
+	return 0;
 }
 
 extern "C" int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n)
 {
 	if (!h || !out || !n || stream < 0 || stream >= h->nstreams) return -EINVAL;
-	if (!h->d_result) return -EAGAIN;
+	Ingest *in = h->ing;
+	if (!in || in->last < 0) return -EAGAIN;
 	HIP_TRY(hipSetDevice(h->device));
-	HIP_TRY(sync_all(h));
-	int32_t len = 0;
-	HIP_TRY(hipMemcpy(&len, h->d_result_len + stream, sizeof(len), hipMemcpyDeviceToHost));
+	if (!in->mirror_valid) {
+		// one transfer for all streams, then every per-stream fetch is a host copy
+		if (!in->h_result) {
+			HIP_TRY(hipHostMalloc(&in->h_result, (size_t)h->nstreams * in->ostride * sizeof(int16_t), hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc(&in->h_result_len, (size_t)h->nstreams * sizeof(int32_t), hipHostMallocDefault));
+		}
+		int r = rtlfm_gpu_fetch_all(h, in->h_result, in->ostride, in->h_result_len);
+		if (r < 0) return r;
+		in->mirror_valid = true;
+	}
+	const int32_t len = in->h_result_len[stream];
 	*n = len;
 	if (len > cap) return -ENOBUFS;
-	if (len > 0)
-		HIP_TRY(hipMemcpy(out, h->d_result + (size_t)stream * h->rstride, (size_t)len * sizeof(int16_t),
-		                  hipMemcpyDeviceToHost));
+	if (len > 0) memcpy(out, in->h_result + (size_t)stream * in->ostride, (size_t)len * sizeof(int16_t));
 	return 0;
 }
 

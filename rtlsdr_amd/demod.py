@@ -66,6 +66,14 @@ class GpuDemod:
         check(self.lib.rtlfm_gpu_fetch(self._h, stream, out.ctypes.data, cap, C.byref(n)), "rtlfm_gpu_fetch")
         return out[:n.value].copy()
 
+    def fetch_all(self):
+        """(out int16 [nstreams, cap], lens int32 [nstreams]) of the last full_demod(): one transfer."""
+        cap = capi.load().rtlfm_result_cap(C.byref(self.cfg)) * max(1, self.cfg.max_blocks) + 16
+        out = np.empty((self.nstreams, cap), dtype=np.int16)
+        lens = np.zeros(self.nstreams, dtype=np.int32)
+        check(self.lib.rtlfm_gpu_fetch_all(self._h, out.ctypes.data, cap, lens.ctypes.data), "rtlfm_gpu_fetch_all")
+        return out, lens
+
     # -- device-resident form ------------------------------------------------
     def result_cap(self, nblocks: int) -> int:
         c = self.lib.rtlfm_result_cap(C.byref(self.cfg)) * nblocks + 16

@@ -723,3 +723,92 @@ def test_boxcar_injected_phase_and_partial_sum(oracle_lib, D, atan):
             for s in range(ns):
                 assert_parity(o[s, :n[s]], want[s, :want_len[s]], cfg, f"D={D} path={path} stream {s}")
                 assert gu.state_dict(g.state_get(s), False) == gu.state_dict(wst[s], False)
+
+
+def _oracle_ragged(oracle_lib, cfg, iq_blocks_per_stream):
+    """The oracle, buffer by buffer, each with its own length (rtlsdr_callback's len is the
+    transfer's actual_length, src/rtl_fm.c:1326-1341)."""
+    lib = oracle_lib.oracle()
+    outs, states = [], []
+    for blocks in iq_blocks_per_stream:
+        st = oracle_lib.new_states(1)[0]
+        scratch = np.zeros(2 * 262144 + 64, dtype=np.int16)
+        parts = []
+        for blk in blocks:
+            blk = np.ascontiguousarray(blk)
+            n = lib.orc_block(C.byref(cfg), C.byref(st), blk, blk.size, scratch)
+            assert n >= 0, n
+            parts.append(scratch[:n].copy())
+        outs.append(np.concatenate(parts) if parts else np.zeros(0, np.int16))
+        states.append(st)
+    return outs, states
+
+
+@pytest.mark.parametrize("name", ["c2_p4_std", "c1_boxcar10_fast", "wbfm_preset", "c3_p6_fir9_deemph_up22050",
+                                  "box42_dc", "p4_squelch", "raw_p2", "am_p4"])
+def test_short_callback_buffers(oracle_lib, name):
+    """push() takes the callback's actual_length: short buffers (whole 512-byte packets) anywhere in
+    any stream, demodulated as the reference does — each stage on that buffer's own length."""
+    from rtlsdr_amd.demod import GpuDemod
+    ov, sig = [(o, s) for n, o, s in CASES if n == name][0]
+    L, nb, ns, depth = 16384, 6, 5, 3
+    cfg = make_cfg(ov, L, depth)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=2718, **sig)
+    lens = np.full((ns, nb), L, dtype=np.int64)
+    # whole runs of full buffers, a short one in one stream, several in the same buffer, a whole short column
+    lens[1, 1] = 8192
+    lens[2, 3] = 512 * int(rng.integers(1, 32)); lens[3, 3] = lens[2, 3]; lens[4, 3] = 1024
+    lens[:, 5] = 4096
+    blocks = [[iq[s, b * L:b * L + lens[s, b]] for b in range(nb)] for s in range(ns)]
+    want, wst = _oracle_ragged(oracle_lib, cfg, blocks)
+    got = [[] for _ in range(ns)]
+    with GpuDemod(cfg, ns, 0) as g:
+        for b0 in range(0, nb, depth):
+            for b in range(b0, b0 + depth):
+                for s in range(ns):
+                    g.rtlsdr_callback(blocks[s][b], s)
+            g.full_demod()
+            o, n = g.fetch_all()
+            for s in range(ns):
+                got[s].append(o[s, :n[s]].copy())
+        sts = [g.state_get(s) for s in range(ns)]
+    for s in range(ns):
+        assert_parity(np.concatenate(got[s]), want[s], cfg, f"{name} stream {s}")
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (name, s)
+
+
+def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
+    """The staging ring has two halves: callbacks keep pushing (from several threads) while the
+    previous run's transfer and kernels are in flight, results are fetched one run late, nothing is
+    lost or reordered."""
+    from concurrent.futures import ThreadPoolExecutor
+    from rtlsdr_amd.demod import GpuDemod
+    ov, sig = [(o, s) for n, o, s in CASES if n == "c3_p6_fir9_deemph"][0]
+    L, ns, depth, runs = 32768, 48, 2, 7
+    nb = depth * runs
+    cfg = make_cfg(ov, L, depth)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=99, **sig)
+    want, want_len, wst = oracle_lib.run_batch(make_cfg(ov, L, nb), iq, nthreads=4)
+    got = [[] for _ in range(ns)]
+
+    def push_run(g, k):
+        def one(s):
+            for b in range(k * depth, (k + 1) * depth):
+                g.rtlsdr_callback(iq[s, b * L:(b + 1) * L], s)
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            list(pool.map(one, range(ns)))
+
+    with GpuDemod(cfg, ns, 0) as g:
+        push_run(g, 0)
+        for k in range(runs):
+            g.full_demod()             # asynchronous: run k is in flight ...
+            if k + 1 < runs:
+                push_run(g, k + 1)     # ... while the callbacks fill the other half
+            o, n = g.fetch_all()       # run k's results
+            for s in range(ns):
+                got[s].append(o[s, :n[s]].copy())
+        sts = [g.state_get(s) for s in range(ns)]
+    for s in range(ns):
+        assert_parity(np.concatenate(got[s]), want[s, :want_len[s]], cfg, f"stream {s}")
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
