@@ -30,6 +30,7 @@ Besides the contract fields the line carries
                        (FETCH_SIZE, WRITE_SIZE; separate runs, no tracing) made by this very
                        invocation on this box before the timed run (N = 1; --pmc 0 skips them)
   roofline.shader_mhz  mean shader clock of the waves of a launch, stamped in the kernel
+  e2e                  host buffers through rtlfm_gpu_push / _run / _fetch_all (PCIe-inclusive; never `value`)
   cpu_baseline         the reference's own code (oracle/_ref) or the oracle port on the host cores
 """
 from __future__ import annotations
@@ -81,6 +82,7 @@ def parse():
     ap.add_argument("--check", type=int, default=1, help="have the cpu_baseline leg compare a slice of the GPU output with the CPU path")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the sustained leg after the K timed steps (0: skip)")
     ap.add_argument("--pmc", type=int, default=-1, help="rocprofv3 PMC passes for roofline.traffic: 1 on, 0 off, -1 on for N = 1 when rocprofv3 exists")
+    ap.add_argument("--e2e", type=int, default=1, help="1: also time the PCIe-inclusive push / run / fetch path (N = 1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scatter", action="store_true",
                     help="N > 1: also time shard.scatter_streams (root GPU -> its owner GPUs) of one step's IQ over RCCL")
@@ -286,6 +288,68 @@ def cpu_baseline_power(cfg, sample, seconds, gate=None):
                       f"x {reps} reps ({samples / 1e6:.0f} Msamples in {dt:.1f} s)"}
 
 
+def e2e_leg(a, job, local_rank, seconds=3.0):
+    """PCIe-inclusive rate through the callback boundary: host buffers -> rtlfm_gpu_push
+    (memcpy into the pinned ring, 16 pushing threads as 16 dongle threads would) -> rtlfm_gpu_run (async
+    H2D + kernels) -> rtlfm_gpu_fetch_all (one D2H), pipelined: the callbacks of run k + 1 fill the other
+    half of the ring while run k is in flight.  Next to it the box's own pinned H2D rate for the same
+    bytes (the ceiling this path can reach) — never `value`."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    import torch
+    from rtlsdr_amd.capi import RtlfmCfg
+    from rtlsdr_amd.demod import GpuDemod
+    S = min(a.streams, 1024)
+    L = a.block_len
+    cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
+    cfg.max_blocks = 1
+    host = job.iq[:S, :L].contiguous().cpu().numpy()  # pageable, as a driver's transfer buffers are
+    nthreads = 16
+    with GpuDemod(cfg, S, local_rank) as g, ThreadPoolExecutor(max_workers=nthreads) as pool:
+        lib, hnd = g.lib, g._h
+        cap = lib.rtlfm_result_cap(C.byref(cfg)) + 16
+        out = np.empty((S, cap), dtype=np.int16)
+        lens = np.zeros(S, dtype=np.int32)
+
+        def push_range(t):
+            for s in range(t, S, nthreads):
+                r = lib.rtlfm_gpu_push(hnd, s, host[s].ctypes.data, L)
+                assert r == 0, r
+
+        def push_all():
+            list(pool.map(push_range, range(nthreads)))
+
+        push_all(); g.full_demod(); push_all()
+        lib.rtlfm_gpu_fetch_all(hnd, out.ctypes.data, cap, lens.ctypes.data)  # warm: ring, mirrors, clocks
+        runs, t0 = 0, time.perf_counter()
+        while True:
+            g.full_demod()   # run k in flight ...
+            push_all()       # ... callbacks fill the other half
+            r = lib.rtlfm_gpu_fetch_all(hnd, out.ctypes.data, cap, lens.ctypes.data)
+            assert r == 0, r
+            runs += 1
+            if time.perf_counter() - t0 > seconds and runs >= 3:
+                break
+        dt = time.perf_counter() - t0
+    nbytes = S * L
+    # the ceiling: the same bytes, pinned host -> device, nothing else
+    pin = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=job.iq.device)
+    dst.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = 5 * nbytes / (time.perf_counter() - t1) / 1e9
+    return {"value": round(runs * S * (L // 2) / dt / 1e6, 1), "unit": "Msamples/s",
+            "GB/s_in": round(runs * nbytes / dt / 1e9, 2), "pinned_h2d_GB/s": round(h2d, 1),
+            "what": f"{S} streams x 1 buffer x {L} B per run, {runs} pipelined runs in {dt:.2f} s: {nthreads} threads rtlfm_gpu_push "
+                    f"(pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | rtlfm_gpu_fetch_all; "
+                    f"bounded by the host memcpy into the ring and PCIe, not by the kernels"}
+
+
 def time_scatter(dist, rank, world, dev, streams_per_rank, bytes_per_stream, reps=3):
     """The one optional exchange of the path: all IQ of a step lands on rank 0's
     GPU and every rank receives its contiguous stream range (shard.scatter_streams: isend/recv
@@ -477,7 +541,9 @@ def main():
         if rank == 0:
             ge.build()
         under_profiler = any("ROCPROF" in k for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not under_profiler)
+        # (rocprofv3's counter mode stalls on config 3's queue of small tail kernels at 4096 streams;
+        # the tail workloads take the passes only on request)
+        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not under_profiler and a.tail in ("", "power"))
         if want_pmc and rank == 0 and world == 1:
             traffic = pmc_traffic(a)
 
@@ -558,6 +624,10 @@ def main():
         clock = job.g.clock_read()
         job.g.clock_probe(False)
 
+    e2e = None
+    if a.e2e and rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child:
+        e2e = e2e_leg(a, job, local_rank)
+
     n_devices, scatter = 1, None
     if dist:
         cdev = dev if dist.get_backend() == "nccl" else "cpu"
@@ -635,6 +705,8 @@ def main():
             },
             "roofline": roof,
         }
+        if e2e:
+            res["e2e"] = e2e
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = job.cpu_baseline(a.cpu_seconds, gate)
             res["cpu_baseline"]["parity_checked"] = gate is not None
