@@ -279,6 +279,10 @@ class PowerReference:
     def __init__(self):
         import shutil
         import tempfile
+        # the reference's scanner() calls into librtlsdr: the product's file-backed device layer
+        # (26 rtlsdr_* symbols over a raw IQ file) is what those calls bind to
+        from rtlsdr_amd import build as product_build
+        C.CDLL(product_build.build_shim(), mode=C.RTLD_GLOBAL)
         self._loader = C.CDLL(LOADER_SO)
         self._loader.ref_loader_open.restype = C.c_void_p
         self._loader.ref_loader_open.argtypes = [C.c_char_p]
@@ -291,7 +295,7 @@ class PowerReference:
             raise OSError("cannot open " + REF_POWER_SO)
         self.lib = C.CDLL(self._tmp.name, handle=self._handle)
         self.lib.ref_power_setup.argtypes = [_P(RtlpowerCfg)]
-        self.lib.ref_power_scan.argtypes = [C.c_void_p]
+        self.lib.ref_power_scan_file.argtypes = [C.c_char_p, C.c_int]
         self.lib.ref_power_get.argtypes = [C.c_void_p, _P(C.c_int32)]
         self.lib.ref_window_coefs.restype = _P(C.c_int)
         self.lib.ref_sinewave.restype = _P(C.c_int16)
@@ -312,11 +316,14 @@ class PowerReference:
     def scan_stream(self, cfg: RtlpowerCfg, iq: np.ndarray):
         """All reads of ONE stream; returns (avg int64 [2^bin_e], samples)."""
         self.lib.ref_power_setup(C.byref(cfg))
+        import tempfile
         iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
         L = int(cfg.buf_len)
-        for r in range(iq.size // L):
-            part = np.ascontiguousarray(iq[r * L:(r + 1) * L])
-            self.lib.ref_power_scan(part.ctypes.data)
+        with tempfile.NamedTemporaryFile(prefix="refp_iq_", suffix=".bin") as f:
+            iq[:iq.size // L * L].tofile(f)
+            f.flush()
+            r = self.lib.ref_power_scan_file(f.name.encode(), iq.size // L)
+            assert r == 0, "the reference's scanner() could not open the file-backed device"
         avg = np.zeros(1 << cfg.bin_e, dtype=np.int64)
         n = C.c_int32()
         self.lib.ref_power_get(avg.ctypes.data, C.byref(n))

@@ -1,16 +1,18 @@
 /*
  * ref_rtlpower_harness.c — builds the REAL rtl_power DSP into oracle/_ref/.
  * TEST INFRASTRUCTURE ONLY.  Contains no reference text: it textually includes
- * the reference translation unit from where it lies (REF_RTL_POWER_C).
+ * the reference translation unit from where it lies (REF_RTL_POWER_C) and drives
+ * its own functions — scanner() (src/rtl_power.c:642-720) included.
  *
- * scanner() (src/rtl_power.c:642-720) cannot be called: its first statements go
- * into librtlsdr (rtlsdr_get_center_freq / rtlsdr_read_sync), which this image
- * cannot build and for which no stand-ins are written.  ref_power_scan() below
- * therefore walks the same sequence calling the REFERENCE'S OWN functions
- * (rms_power, downsample_iq/fifth_order, generic_fir, remove_dc, fix_fft,
- * real_conj, sine_table, the window functions) and restates only the inline
- * glue between them, each piece marked with the lines it stands for.
+ * scanner() goes into librtlsdr first (rtlsdr_get_center_freq / rtlsdr_read_sync),
+ * which this image cannot build; no stand-ins are written for it here.  The object
+ * keeps those references undefined (oracle/ref_loader.c opens it RTLD_LAZY) and the
+ * tests load the PRODUCT's file-backed device layer, librtlsdr_file.so (the §8b row
+ * of SURVEY.md, built from rtlsdr_amd/csrc/host/rtlsdr_file.c), into the process
+ * first: scanner() then reads its buffers from a file through the same 26-symbol
+ * API the tools link against.
  */
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -61,59 +63,23 @@ int ref_power_setup(const rtlpower_cfg *c)
 	return 0;
 }
 
-/* One read of tunes[0], following scanner() :657-718 */
-int ref_power_scan(const uint8_t *buf8)
+/* nreads calls of the reference's own scanner() (src/rtl_power.c:642-720).  scanner() begins
+ * with rtlsdr_get_center_freq() / rtlsdr_read_sync(): they bind (lazily) to whatever device layer
+ * the process has loaded — in the tests the product's file-backed librtlsdr_file.so
+ * (SURVEY.md §8b), opened RTLD_GLOBAL before this object, reading the bytes from iq_path.  Nothing
+ * of scanner() is restated here. */
+int ref_power_scan_file(const char *iq_path, int nreads)
 {
 	struct tuning_state *ts = &tunes[0];
-	int j, j2, offset, ds, ds_p;
-	int bin_e = ts->bin_e, bin_len = 1 << bin_e, buf_len = ts->buf_len;
-	int32_t w;
-	memcpy(ts->buf8, buf8, (size_t)buf_len);        /* stands for rtlsdr_read_sync, :657 */
-	if (bin_len == 1) {
-		rms_power(ts);                              /* reference function */
-		return 0;
-	}
-	for (j = 0; j < buf_len; j++)                   /* glue :666-668 */
-		fft_buf[j] = (int16_t)ts->buf8[j] - 127;
-	ds = ts->downsample;
-	ds_p = ts->downsample_passes;
-	if (boxcar && ds > 1) {                         /* glue :671-681 */
-		j = 2, j2 = 0;
-		while (j < buf_len) {
-			fft_buf[j2] += fft_buf[j];
-			fft_buf[j2 + 1] += fft_buf[j + 1];
-			fft_buf[j] = 0;
-			fft_buf[j + 1] = 0;
-			j += 2;
-			if (j % (ds * 2) == 0) j2 += 2;
-		}
-	} else if (ds_p) {
-		for (j = 0; j < ds_p; j++)
-			downsample_iq(fft_buf, buf_len >> j);   /* reference function */
-		if (comp_fir_size == 9 && ds_p <= CIC_TABLE_MAX) {
-			generic_fir(fft_buf, buf_len >> j, cic_9_tables[ds_p]);        /* reference function */
-			generic_fir(fft_buf + 1, (buf_len >> j) - 1, cic_9_tables[ds_p]);
-		}
-	}
-	remove_dc(fft_buf, buf_len / ds);               /* reference function */
-	remove_dc(fft_buf + 1, (buf_len / ds) - 1);
-	for (offset = 0; offset < (buf_len / ds); offset += (2 * bin_len)) {
-		for (j = 0; j < bin_len; j++) {             /* glue :697-706 */
-			w = (int32_t)fft_buf[offset + j * 2];
-			w *= (int32_t)(window_coefs[j]);
-			fft_buf[offset + j * 2] = (int16_t)w;
-			w = (int32_t)fft_buf[offset + j * 2 + 1];
-			w *= (int32_t)(window_coefs[j]);
-			fft_buf[offset + j * 2 + 1] = (int16_t)w;
-		}
-		fix_fft(fft_buf + offset, bin_e);           /* reference function */
-		for (j = 0; j < bin_len; j++) {             /* glue :708-716 over real_conj() */
-			long p = real_conj(fft_buf[offset + j * 2], fft_buf[offset + j * 2 + 1]);
-			if (!peak_hold) ts->avg[j] += p;
-			else ts->avg[j] = MAX(p, ts->avg[j]);
-		}
-		ts->samples += ds;                          /* :717 */
-	}
+	setenv("RTLSDR_FILE", iq_path, 1);
+	if (rtlsdr_open(&dev, 0) < 0 || !dev)
+		return -1;
+	/* the device already sits on the hop's frequency: retune() (:542-552) would drop 4096 bytes */
+	rtlsdr_set_center_freq(dev, (uint32_t)ts->freq);
+	for (int r = 0; r < nreads; r++)
+		scanner();
+	rtlsdr_close(dev);
+	dev = NULL;
 	return 0;
 }
 

@@ -50,6 +50,19 @@ CLI_OUT = os.path.join(HOST, "rtl_fm_hip")
 POWER_CLI_OUT = os.path.join(HOST, "rtl_power_hip")
 
 
+def build_shim(force: bool = False, verbose: bool = False) -> str:
+    """Only the file-backed librtlsdr device layer (plain gcc; no GPU library needed)."""
+    inc = os.path.join(CSRC, "..", "..", "include")
+    shim_src = os.path.join(HOST, "rtlsdr_file.c")
+    deps = [shim_src, os.path.join(inc, "rtlsdr_file.h")]
+    if force or not os.path.exists(SHIM_OUT) or any(os.path.getmtime(x) > os.path.getmtime(SHIM_OUT) for x in deps):
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", SHIM_OUT, shim_src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return SHIM_OUT
+
+
 def build_host(force: bool = False, verbose: bool = False) -> tuple[str, str]:
     """The file-backed librtlsdr device layer (26 rtlsdr_* symbols) and the rtl_fm-shaped
     CLI that sits on it and on librtlfm_hip.so.  Plain gcc/g++."""
