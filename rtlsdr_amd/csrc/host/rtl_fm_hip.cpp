@@ -68,7 +68,8 @@ struct App {
 	FILE *file = nullptr;
 	rtlamd_wave wave{};
 	int verbosity = 0;
-	uint64_t blocks_in = 0, samples_out = 0;
+	int conseq_squelch = 10;
+	uint64_t blocks_in = 0, samples_out = 0, blocks_squelched = 0;
 };
 
 // the rtlsdr_read_async callback (reference rtlsdr_callback, src/rtl_fm.c:1274)
@@ -134,6 +135,18 @@ void demod_thread(App *a)
 			break;
 		}
 		pcm.resize((size_t)n);
+		if (a->cfg.squelch_level) {
+			// demod_thread_fn(), src/rtl_fm.c:1366-1370: while the squelch has been closed for more than
+			// conseq_squelch buffers nothing goes to the output thread, and the counter is held one above
+			// the limit ("hair trigger").  squelch_hits starts at 11 (:1615): silence until it first opens.
+			rtlfm_stream_state st;
+			if (rtlfm_gpu_state_get(a->gpu, 0, &st) == 0 && st.squelch_hits > a->conseq_squelch) {
+				st.squelch_hits = a->conseq_squelch + 1;
+				rtlfm_gpu_state_set(a->gpu, 0, &st);
+				a->blocks_squelched++;
+				continue;
+			}
+		}
 		std::lock_guard<std::mutex> g(a->p.m);
 		a->p.out_q.push_back(std::move(pcm));
 		a->p.cv_out.notify_one();
@@ -174,7 +187,7 @@ void usage()
 	        "\t[-A std/fast/lut choose atan math (default: std)]\n"
 	        "\t[-E enable_option]  edge, dc, rdc, deemp, offset\n"
 	        "\t[-c de-emphasis_time_constant in us: us (75), eu (50) or a number]\n"
-	        "\t[-o oversampling (default: 1)]  [-l squelch_level]  [-q rdc_block_const]\n"
+	        "\t[-o oversampling (default: 1)]  [-l squelch_level]  [-t squelch_delay (default: 10)]  [-q rdc_block_const]\n"
 	        "\t[-W length of one buffer in units of 512 bytes (default: 32 = 16384 B)]\n"
 	        "\t[-H write a wave header with the auxi chunk SDR programs read the frequency from]\n"
 	        "\t[-d device_index] [-g gain] [-p ppm]  accepted and passed to the device layer\n"
@@ -192,11 +205,12 @@ int main(int argc, char **argv)
 	int rate_in = 24000, min_capture = 1000000, time_constant = 75;
 	int fifth = 0, edge = 0, dev_index = 0, gain = -100, ppm = 0;
 	uint32_t freq = 0;
-	bool have_freq = false, write_wav = false;
+	bool have_freq = false, write_wav = false, wb_mode = false;
+	int conseq_squelch = 10;  // demod_init(), src/rtl_fm.c:1613
 	c.rate_out = 24000;
 	c.max_blocks = 8;
 	int opt;
-	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:r:p:E:F:A:M:hm:q:c:W:Hv")) != -1) {
+	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:t:r:p:E:F:A:M:hm:q:c:W:Hv")) != -1) {
 		switch (opt) {
 		case 'd': dev_index = atoi(optarg); break;
 		case 'f': freq = (uint32_t)atofs(optarg); have_freq = true; break;
@@ -204,6 +218,10 @@ int main(int argc, char **argv)
 		case 'p': ppm = (int)atof(optarg); break;
 		case 'm': min_capture = (int)atofs(optarg); break;
 		case 'l': c.squelch_level = (int)atof(optarg); break;
+		case 't':  // src/rtl_fm.c:1774-1781 (a negative value also asks to terminate on squelch: not restated)
+			conseq_squelch = (int)atof(optarg);
+			if (conseq_squelch < 0) conseq_squelch = -conseq_squelch;
+			break;
 		case 's': rate_in = (int)atofs(optarg); c.rate_out = rate_in; break;
 		case 'r': c.rate_out2 = (int)atofs(optarg); break;
 		case 'o': c.post_downsample = (int)atof(optarg); break;
@@ -234,6 +252,7 @@ int main(int argc, char **argv)
 				c.custom_atan = RTLFM_ATAN_FAST;
 				c.deemph = 1;
 				c.squelch_level = 0;
+				wb_mode = true;
 			}
 			break;
 		case 'c':
@@ -253,6 +272,9 @@ int main(int argc, char **argv)
 		}
 	}
 	if (!have_freq) { fprintf(stderr, "Please specify a frequency.\n"); return 1; }
+	if (wb_mode) freq += 16000;  // controller_thread_fn(), src/rtl_fm.c:1455-1460: "wbfm: adding 16000 Hz to every input frequency"
+	a.conseq_squelch = conseq_squelch;
+	if (c.squelch_level) c.max_blocks = 1;  // the squelch rule below is the reference's per-buffer rule
 	rate_in *= c.post_downsample;  // src/rtl_fm.c:1886
 	const char *filename = optind < argc ? argv[optind] : "-";
 
@@ -291,8 +313,8 @@ int main(int argc, char **argv)
 		if (write_wav) rtlamd_wave_finalize(&a.wave, a.file);  // src/rtl_fm.c:2041-2045
 		fclose(a.file);
 	}
-	fprintf(stderr, "%llu buffers in, %llu samples out%s\n", (unsigned long long)a.blocks_in,
-	        (unsigned long long)a.samples_out, a.p.failed ? " (FAILED)" : "");
+	fprintf(stderr, "%llu buffers in, %llu samples out, %llu buffers held back by the squelch%s\n", (unsigned long long)a.blocks_in,
+	        (unsigned long long)a.samples_out, (unsigned long long)a.blocks_squelched, a.p.failed ? " (FAILED)" : "");
 	rtlfm_gpu_destroy(a.gpu);
 	rtlsdr_close(a.dev);
 	return a.p.failed ? 3 : 0;

@@ -35,8 +35,9 @@ def test_cli_output_matches_oracle(oracle_lib, tmp_path, argv, plan, fs):
     rate_in, min_capture, fifth, ov = plan
     cfg = RtlfmCfg.default(**ov)
     cf, cr = C.c_uint32(), C.c_uint32()
-    oracle_lib.oracle().orc_optimal_settings(C.byref(cfg), 100000000, rate_in, min_capture, fifth, 0,
-                                             C.byref(cf), C.byref(cr))
+    # -M wbfm tunes 16 kHz up (controller_thread_fn, src/rtl_fm.c:1455-1460)
+    oracle_lib.oracle().orc_optimal_settings(C.byref(cfg), 100000000 + (16000 if "wbfm" in argv else 0), rate_in, min_capture,
+                                             fifth, 0, C.byref(cf), C.byref(cr))
     if cfg.deemph:
         cfg.deemph_a = oracle_lib.oracle().orc_deemph_a(cfg.rate_out, 75)
     L = int(cfg.block_len)
@@ -97,3 +98,38 @@ def test_rtl_power_cli_matches_oracle(oracle_lib, tmp_path, argv, passes):
         assert lib.rtlpower_csv_dbm(C.byref(plan), i, a.ctypes.data, int(n[0]), buf, len(buf)) > 0
         got = lines[i].split(", ", 2)[2]  # drop "date, time, "
         assert got + "\n" == buf.value.decode(), (i, got[:80], buf.value[:80])
+
+
+def test_cli_squelch_holds_output_back_like_demod_thread_fn(oracle_lib, tmp_path):
+    """-l: rtl_fm's demod thread forwards nothing while squelch_hits > conseq_squelch and clamps the
+    counter (src/rtl_fm.c:1366-1370); squelch_hits starts at 11, so the tool is silent until the
+    squelch first opens.  Capture: silence, signal, silence."""
+    _, cli = hipbuild.build_host()
+    L, nb = 16384, 60
+    cfg = RtlfmCfg.default(rate_out=24000, squelch_level=40)
+    cf, cr = C.c_uint32(), C.c_uint32()
+    oracle_lib.oracle().orc_optimal_settings(C.byref(cfg), 100000000, 24000, 1000000, 0, 0, C.byref(cf), C.byref(cr))
+    sig = synth.fm_iq_u8(1, L // 2 * nb, fs=1.008e6, dev_hz=2.5e3, amplitude=60.0, seed=77)[0].reshape(nb, L)
+    quiet = synth.fm_iq_u8(1, L // 2 * nb, fs=1.008e6, dev_hz=2.5e3, amplitude=0.0, noise_lsb=1, seed=78)[0].reshape(nb, L)
+    iq = np.concatenate([quiet[:8], sig[8:30], quiet[30:]]).ravel()
+    src, out = tmp_path / "capture.bin", tmp_path / "audio.raw"
+    iq.tofile(src)
+    r = subprocess.run([cli, "-f", "100M", "-s", "24k", "-l", "40", "-t", "3", str(out)], env=dict(os.environ, RTLSDR_FILE=str(src)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    got = np.fromfile(out, dtype=np.int16)
+    # the same rule over the oracle's per-buffer outputs
+    lib = oracle_lib.oracle()
+    st = oracle_lib.new_states(1)[0]
+    scratch = np.zeros(L, dtype=np.int16)
+    want, held = [], 0
+    for b in range(nb):
+        n = lib.orc_block(C.byref(cfg), C.byref(st), np.ascontiguousarray(iq[b * L:(b + 1) * L]), L, scratch)
+        if st.squelch_hits > 3:
+            st.squelch_hits = 4
+            held += 1
+            continue
+        want.append(scratch[:n].copy())
+    want = np.concatenate(want)
+    assert 20 < held < nb - 10 and f"{held} buffers held back" in r.stderr
+    assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
