@@ -9,20 +9,8 @@
 // low_pass keeps a running sum (now_r, now_j) and a count prev_index across buffers, so with
 // p0 samples already accumulated at the start of the run, output k covers run samples
 // [k*D - p0, (k+1)*D - p0): boundaries fall anywhere and the number of outputs per tile and
-// per buffer varies.  Per tile:
-//   1. the tile is staged in wave-private LDS as S = raw ^ 0x7f (each byte -(u-127) as int8),
-//      one dword = two complex samples, skewed by one dword per 32 so that lanes reading with
-//      any stride D/2 do not pile up on a bank;
-//   2. lane l takes outputs e = l, l+64, ...: a window is at most D/2+1 dwords, each dword
-//      contributes with two v_dot4_i32_i8 whose +-1 taps carry the (-j)^n rotation (they only
-//      depend on the dword's parity); the two edge dwords are masked to the sample that
-//      belongs to the window.  Output E_t (the window the tile leaves unfinished) is summed
-//      the same way and becomes the carry;
-//   3. the sums go to LDS as packed int16 pairs (the reference's int16 store), each lane reads
-//      its predecessor and runs the discriminator; the first output of a buffer always takes
-//      polar_discriminant (src/rtl_fm.c:935-937);
-//   4. PCM is collected in LDS and stored at the start of the next tile, before that tile's
-//      reload is issued (stores younger than the loads would put their latency into the wait).
+// per buffer varies.  A boxcar is P(hi) - P(lo) of a prefix sum P, so the cost of a tile does
+// not depend on D: see k_boxcar_scan below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cerrno>
@@ -59,202 +47,8 @@ struct Params {
 	int R;                      // k_boxcar_scan: outputs per lane and tile, ceil((4096 / D + 1) / 64)
 };
 
-// LDS layout in dwords
-struct Lds {
-	static constexpr int atan = 0;                       // 17 doubles
-	static constexpr int carry = 34;                     // now_r, now_j
-	static constexpr int tile = 36;                      // 2048 dwords + 1 per 32
-	static constexpr int outs = tile + kTileDwords + 64; // [out_cap + 2] packed (I,Q); entry 0 = previous output
-	__host__ __device__ static int pcm(int out_cap) { return outs + out_cap + 2; }
-	__host__ __device__ static int total(int out_cap) { return pcm(out_cap) + (out_cap + 3) / 2; }
-};
-
-__device__ __forceinline__ int tile_at(int d) { return Lds::tile + d + (d >> 5); }
-
-template <bool STD>
-__global__ void __launch_bounds__(64, 3) k_boxcar_fused(const Params p)
-{
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-	const int lane = threadIdx.x;
-	const int wave = blockIdx.x;
-	const int seg = wave % p.segs;
-	const int s = wave / p.segs;
-	if (s >= p.nstreams) return;
-	const int tpb = (int)(p.block_len / kTileBytes);
-	const int b0 = seg * p.blocks_per_seg;
-	int b1 = b0 + p.blocks_per_seg;
-	if (b1 > p.nblocks) b1 = p.nblocks;
-	if (b0 >= b1) return;
-	const bool from_state = (b0 == 0);
-	const bool writes_state = (b1 == p.nblocks);
-	const state_t *sin = p.sin + s;
-	state_t *sout = p.sout + s;
-	const int D = p.D;
-	const int O0 = Lds::outs, P0 = Lds::pcm(p.out_cap);
-	uint16_t *pcm = reinterpret_cast<uint16_t *>(lds + P0);
-
-	// the state record is double-buffered; the wave that ends the run carries the fields this
-	// kernel does not own over to the new copy (see fused_kernel.h)
-	if (writes_state) {
-		const uint32_t *a = reinterpret_cast<const uint32_t *>(sin);
-		uint32_t *b = reinterpret_cast<uint32_t *>(sout);
-		for (int k = lane; k < (int)(sizeof(state_t) / 4); k += 64) b[k] = a[k];
-	}
-	if (lane < 17) reinterpret_cast<double *>(lds + Lds::atan)[lane] = k_atan_nodes[lane];
-	const int p0 = sin->prev_index;
-	const int gt_first = b0 * tpb;
-	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
-	const int gt_end = b1 * tpb;
-	// samples accumulated when the first processed tile starts, outputs completed before it
-	int ph, kb;
-	{
-		const long long n = (long long)p0 + (long long)gt_begin * kTileSamples;
-		ph = (int)(n % D);
-		kb = (int)(n / D);
-	}
-	if (lane == 0) {
-		lds[Lds::carry] = from_state ? (uint32_t)sin->now_r : 0u;
-		lds[Lds::carry + 1] = from_state ? (uint32_t)sin->now_j : 0u;
-		lds[O0] = from_state ? pack_iq((int16_t)sin->pre_r, (int16_t)sin->pre_j) : 0u;
-	}
-	__builtin_amdgcn_wave_barrier();
-	const fused::AtanNodesLds nodes{reinterpret_cast<const double *>(lds + Lds::atan)};
-
-	// +-1 taps on S = -x for an even / odd dword of a buffer (samples n%4 = 0,1 / 2,3):
-	//   rotated sample n%4: 0:(a,b) 1:(b,-a) 2:(-a,-b) 3:(-b,a); bytes of a dword: a0 b0 a1 b1
-	const int tI_even = p.rotate ? (int)0xFF0000FFu : (int)0x00FF00FFu;  // -(a0 + b1) | -(a0 + a1)
-	const int tQ_even = p.rotate ? (int)0x0001FF00u : (int)0xFF00FF00u;  // -(b0 - a1) | -(b0 + b1)
-	const int tI_odd = p.rotate ? (int)0x01000001u : tI_even;
-	const int tQ_odd = p.rotate ? (int)0x00FF0100u : tQ_even;
-
-	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
-	int16_t *out_base = p.out + (size_t)s * p.out_stride;
-	uint4 cur[8];
-	auto load_from = [&](const uint8_t *tb) {
-#pragma unroll
-		for (int k = 0; k < 8; k++) cur[k] = fused::load_stream16(tb + k * 1024 + lane * 16);
-	};
-	load_from(stream_base + (size_t)gt_begin * kTileBytes);
-
-	int flush_n = 0, flush_kb = 0;  // PCM of the previous tile, waiting in LDS
-	auto flush = [&]() {
-		for (int e = lane; e < flush_n; e += 64) out_base[(size_t)flush_kb + e] = (int16_t)pcm[e];
-	};
-
-	for (int gt = gt_begin; gt < gt_end; gt++) {
-		const bool more = gt + 1 < gt_end;
-		const bool bs = (gt % tpb) == 0;  // this tile starts a buffer
-		const bool emit = gt >= gt_first;
-		// outputs completing in this tile, and the phase it leaves behind
-		const int wrap = (ph + p.r4096 >= D) ? 1 : 0;
-		const int Et = p.q4096 + wrap;
-		const int ph_next = ph + p.r4096 - (wrap ? D : 0);
-
-		// ---- 1. stage S = raw ^ 0x7f7f7f7f: chunk 64k + lane = dwords 4(64k + lane) .. +3
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			const int d = 4 * (64 * k + lane);
-			uint32_t *dst = lds + tile_at(d);  // four dwords of one chunk never straddle a multiple of 32
-			dst[0] = cur[k].x ^ 0x7f7f7f7fu; dst[1] = cur[k].y ^ 0x7f7f7f7fu;
-			dst[2] = cur[k].z ^ 0x7f7f7f7fu; dst[3] = cur[k].w ^ 0x7f7f7f7fu;
-		}
-		__builtin_amdgcn_wave_barrier();
-		flush();  // the previous tile's PCM, before the reload is issued
-		load_from(more ? stream_base + (size_t)(gt + 1) * kTileBytes : p.dummy_tile);  // unconditional (see fused_kernel.h)
-
-		// ---- 2. window sums, outputs e = lane, lane + 64, ...; e == Et is the unfinished window (carry)
-		const int rounds = (Et + 1 + 63) / 64;
-		for (int r = 0; r < rounds; r++) {
-			const int e = r * 64 + lane;
-			const bool active = e <= Et;
-			int lo = e * D - ph, hi = lo + D;
-			if (lo < 0) lo = 0;
-			if (hi > kTileSamples) hi = kTileSamples;
-			int ai = 0, aq = 0;
-			if (active && e == 0) { ai = (int)lds[Lds::carry]; aq = (int)lds[Lds::carry + 1]; }
-			if (active && hi > lo) {
-				const int d0 = lo >> 1, d1 = (hi - 1) >> 1;
-				const bool odd0 = d0 & 1;
-				const int tIa = odd0 ? tI_odd : tI_even, tQa = odd0 ? tQ_odd : tQ_even;  // parity of d0
-				const int tIb = odd0 ? tI_even : tI_odd, tQb = odd0 ? tQ_even : tQ_odd;  // the other one
-				// first dword: drop its first sample if the window starts on the second one
-				uint32_t w = lds[tile_at(d0)];
-				if (lo & 1) w &= 0xFFFF0000u;
-				if (d0 == d1 && !((hi - 1) & 1)) w &= 0x0000FFFFu;
-				ai = __builtin_amdgcn_sdot4((int)w, tIa, ai, false);
-				aq = __builtin_amdgcn_sdot4((int)w, tQa, aq, false);
-				// interior dwords d0 + j, j = 1 .. d1 - d0 - 1 (at most D/2 - 1 of them), two per trip
-				for (int j = 1; j < D / 2; j += 2) {
-					if (d0 + j < d1) {
-						const uint32_t v = lds[tile_at(d0 + j)];
-						ai = __builtin_amdgcn_sdot4((int)v, tIb, ai, false);
-						aq = __builtin_amdgcn_sdot4((int)v, tQb, aq, false);
-					}
-					if (d0 + j + 1 < d1) {
-						const uint32_t v = lds[tile_at(d0 + j + 1)];
-						ai = __builtin_amdgcn_sdot4((int)v, tIa, ai, false);
-						aq = __builtin_amdgcn_sdot4((int)v, tQa, aq, false);
-					}
-				}
-				if (d1 > d0) {
-					// last dword: drop its second sample if the window ends on the first one
-					uint32_t v = lds[tile_at(d1)];
-					if (!((hi - 1) & 1)) v &= 0x0000FFFFu;
-					const bool same = ((d1 - d0) & 1) == 0;
-					ai = __builtin_amdgcn_sdot4((int)v, same ? tIa : tIb, ai, false);
-					aq = __builtin_amdgcn_sdot4((int)v, same ? tQa : tQb, aq, false);
-				}
-			}
-			const uint32_t z = pack_iq((int16_t)ai, (int16_t)aq);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
-			if (active && e < Et) lds[O0 + 1 + e] = z;
-			if (active && e == Et) { lds[Lds::carry] = (uint32_t)ai; lds[Lds::carry + 1] = (uint32_t)aq; }
-		}
-		__builtin_amdgcn_wave_barrier();
-		// ---- 3. discriminator, in a loop of its own: the rounds no longer wait for each other's
-		// LDS store -> load (that dependency, eleven times per tile at /6, was what the kernel cost)
-		for (int r = 0; r < rounds; r++) {
-			const int e = r * 64 + lane;
-			const bool active = e <= Et;
-			if (active && e < Et) {
-				const uint32_t z = lds[O0 + 1 + e];
-				const uint32_t b = lds[O0 + e];  // the previous output (entry 0: the last one of the previous tile)
-				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
-				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
-				const int cr = fused::dot2_first(z, b);
-				const int cj = fused::dot2_first(z, bx);
-				int v;
-				if (!STD && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
-				else if (STD || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
-				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
-				else v = lut_atan2_q14_direct(cj, cr, nodes);
-				pcm[e] = (uint16_t)(int16_t)v;
-			}
-		}
-		__builtin_amdgcn_wave_barrier();
-		// the last complete output becomes entry 0 for the next tile
-		if (lane == 0) lds[O0] = lds[O0 + Et];
-		__builtin_amdgcn_wave_barrier();
-		flush_n = emit ? Et : 0;
-		flush_kb = kb;
-		kb += Et;
-		ph = ph_next;
-	}
-	flush();
-	if (writes_state && lane == 0) {
-		sout->prev_index = ph;
-		sout->now_r = (int)lds[Lds::carry];
-		sout->now_j = (int)lds[Lds::carry + 1];
-		const iq16 w = unpack_iq(lds[O0]);
-		if (STD || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
-		p.cnt[s] = kb;
-	}
-}
-
-// ------------------------------------------------------------------------------------------
-// The same front end with the window sums taken as differences of a prefix sum: a boxcar is
-// P(hi) - P(lo), so the cost of a tile no longer depends on D (the window walk above is O(D/2)
-// LDS gathers and dot products per output and per component, 1619 VALU instructions per tile
-// at /6).  Per 8 KiB tile:
+// Per 8 KiB tile (round 1 walked every window: O(D/2) LDS gathers and dot products per output and
+// per component, 1619 VALU instructions per tile at /6):
 //   1. the coalesced (non-temporal) loads are staged through LDS as S = raw ^ 0x7f and read back
 //      lane-contiguous: lane l owns dwords [32l, 32l + 32) = samples [64l, 64l + 64).  Rows are
 //      36 dwords apart, which makes both the 16-byte stores (eight consecutive lanes fill one row)
@@ -584,19 +378,12 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	segs = (nblocks + bps - 1) / bps;
 	p.segs = segs; p.blocks_per_seg = bps;
 	const int waves = nstreams * segs;
-	static const bool walk = getenv("RTLFM_BOXCAR_WALK") != nullptr;  // the O(D) window walk, for A/B measurements
 	const bool std_fm = c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM;
-	if (walk) {
-		const size_t lds_bytes = (size_t)Lds::total(p.out_cap) * 4;
-		if (std_fm) hipLaunchKernelGGL((k_boxcar_fused<true>), dim3(waves), dim3(64), lds_bytes, q, p);
-		else hipLaunchKernelGGL((k_boxcar_fused<false>), dim3(waves), dim3(64), lds_bytes, q, p);
-	} else {
-		p.has_first = (p.D & 1) ? 1 : 0;
-		p.R = (p.q4096 + 1 + 63) / 64;
-		const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0) * 4;
-		if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<true>), dim3(waves), dim3(64), lds_bytes, q, p);
-		else hipLaunchKernelGGL((k_boxcar_scan<false>), dim3(waves), dim3(64), lds_bytes, q, p);
-	}
+	p.has_first = (p.D & 1) ? 1 : 0;
+	p.R = (p.q4096 + 1 + 63) / 64;
+	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0) * 4;
+	if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<true>), dim3(waves), dim3(64), lds_bytes, q, p);
+	else hipLaunchKernelGGL((k_boxcar_scan<false>), dim3(waves), dim3(64), lds_bytes, q, p);
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 
