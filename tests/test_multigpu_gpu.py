@@ -62,3 +62,35 @@ def test_bench_gpus_2_starts_two_ranks():
     # whole-job value: both ranks' samples over the max-over-ranks time
     per_step = 2 * 32 * 4 * 262144 // 2
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
+
+
+@pytest.mark.parametrize("args", [
+    ["--workload", "c2", "--streams", "16", "--blocks", "4"],
+    ["--workload", "ns4096", "--streams", "64", "--blocks", "1"],
+    ["--workload", "c1", "--streams", "16", "--blocks", "4"],
+    ["--workload", "wbfm", "--streams", "16", "--blocks", "4"],
+    ["--workload", "c3", "--streams", "64", "--blocks", "2"],
+    ["--workload", "c4", "--streams", "8", "--blocks", "4"],
+])
+def test_bench_workloads_emit_the_contract_line(args):
+    """Every BASELINE-shaped workload of bench.py at a small size: one JSON line with the contract's
+    fields, a roofline object incl. the sustained leg, a cpu_baseline with its parity gate passed."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--pmc", "0", "--sustain", "0.2",
+           "--cpu-seconds", "0.5"] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["vs_baseline"] is None
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and 0 < ro["frac"] < 1 and ro["sustained"]["steps"] >= 4
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert d["cpu_baseline"]["parity_checked"] is True and d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert args[1] in d["config"]["workload"]
+    if args[1] != "c4":
+        assert d["e2e"]["value"] > 0
