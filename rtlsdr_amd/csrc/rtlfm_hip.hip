@@ -58,6 +58,7 @@ struct rtlfm_gpu {
 	int32_t *d_cnt[2] = {nullptr, nullptr}, *d_cnt2 = nullptr;  // d_cnt: per step parity
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
+	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
 	int deemph_chunks = 0;
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
 	size_t deep_stride = 0;
@@ -351,7 +352,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -590,6 +591,8 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		cur = d; cur_stride = ds; T = Tout;
 		Nblk = T / nblocks; D = 1;
 	}
+	bool fuse_lpr = false;
+	int16_t *lpr_dst = nullptr; size_t lpr_ds = 0;
 	if (tp.deemph) {
 		DeemphStep st;
 		st.a = (uint32_t)c.deemph_a; st.half = (uint32_t)(c.deemph_a / 2);
@@ -609,14 +612,19 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const int L = T >= 8192 ? 1024 : 512;
 			const int mc = T / L + 2;
 			if ((size_t)mc > (size_t)h->deemph_chunks) {
-				if (h->d_deemph_tab) { HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); }
-				h->d_deemph_tab = nullptr; h->d_deemph_inc = nullptr;
+				if (h->d_deemph_tab) { HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); HIP_TRY(hipFree(h->d_lpr_chunks)); }
+				h->d_deemph_tab = nullptr; h->d_deemph_inc = nullptr; h->d_lpr_chunks = nullptr;
 				HIP_TRY(hipMalloc(&h->d_deemph_tab, (size_t)S * mc * sizeof(DeemphChunk)));
 				HIP_TRY(hipMalloc(&h->d_deemph_inc, (size_t)S * mc * sizeof(uint32_t)));
+				HIP_TRY(hipMalloc(&h->d_lpr_chunks, (size_t)S * mc * sizeof(LprChunk)));
 				h->deemph_chunks = mc;
 			}
 			const int mcs = mc;
 			const bool dbg_sync = getenv("RTLFM_TAIL_SYNC") != nullptr;
+			// deemph_filter followed directly by low_pass_real (-M wbfm): the replay pass feeds the
+			// resampler's accumulator instead of writing the filtered samples (staged_kernels.h)
+			fuse_lpr = tp.lpr && !tp.adc && !getenv("RTLFM_LPR_SEPARATE");
+			if (fuse_lpr) next_dst(&lpr_dst, &lpr_ds);
 			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
 			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
 			const size_t per_wave = 64 / lpc;
@@ -632,7 +640,14 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		k_deemph_scan_b<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
 		                                       h->d_deemph_inc, sin, sout);                                         \
 		RTLFM_DBG_SYNC("b");                                                                                           \
-		k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);         \
+		if (fuse_lpr) {                                                                                              \
+			k_deemph_scan_c_lpr<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst,  \
+			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks);   \
+			k_lpr_fixup<<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
+			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2);                              \
+		} else {                                                                                                     \
+			k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);     \
+		}                                                                                                            \
 		RTLFM_DBG_SYNC("c");                                                                                           \
 	} while (0)
 			if (pow2) RTLFM_DEEMPH_SCAN(2);
@@ -649,6 +664,12 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		                                           sout, h->d_adc_avg);
 		k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, S, T, sin,
 		                                                  h->d_adc_avg);
+	}
+	if (tp.lpr && fuse_lpr) {
+		cur = lpr_dst; cur_stride = lpr_ds;
+		if (d_out_len)
+			HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt2, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+		return 0;
 	}
 	if (tp.lpr) {
 		int16_t *d; size_t ds;

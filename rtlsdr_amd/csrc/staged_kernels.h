@@ -750,6 +750,161 @@ k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
 
+// floor(a / b) for 0 <= a < 2^52, 0 < b < 2^31: the operands are exact in fp64, the correctly
+// rounded quotient is at most one off after truncation, and the remainder says which way (a 64-bit
+// integer division expands to ~100 instructions here, this to ~25)
+__device__ __forceinline__ long long floor_div_pos(long long a, int b)
+{
+	long long q = (long long)((double)a / (double)b);
+	long long r = a - q * (long long)b;
+	if (r < 0) { q -= 1; r += b; }
+	else if (r >= b) { q += 1; r -= b; }
+	return q;
+}
+
+// ---- the replay pass with low_pass_real folded in ---------------------------------------------
+// `-M wbfm` is deemph_filter followed by low_pass_real (src/rtl_fm.c:1264-1271): the replay pass
+// above would write 2 bytes per filtered sample only for k_low_pass_real to read them back and keep
+// one in five.  Here the lane that replays a chunk feeds the filtered samples straight into the
+// reference's accumulator (now_lpr += y; prev_lpr_index += slow; emit when it reaches fast): the
+// phase and the output index at the chunk's start are closed forms, the sums are linear, so only
+// the one output that straddles a chunk boundary needs the neighbour's partial sum - it is put
+// together by k_lpr_fixup from head[c] (the sum up to the chunk's first emission) and tail[] (what
+// was left in the accumulator at the end of the chunks before).
+template <int MAGIC, class Sink>
+__device__ __forceinline__ uint32_t deemph_walk_sink(const int16_t *r, int n, uint32_t avgb, const DeemphStep &ds, bool filter,
+                                                    Sink &&sink)
+{
+	auto one = [&](int k) {
+		const uint32_t xb = (uint32_t)(uint16_t)r[k] ^ 0x8000u;
+		avgb = filter ? ds.step<MAGIC>(xb, avgb) : xb;
+		sink((int)(int16_t)(uint16_t)(avgb ^ 0x8000u));
+	};
+	int k = 0;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	for (; k < head && k < n; k++) one(k);
+	auto group = [&](const uint4 &g) {
+		const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const uint32_t b = w[j] ^ 0x80008000u;
+			avgb = filter ? ds.step<MAGIC>(b & 0xffffu, avgb) : (b & 0xffffu);
+			sink((int)(int16_t)(uint16_t)(avgb ^ 0x8000u));
+			avgb = filter ? ds.step<MAGIC>(b >> 16, avgb) : (b >> 16);
+			sink((int)(int16_t)(uint16_t)(avgb ^ 0x8000u));
+		}
+	};
+	if (k + 64 <= n) {
+		uint4 cur[8], nxt[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
+		for (; k + 64 <= n; k += 64) {
+			const bool more = k + 128 <= n;
+			const uint4 *np = reinterpret_cast<const uint4 *>(r + (more ? k + 64 : k));
+#pragma unroll
+			for (int j = 0; j < 8; j++) nxt[j] = np[j];
+#pragma unroll
+			for (int j = 0; j < 8; j++) group(cur[j]);
+#pragma unroll
+			for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+		}
+	}
+	for (; k + 8 <= n; k += 8) group(*reinterpret_cast<const uint4 *>(r + k));
+	for (; k < n; k++) one(k);
+	return avgb;
+}
+
+struct LprChunk {
+	uint32_t head;   // accumulator at the chunk's first emission (the part of the straddling output that lies in this chunk)
+	uint32_t tail;   // accumulator at the chunk's end
+	int32_t mfirst;  // index of the output of the first emission, -1: the chunk emitted nothing
+};
+
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                    DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, int16_t *__restrict__ B,
+                    size_t bstride, int fast, int slow, const state_t *__restrict__ sin, state_t *__restrict__ sout,
+                    LprChunk *__restrict__ lc)
+{
+	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	const int16_t *r = R + s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	const int nc = deemph_chunks(n, head, L);
+	if (c >= nc) return;
+	int begin, end;
+	deemph_chunk_range(c, n, head, L, begin, end);
+	// a stream whose carried deemph state lay outside int16 was filtered in place by pass B (plain form)
+	const bool filter = incoming[s * max_chunks] != 0xffffffffu;
+	const int div = fast / slow;
+	const long long p0 = sin[s].prev_lpr_index;
+	const long long idx0 = p0 + (long long)begin * slow;
+	int m = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
+	long long ph = idx0 - (long long)m * fast;
+	uint32_t acc = c == 0 ? (uint32_t)sin[s].now_lpr : 0u;
+	LprChunk out;
+	out.mfirst = -1; out.head = 0;
+	int16_t *bo = B + s * bstride;
+	const int sl = slow, fa = fast;
+	int phi = (int)ph;  // < fast + slow
+	auto sink = [&](int y) {
+		acc += (uint32_t)y;
+		phi += sl;
+		if (phi >= fa) {
+			if (out.mfirst < 0 && c > 0) { out.mfirst = m; out.head = acc; }
+			else { if (out.mfirst < 0) out.mfirst = m; bo[m] = (int16_t)((int)acc / div); }
+			m++;
+			phi -= fa;
+			acc = 0;
+		}
+	};
+	const uint32_t v = deemph_walk_sink<MAGIC>(r + begin, end - begin, filter ? incoming[s * max_chunks + c] : 0u, ds, filter, sink);
+	out.tail = acc;
+	lc[s * max_chunks + c] = out;
+	if (filter && c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+}
+
+// the outputs that straddle chunk boundaries, the carried accumulator and the output count
+__global__ void __launch_bounds__(64)
+k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams, int max_chunks,
+            int L, const LprChunk *__restrict__ lc, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
+            const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out)
+{
+	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
+	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	const int16_t *r = R + s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	const int nc = deemph_chunks(n, head, L);
+	if (c >= nc) return;
+	const LprChunk *l0 = lc + s * max_chunks;
+	const int div = fast / slow;
+	// what the chunks before c left in the accumulator since their last emission
+	auto carried = [&](int upto) {
+		uint32_t sum = 0;
+		for (int j = upto; j >= 0; j--) {
+			sum += l0[j].tail;
+			if (l0[j].mfirst >= 0) break;
+		}
+		return sum;
+	};
+	if (c > 0 && l0[c].mfirst >= 0) B[s * bstride + l0[c].mfirst] = (int16_t)((int)(l0[c].head + carried(c - 1)) / div);
+	if (c == nc - 1) {
+		const long long p0 = sin[s].prev_lpr_index;
+		const long long tot = p0 + (long long)n * slow;
+		const int E = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(tot, fast) : (int)(tot / fast);
+		sout[s].now_lpr = (int)carried(c);
+		sout[s].prev_lpr_index = (int)(tot - (long long)E * fast);
+		cnt_out[s] = E;
+	}
+}
+
 // dc_block_audio_filter (src/rtl_fm.c:1028-1041) works on whatever result_len a buffer has.
 // Buffer b of a stream owns the decimated samples [dec_block_begin(b), dec_block_begin(b+1)) of
 // the run (N input samples per buffer, boxcar D with prev_index carried in; D == 1 describes a
@@ -816,18 +971,6 @@ k_adc_apply(int16_t *__restrict__ R, size_t rstride, int N, int D, int nblocks, 
 // emitted at input ceil(((m+1)*fast - p0)/slow) - 1 and is the sum since the
 // previous emission (plus the carried now_lpr for m == 0) divided by
 // fast/slow (truncating).  n_in[s] (or T) inputs; cnt_out[s] outputs.
-// floor(a / b) for 0 <= a < 2^52, 0 < b < 2^31: the operands are exact in fp64, the correctly
-// rounded quotient is at most one off after truncation, and the remainder says which way (a 64-bit
-// integer division expands to ~100 instructions here, this to ~25)
-__device__ __forceinline__ long long floor_div_pos(long long a, int b)
-{
-	long long q = (long long)((double)a / (double)b);
-	long long r = a - q * (long long)b;
-	if (r < 0) { q -= 1; r += b; }
-	else if (r >= b) { q += 1; r -= b; }
-	return q;
-}
-
 // One thread per output m: the number of inputs consumed when output m - 1 left costs one division;
 // from there the thread walks the reference's own phase accumulator (prev_lpr_index += slow, emit
 // when it reaches fast) until its output leaves - or the inputs run out, which makes it the thread

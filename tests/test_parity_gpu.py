@@ -812,3 +812,40 @@ def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
     for s in range(ns):
         assert_parity(np.concatenate(got[s]), want[s, :want_len[s]], cfg, f"stream {s}")
         assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+
+
+@pytest.mark.parametrize("a,rates", [(13, (170000, 32000)), (2, (48000, 11025)), (30, (240000, 96000)), (9, (170000, 169999))])
+def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates):
+    """deemph_filter followed directly by low_pass_real on long runs (-M wbfm's tail): the time-parallel
+    filter's replay pass feeds the resampler's accumulator itself; outputs that straddle chunk
+    boundaries are put together afterwards.  Carried / injected accumulator, phase and filter state
+    (one stream with a filter state outside int16: the plain form), runs split over launches."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, nb, ns = 32768, 6, 6
+    ov = dict(downsample=6, custom_atan=1, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],
+              resampler=capi.RESAMPLE_LOW_PASS_REAL)
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=4100 + a, fs=1.02e6, dev_hz=75e3, amplitude=30.0)
+    st0 = oracle_lib.new_states(ns)
+    for s in range(ns):
+        st0[s].now_lpr = 1000 * s - 2500
+        st0[s].prev_lpr_index = (s * 7919) % rates[0]
+        st0[s].deemph_avg = 123 * s
+    st0[ns - 1].deemph_avg = 90000
+    st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
+    for splits in (None, [(0, 2), (2, 3), (3, 6)]):
+        outs = [[] for _ in range(ns)]
+        with GpuDemod(cfg, ns, 0) as g:
+            for s in range(ns):
+                g.state_set(s, st_copy[s])
+            d = torch.from_numpy(iq).cuda()
+            for b0, b1 in (splits or [(0, nb)]):
+                o, n = g.run_torch(d[:, b0 * L:b1 * L].contiguous()); g.sync()
+                o = o.cpu().numpy(); n = n.cpu().numpy()
+                for s in range(ns):
+                    outs[s].append(o[s, :n[s]].copy())
+            sts = [g.state_get(s) for s in range(ns)]
+        for s in range(ns):
+            assert np.array_equal(np.concatenate(outs[s]), want[s, :want_len[s]]), (a, rates, splits, s)
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (a, rates, splits, s)
