@@ -134,3 +134,60 @@ def test_default_buffer_size_many_buffers(oracle_lib):
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() <= 1e-4
     assert gu.state_dict(fst[S - 1], False) == gu.state_dict(st, False)
+
+
+def test_north_star_shape_4096_streams(oracle_lib):
+    """north_star's target shape: 4096 batched 2.4 MS/s streams through the /16 FM path, 1 and then 3
+    more 262144-B buffers each (one wave per stream and buffer run, no second wave per slot)."""
+    S, NB, L = 4096, 4, 262144
+    cfg = RtlfmCfg.default(downsample=16, downsample_passes=4, rate_out=150000, block_len=L, max_blocks=NB)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0))
+    fo, fl, fst, used = _run(cfg, iq, 2, splits=[(0, 1), (1, 4)])
+    assert used == 2
+    got = _concat(fo, fl)
+    n = got.shape[1]
+    assert n == NB * (L // 2 // 16)
+    so, sl, sst, used1 = _run(cfg, iq, 1)
+    assert used1 == 1 and torch.equal(got, so[0][:, :n]), "fused (1 + 3 buffers) != staged (4 buffers)"
+    del so
+    for s in (0, 2048, 4095):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        d = np.abs(got[s].cpu().numpy().astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()))
+        assert gu.state_dict(fst[s], False) == gu.state_dict(st, False)
+
+
+def test_wbfm_shape_full_size(oracle_lib):
+    """rtl_fm -M wbfm at scale: 1024 streams x 16 x 262144 B, boxcar /6 (not dividing the buffer),
+    -A fast, deemph, low_pass_real 170k -> 32k: the prefix-sum front end and the replay pass that
+    feeds the resampler against the staged kernels + sequential filter on every sample, and
+    against the oracle on sampled streams."""
+    import os
+    from rtlsdr_amd.capi import ATAN_FAST, RESAMPLE_LOW_PASS_REAL
+    S, NB, L = 1024, 16, 262144
+    cfg = RtlfmCfg.default(downsample=6, custom_atan=ATAN_FAST, rate_out=170000, deemph=1, deemph_a=13, rate_out2=32000,
+                           resampler=RESAMPLE_LOW_PASS_REAL, block_len=L, max_blocks=NB)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0), fs=1.02e6, dev_hz=75e3, amplitude=30.0)
+    fo, fl, fst, used = _run(cfg, iq, 2)
+    assert used == 2
+    os.environ["RTLFM_DEEMPH_SEQUENTIAL"] = "1"
+    try:
+        so, sl, sst, used1 = _run(cfg, iq, 1)
+    finally:
+        del os.environ["RTLFM_DEEMPH_SEQUENTIAL"]
+    assert used1 == 1 and torch.equal(fl[0], sl[0])
+    n = int(fl[0].max())
+    mask = torch.arange(n, device=iq.device)[None, :] < fl[0][:, None]
+    assert torch.equal(fo[0][:, :n][mask], so[0][:, :n][mask]), "fused boxcar + fused tail != staged + sequential"
+    del so
+    for s in (0, 512, 1023):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        got = fo[0][s, :int(fl[0][s])].cpu().numpy()
+        assert np.array_equal(got, want), s
+        assert gu.state_dict(fst[s], False) == gu.state_dict(st, False)
+    po_, pl_, pst, _ = _run(cfg, iq, 2, splits=[(0, 5), (5, 6), (6, 16)])
+    tot = sum(int(l[0]) for l in pl_)
+    assert tot == int(fl[0][0])
+    assert torch.equal(torch.cat([o[0, :int(l[0])] for o, l in zip(po_, pl_)]), fo[0][0, :tot])
+    for s in fst:
+        assert gu.state_dict(pst[s], False) == gu.state_dict(fst[s], False)
