@@ -23,6 +23,7 @@
 namespace rtlfm {
 namespace boxfused {
 
+constexpr int kMaxD = 2047;
 constexpr int kTileBytes = 8192;
 constexpr int kTileSamples = 4096;
 constexpr int kTileDwords = 2048;
@@ -66,7 +67,8 @@ struct Params {
 //      compact byte-pair copy of the tile.  The window's other end is the neighbouring lane's
 //      value (DPP wave_shr:1), the previous output for the discriminator likewise, so there is
 //      no LDS store -> load dependency between the rounds;
-//   5. the unfinished window: tile total - P(last boundary), exact in 16 bits for D <= 256.
+//   5. the unfinished window: tile total - P(last boundary), exact in 16 bits for D <= 256; for
+//      larger D the run's final partial sum is redone in 32 bits by k_boxcar_partial32.
 struct ScanLds {
 	static constexpr int atan = 0;                   // 17 doubles
 	static constexpr int scratch = 34;               // boundary and value of the tile's last complete output
@@ -345,11 +347,41 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	}
 }
 
+// D > 256: the partial sum the run leaves in (now_r, now_j) no longer fits the 16-bit lanes the
+// prefix sums live in (the outputs themselves are int16 by definition, src/rtl_fm.c:473-474, so
+// they are unaffected).  One lane per stream adds up the samples behind the last complete output
+// again, in 32 bits: fewer than D of them.
+__global__ void __launch_bounds__(64) k_boxcar_partial32(const Params p)
+{
+	const int s = (int)(blockIdx.x * 64 + threadIdx.x);
+	if (s >= p.nstreams) return;
+	const long long total = (long long)p.nblocks * (p.block_len / 2);
+	const int left = p.sout[s].prev_index;  // samples in the unfinished window, written by k_boxcar_scan
+	long long first = total - left;         // its first sample of this run (negative: it began before the run)
+	int ar = 0, aj = 0;
+	if (first < 0) { ar = p.sin[s].now_r; aj = p.sin[s].now_j; first = 0; }
+	const uint8_t *src = p.iq + (size_t)s * p.stream_stride;
+	for (long long i = first; i < total; i++) {
+		const int a = (int)src[2 * i] - 127, b = (int)src[2 * i + 1] - 127;
+		// rotate16_neg90 restarts with every buffer, and buffers are multiples of four samples
+		switch (p.rotate ? (int)(i & 3) : 0) {
+		case 0: ar += a; aj += b; break;
+		case 1: ar += b; aj -= a; break;
+		case 2: ar -= a; aj -= b; break;
+		default: ar -= b; aj += a; break;
+		}
+	}
+	p.sout[s].now_r = ar;
+	p.sout[s].now_j = aj;
+}
+
 inline bool supported(const rtlfm_cfg &c)
 {
 	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
 		return false;
-	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > 256) return false;
+	// at least two outputs per 4096-sample tile: a wave that starts mid-stream takes its first
+	// "previous output" from its warm-up tile
+	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > kMaxD) return false;
 	if (c.comp_fir_size || c.dc_block_raw || c.squelch_level) return false;
 	if (c.block_len % kTileBytes) return false;
 	return true;
@@ -384,6 +416,7 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0) * 4;
 	if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<true>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else hipLaunchKernelGGL((k_boxcar_scan<false>), dim3(waves), dim3(64), lds_bytes, q, p);
+	if (p.D > 256) hipLaunchKernelGGL(k_boxcar_partial32, dim3((nstreams + 63) / 64), dim3(64), 0, q, p);
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }
 

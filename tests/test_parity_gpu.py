@@ -691,7 +691,8 @@ def test_atan2_q14_against_libm_and_oracle(oracle_lib):
     assert int((a != host).sum()) == 0, f"atan2_q14 vs glibc chain: {(a != host).sum()} of {n} differ"
 
 
-@pytest.mark.parametrize("D,atan", [(10, 0), (6, 1), (16, 2), (7, 0), (255, 1), (2, 0), (3, 1)])
+@pytest.mark.parametrize("D,atan", [(10, 0), (6, 1), (16, 2), (7, 0), (255, 1), (2, 0), (3, 1), (257, 0), (334, 2), (1000, 0),
+                                    (2047, 0), (2048, 0)])
 def test_boxcar_injected_phase_and_partial_sum(oracle_lib, D, atan):
     """low_pass (src/rtl_fm.c:461-481) carries (now_r, now_j, prev_index) between buffers.  A state
     injected through rtlfm_gpu_state_set may hold any phase — with an even D an odd prev_index makes
@@ -703,6 +704,10 @@ def test_boxcar_injected_phase_and_partial_sum(oracle_lib, D, atan):
     cfg = make_cfg(ov, L, nb)
     iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=5150 + D, amplitude=20.0 if atan == 1 else 60.0)
     iq[ns - 1] = synth.random_u8(1, L * nb, seed=D)[0] if atan != 1 else iq[ns - 1]
+    if D >= 1000:  # a partial sum that needs more than 16 bits: a constant full-scale corner, phase kept by offset tuning
+        iq[ns - 2] = 255
+        ov["offset_tuning"] = 1
+        cfg = make_cfg(ov, L, nb)
     st0 = oracle_lib.new_states(ns)
     for s in range(ns):
         st0[s].prev_index = (2 * s + 1) % D
