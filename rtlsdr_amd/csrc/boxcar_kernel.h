@@ -51,9 +51,10 @@ struct Params {
 // Per 8 KiB tile (round 1 walked every window: O(D/2) LDS gathers and dot products per output and
 // per component, 1619 VALU instructions per tile at /6):
 //   1. the coalesced (non-temporal) loads are staged through LDS as S = raw ^ 0x7f and read back
-//      lane-contiguous: lane l owns dwords [32l, 32l + 32) = samples [64l, 64l + 64).  Rows are
-//      36 dwords apart, which makes both the 16-byte stores (eight consecutive lanes fill one row)
-//      and the 16-byte read-backs (eight lanes, eight rows) cover all 32 banks exactly once;
+//      lane-contiguous: lane l owns dwords [32l, 32l + 32) = samples [64l, 64l + 64).  The 16-byte
+//      slots of a row are XOR-swizzled with the row number (row_at), which makes both the 16-byte
+//      stores (eight consecutive lanes fill one row) and the 16-byte read-backs (eight lanes, eight
+//      rows) cover all 32 banks exactly once;
 //   2. a running sum along the lane's 32 dwords: two v_dot4_i32_i8 per dword whose +-1 taps carry
 //      the (-j)^n rotation and whose third operand is the sum so far - the chain IS the prefix.
 //      Before each dword the pair (I, Q) is packed to 16 + 16 bits with one v_perm: the reference
@@ -73,7 +74,7 @@ struct ScanLds {
 	static constexpr int atan = 0;                   // 17 doubles
 	static constexpr int scratch = 34;               // boundary and value of the tile's last complete output
 	static constexpr int rows = 36;                  // S, then P2: 64 rows of 32 dwords, 36 apart; + P2[2048]
-	static constexpr int row_stride = 36;
+	static constexpr int row_stride = 32;            // rows back to back, the 16-byte slot index XORed with the row (row_at)
 	static constexpr int first = rows + 65 * row_stride;  // byte pairs of each dword's first sample: 64 rows of 16 dwords, 20 apart
 	static constexpr int first_stride = 20;
 	// the byte-pair copy is only allocated for odd D.  With an even D the window ends are all even or
@@ -121,11 +122,22 @@ __device__ __forceinline__ void chain_settle(int &accI, int &accQ)
 	asm volatile("s_nop 4" : "+v"(accI), "+v"(accQ));
 }
 
+// Where dword d of the tile-sized S / P2 area lives: row r = d >> 5 (one lane's 32 dwords) keeps its
+// place, its eight 16-byte slots are permuted by r & 7.  Eight consecutive lanes reading or writing
+// "their" slot j then touch eight different slots = all 32 banks once, as do eight lanes that fill
+// one row - without the four padding dwords per row that a skewed layout costs: 9.2 KiB per wave
+// instead of 10.4, which is the difference between three and four waves per SIMD (-7 % at /10,
+// -9 % at /6).
+__device__ __forceinline__ int row_at(int d)
+{
+	return d ^ ((int)__builtin_amdgcn_ubfe((uint32_t)d, 5, 3) << 2);
+}
+
 __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) + fused::as_s2(b)); }
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) - fused::as_s2(b)); }
 
 #ifndef RTLFM_BOXSCAN_WAVES_PER_SIMD
-#define RTLFM_BOXSCAN_WAVES_PER_SIMD 3
+#define RTLFM_BOXSCAN_WAVES_PER_SIMD 4
 #endif
 
 template <bool STD>
@@ -208,7 +220,6 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		const int t = 8 * j1 + (lane - 8);
 		if (lane >= 8 && lane < 16 && j1 >= j0 && t < last) g16[t] = (int16_t)pcm[t];
 	};
-	uint32_t *row = lds + ScanLds::rows + ScanLds::row_stride * lane;  // this lane's 32 dwords
 
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		const bool more = gt + 1 < gt_end;
@@ -224,7 +235,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			const int c = 64 * k + lane;
 			uint4 v = cur[k];
 			v.x ^= 0x7f7f7f7fu; v.y ^= 0x7f7f7f7fu; v.z ^= 0x7f7f7f7fu; v.w ^= 0x7f7f7f7fu;
-			*reinterpret_cast<uint4 *>(lds + ScanLds::rows + ScanLds::row_stride * (c >> 3) + 4 * (c & 7)) = v;
+			*reinterpret_cast<uint4 *>(lds + ScanLds::rows + row_at(4 * c)) = v;
 		}
 		__builtin_amdgcn_wave_barrier();
 		flush();
@@ -235,7 +246,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		int accI = 0, accQ = 0;
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(row + 4 * j);
+			const uint4 v = *reinterpret_cast<const uint4 *>(lds + ScanLds::rows + row_at(32 * lane + 4 * j));
 			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 			if (first_in_lds) {
 				// bytes 0, 1 of every dword (its first sample), two dwords per dword
@@ -259,9 +270,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			uint4 v;
 			v.x = pk_add16(pk[4 * j], off); v.y = pk_add16(pk[4 * j + 1], off);
 			v.z = pk_add16(pk[4 * j + 2], off); v.w = pk_add16(pk[4 * j + 3], off);
-			*reinterpret_cast<uint4 *>(row + 4 * j) = v;
+			*reinterpret_cast<uint4 *>(lds + ScanLds::rows + row_at(32 * lane + 4 * j)) = v;
 		}
-		if (lane == 0) lds[ScanLds::rows + ScanLds::row_stride * 64] = tot;  // P2[2048]
+		if (lane == 0) lds[ScanLds::rows + row_at(2048)] = tot;  // P2[2048]
 		__builtin_amdgcn_wave_barrier();
 
 		// ---- 4. lane l takes the R consecutive outputs e = l R .. l R + R - 1: the window's other end
@@ -275,7 +286,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			int n = (e + 1) * D - ph;
 			if (n > kTileSamples) n = kTileSamples;  // outputs past Et
 			const int d = n >> 1;
-			uint32_t Pv = lds[ScanLds::rows + d + 4 * (d >> 5)];
+			uint32_t Pv = lds[ScanLds::rows + row_at(d)];
 			if (need_odd) {
 				uint32_t fp;
 				if (first_in_lds) fp = reinterpret_cast<const uint16_t *>(lds + ScanLds::first)[d + ((d >> 5) << 3)];
