@@ -59,6 +59,7 @@ struct rtlfm_gpu {
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
+	int32_t *d_deemph_fb = nullptr;       // [nstreams] streams the one-pass filter hands to the four passes
 	int deemph_chunks = 0;
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
 	size_t deep_stride = 0;
@@ -352,7 +353,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_deemph_fb, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -619,6 +620,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				HIP_TRY(hipMalloc(&h->d_lpr_chunks, (size_t)S * mc * sizeof(LprChunk)));
 				h->deemph_chunks = mc;
 			}
+			if (!h->d_deemph_fb) HIP_TRY(hipMalloc(&h->d_deemph_fb, (size_t)S * sizeof(int32_t)));
 			const int mcs = mc;
 			const bool dbg_sync = getenv("RTLFM_TAIL_SYNC") != nullptr;
 			// deemph_filter followed directly by low_pass_real (-M wbfm): the replay pass feeds the
@@ -630,21 +632,37 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const size_t per_wave = 64 / lpc;
 			const unsigned ga = (unsigned)(((size_t)S * mcs + per_wave - 1) / per_wave), gc = (unsigned)(((size_t)S * mcs + 63) / 64);
 #define RTLFM_DBG_SYNC(what) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(q); fprintf(stderr, "rtlfm_hip[tail]: %s done (%s)\n", what, hipGetErrorString(e_)); } } while (0)
+			// One pass where the resampler follows directly: every chunk finds its incoming state from the
+			// W samples before it (staged_kernels.h, k_deemph_spec_lpr); the streams it cannot settle
+			// that way (silence) raise a flag and alone go through the four passes below.
+			const bool spec = fuse_lpr && !getenv("RTLFM_DEEMPH_FOUR_PASS");
+			const int32_t *only = spec ? h->d_deemph_fb : nullptr;
+			const int Ls = 2048, Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
+			const int mcsp = T / Ls + 2;
+			const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
+			if (spec) HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
 #define RTLFM_DEEMPH_SCAN(M)                                                                                        \
 	do {                                                                                                            \
 		RTLFM_DBG_SYNC("before deemph scan");                                                                          \
-		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
+		if (spec) {                                                                                                  \
+			k_deemph_spec_lpr<M><<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds,     \
+			                                         c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, h->d_deemph_fb); \
+			k_lpr_fixup<<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcsp, Ls, h->d_lpr_chunks, lpr_dst, lpr_ds,       \
+			                               c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, nullptr, h->d_deemph_fb);   \
+			RTLFM_DBG_SYNC("one pass");                                                                                \
+		}                                                                                                            \
+		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
 		RTLFM_DBG_SYNC("a1");                                                                                          \
-		k_deemph_scan_a2<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);         \
+		k_deemph_scan_a2<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
 		RTLFM_DBG_SYNC("a2");                                                                                          \
 		k_deemph_scan_b<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
-		                                       h->d_deemph_inc, sin, sout);                                         \
+		                                       h->d_deemph_inc, sin, sout, only);                                   \
 		RTLFM_DBG_SYNC("b");                                                                                           \
 		if (fuse_lpr) {                                                                                              \
 			k_deemph_scan_c_lpr<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst,  \
-			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks);   \
+			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, only); \
 			k_lpr_fixup<<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
-			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2);                              \
+			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, only);                        \
 		} else {                                                                                                     \
 			k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);     \
 		}                                                                                                            \

@@ -592,12 +592,13 @@ __device__ __forceinline__ int deemph_chunks(int n, int head, int L)
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab)
+                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab,
+                 const int32_t *__restrict__ only = nullptr)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams) return;
+	if (s >= (size_t)nstreams || (only && !only[s])) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -659,13 +660,14 @@ k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_a2(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab)
+                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab,
+                 const int32_t *__restrict__ only = nullptr)
 {
 	const int sub = threadIdx.x & (lpc - 1);
 	const size_t g = (size_t)blockIdx.x * (64 / lpc) + threadIdx.x / lpc;  // (stream, chunk) index
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams) return;
+	if (s >= (size_t)nstreams || (only && !only[s])) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -689,12 +691,12 @@ template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                 DeemphStep ds, int max_chunks, int L, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
-                const state_t *__restrict__ sin, state_t *__restrict__ sout)
+                const state_t *__restrict__ sin, state_t *__restrict__ sout, const int32_t *__restrict__ only = nullptr)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams) return;
+	if (s >= (size_t)nstreams || (only && !only[s])) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	uint32_t *inc = incoming + s * max_chunks;
@@ -825,12 +827,12 @@ __global__ void __launch_bounds__(64)
 k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                     DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, int16_t *__restrict__ B,
                     size_t bstride, int fast, int slow, const state_t *__restrict__ sin, state_t *__restrict__ sout,
-                    LprChunk *__restrict__ lc)
+                    LprChunk *__restrict__ lc, const int32_t *__restrict__ only = nullptr)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams) return;
+	if (s >= (size_t)nstreams || (only && !only[s])) return;
 	const int n = cnt ? cnt[s] : T;
 	const int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -868,16 +870,116 @@ k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const 
 	if (filter && c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
 
-// the outputs that straddle chunk boundaries, the carried accumulator and the output count
+// ---- one pass instead of A1 / A2 / B / C --------------------------------------------------------
+// The filter forgets: two walks from the two extreme states meet after ~11 a samples on any signal
+// that moves (a = 13: 143 in the median, 232 at most on the wbfm test signal; a = 2: 17 / 23).  So a
+// chunk does not need the tables of passes A and B to learn its incoming state: it walks both
+// extremes over the W samples before its own first one, and if they have met, that IS the state the
+// chunk starts from, exactly, whatever came before.  Then it replays its samples into the
+// resampler as k_deemph_scan_c_lpr does.  One read of the run plus W / L instead of two.  A chunk
+// whose extremes have not met (a silent stream) raises its stream's flag, and the flagged streams
+// go through the four passes afterwards (`only`); a filter state outside int16 likewise.
+template <int MAGIC>
+__device__ __forceinline__ void deemph_walk_pair(const int16_t *r, int n, uint32_t &lo, uint32_t &hi, const DeemphStep &ds)
+{
+	int k = 0;
+	const int pre = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	for (; k < pre && k < n; k++) {
+		const uint32_t x = (uint32_t)(uint16_t)r[k] ^ 0x8000u;
+		lo = ds.step<MAGIC>(x, lo); hi = ds.step<MAGIC>(x, hi);
+	}
+	for (; k + 8 <= n; k += 8) {
+		const uint4 g = *reinterpret_cast<const uint4 *>(r + k);
+		const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const uint32_t b2 = w[i] ^ 0x80008000u;
+			lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
+			lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
+		}
+	}
+	for (; k < n; k++) {
+		const uint32_t x = (uint32_t)(uint16_t)r[k] ^ 0x8000u;
+		lo = ds.step<MAGIC>(x, lo); hi = ds.step<MAGIC>(x, hi);
+	}
+}
+
+template <int MAGIC>
 __global__ void __launch_bounds__(64)
-k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams, int max_chunks,
-            int L, const LprChunk *__restrict__ lc, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
-            const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out)
+k_deemph_spec_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                  DeemphStep ds, int max_chunks, int L, int W, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *__restrict__ lc,
+                  int32_t *__restrict__ fallback)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
 	if (s >= (size_t)nstreams) return;
+	const int n = cnt ? cnt[s] : T;
+	const int16_t *r = R + s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	const int nc = deemph_chunks(n, head, L);
+	if (c >= nc) return;
+	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {  // only rtlfm_gpu_state_set can do that: the four passes' plain form
+		if (c == 0) fallback[s] = 1;
+		return;
+	}
+	int begin, end;
+	deemph_chunk_range(c, n, head, L, begin, end);
+	uint32_t v = (uint32_t)(sin[s].deemph_avg + 32768);
+	if (begin > 0) {
+		if (begin <= W) {
+			// close to the start of the run: from the carried state itself
+			uint32_t v2 = v;
+			deemph_walk_pair<MAGIC>(r, begin, v, v2, ds);
+		} else {
+			uint32_t lo = 0, hi = 65535;
+			deemph_walk_pair<MAGIC>(r + begin - W, W, lo, hi, ds);
+			if (lo != hi) {
+				fallback[s] = 1;
+				return;
+			}
+			v = lo;
+		}
+	}
+	const int div = fast / slow;
+	const long long p0 = sin[s].prev_lpr_index;
+	const long long idx0 = p0 + (long long)begin * slow;
+	int m = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
+	uint32_t acc = c == 0 ? (uint32_t)sin[s].now_lpr : 0u;
+	LprChunk out;
+	out.mfirst = -1; out.head = 0;
+	int16_t *bo = B + s * bstride;
+	const int sl = slow, fa = fast;
+	int phi = (int)(idx0 - (long long)m * fast);
+	auto sink = [&](int y) {
+		acc += (uint32_t)y;
+		phi += sl;
+		if (phi >= fa) {
+			if (out.mfirst < 0 && c > 0) { out.mfirst = m; out.head = acc; }
+			else { if (out.mfirst < 0) out.mfirst = m; bo[m] = (int16_t)((int)acc / div); }
+			m++;
+			phi -= fa;
+			acc = 0;
+		}
+	};
+	v = deemph_walk_sink<MAGIC>(r + begin, end - begin, v, ds, true, sink);
+	out.tail = acc;
+	lc[s * max_chunks + c] = out;
+	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+}
+
+// the outputs that straddle chunk boundaries, the carried accumulator and the output count
+__global__ void __launch_bounds__(64)
+k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams, int max_chunks,
+            int L, const LprChunk *__restrict__ lc, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
+            const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out,
+            const int32_t *__restrict__ only = nullptr, const int32_t *__restrict__ skip = nullptr)
+{
+	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+	const size_t s = g / max_chunks;
+	const int c = (int)(g % max_chunks);
+	if (s >= (size_t)nstreams || (only && !only[s]) || (skip && skip[s])) return;
 	const int n = cnt ? cnt[s] : T;
 	const int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);

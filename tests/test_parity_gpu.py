@@ -824,13 +824,17 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates):
     """deemph_filter followed directly by low_pass_real on long runs (-M wbfm's tail): the time-parallel
     filter's replay pass feeds the resampler's accumulator itself; outputs that straddle chunk
     boundaries are put together afterwards.  Carried / injected accumulator, phase and filter state
-    (one stream with a filter state outside int16: the plain form), runs split over launches."""
+    (one stream with a filter state outside int16: the plain form), a silent stream and one that falls
+    silent half way (there the one-pass filter cannot settle its chunks and hands the stream to the
+    four passes), runs split over launches."""
     from rtlsdr_amd.demod import GpuDemod
     L, nb, ns = 32768, 6, 6
     ov = dict(downsample=6, custom_atan=1, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],
               resampler=capi.RESAMPLE_LOW_PASS_REAL)
     cfg = make_cfg(ov, L, nb)
     iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=4100 + a, fs=1.02e6, dev_hz=75e3, amplitude=30.0)
+    iq[1] = 127                  # silence: the filter's two extreme walks never meet (the four-pass route)
+    iq[2, L * 2:L * 4] = 127     # ... and a stream that falls silent for two buffers
     st0 = oracle_lib.new_states(ns)
     for s in range(ns):
         st0[s].now_lpr = 1000 * s - 2500
