@@ -418,8 +418,13 @@ class FmJob:
         amp = 40.0 if a.atan == "fast" else 60.0  # -A fast overflows above |z| ~ 724
         if a.atan == "fast" and a.boxcar:
             amp = min(40.0, 500.0 / a.boxcar)
-        self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=75e3 if a.fs > 2e6 or a.tail == "wbfm" else 5e3,
-                                       amplitude=amp, first_stream=rank * S)
+        if a.pmc_child:
+            # counter passes only weigh bytes: one fill kernel instead of the signal generator's thousands of
+            # small dispatches (rocprofv3's counter mode stalled on those at 4096 streams)
+            self.iq = torch.randint(0, 256, (S, NB * L), dtype=torch.uint8, device=dev)
+        else:
+            self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=75e3 if a.fs > 2e6 or a.tail == "wbfm" else 5e3,
+                                           amplitude=amp, first_stream=rank * S)
         self.g = GpuDemod(self.cfg, S, local_rank)
         self.g.set_path(a.path)
         cap = self.g.result_cap(NB)
@@ -485,7 +490,10 @@ class PowerJob:
         self.cfg = RtlpowerCfg.default(bin_e=self.bin_e, window=1, buf_len=L)
         S, NB = a.streams, a.blocks
         self.samples = S * NB * L // 2
-        self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=50e3, first_stream=rank * S)
+        if a.pmc_child:
+            self.iq = torch.randint(0, 256, (S, NB * L), dtype=torch.uint8, device=dev)
+        else:
+            self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=50e3, first_stream=rank * S)
         self.g = GpuPower(self.cfg, S, local_rank)
         self.local_rank = local_rank
         # 2 B read per complex sample + the int64 accumulators written back once per launch
@@ -541,9 +549,7 @@ def main():
         if rank == 0:
             ge.build()
         under_profiler = any("ROCPROF" in k for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        # (rocprofv3's counter mode stalls on config 3's queue of small tail kernels at 4096 streams;
-        # the tail workloads take the passes only on request)
-        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not under_profiler and a.tail in ("", "power"))
+        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not under_profiler)
         if want_pmc and rank == 0 and world == 1:
             traffic = pmc_traffic(a)
 

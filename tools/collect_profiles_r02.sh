@@ -27,7 +27,8 @@ for r in rows[:10]:
 PY
 }
 cd /tmp && export TMPDIR=/tmp
-COMMON="--steps 40 --warmup 10 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0"
+# long enough that the clock ramp of the first launches after idle does not weigh on the averages
+COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0"
 for spec in "c2:" "ns4096:--workload ns4096" "box10:--boxcar 10" "box6:--boxcar 6" "c1:--workload c1" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
   tag=${spec%%:*}; args=${spec#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 $ROOT/bench.py $COMMON $args > $OUT/trace_$tag.log 2>&1
