@@ -91,6 +91,8 @@ typedef struct rtlfm_cfg {
 	int32_t squelch_level;      /* 0 = off (src/rtl_fm.c:1204) */
 	uint32_t block_len;         /* bytes per callback buffer = lp_len, multiple of 512 */
 	int32_t max_blocks;         /* most blocks per stream one run may take */
+	int32_t report_levels;      /* 1: keep the per-buffer rms() of the decimated IQ (what -L prints,
+	                               src/rtl_fm.c:1217-1237) for rtlfm_gpu_levels() also when the squelch is off */
 } rtlfm_cfg;
 
 /*
@@ -191,6 +193,14 @@ int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n);
 /* The same for all streams at once: stream s gets lens[s] samples at out + s * out_stride (int16
  * elements; rtlfm_result_cap() * max_blocks is always enough).  One device-to-host transfer. */
 int rtlfm_gpu_fetch_all(rtlfm_gpu *h, int16_t *out, size_t out_stride, int32_t *lens);
+
+/*
+ * rms() of the decimated IQ (`sr` in full_demod(), src/rtl_fm.c:1204-1237) of every buffer of the
+ * last run for `stream`: what the squelch compared with squelch_level and what -L prints.  Needs
+ * cfg.squelch_level or cfg.report_levels; a buffer whose rms() came out negative (the wrapped sum
+ * of squares, see rms()) reads INT32_MIN as in the reference.  *n = buffers in the last run.
+ */
+int rtlfm_gpu_levels(rtlfm_gpu *h, int stream, int32_t *rms, int cap, int *n);
 
 int rtlfm_gpu_state_get(rtlfm_gpu *h, int stream, rtlfm_stream_state *st);
 int rtlfm_gpu_state_set(rtlfm_gpu *h, int stream, const rtlfm_stream_state *st);

@@ -46,7 +46,13 @@ class RtlfmCfg(C.Structure):
         ("squelch_level", C.c_int32),
         ("block_len", C.c_uint32),
         ("max_blocks", C.c_int32),
+        ("report_levels", C.c_int32),
     ]
+
+    @classmethod
+    def from_saved(cls, raw: bytes) -> "RtlfmCfg":
+        """A configuration stored by an earlier round's fixture: later fields are zero."""
+        return cls.from_buffer_copy(raw.ljust(C.sizeof(cls), b"\0"))
 
     @classmethod
     def default(cls, **kw) -> "RtlfmCfg":
@@ -169,6 +175,7 @@ _SIGNATURES = [
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rtlfm_gpu_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, _P(C.c_int)]),
     ("rtlfm_gpu_fetch_all", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rtlfm_gpu_levels", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, _P(C.c_int)]),
     ("rtlfm_gpu_state_get", C.c_int, [C.c_void_p, C.c_int, _P(RtlfmStreamState)]),
     ("rtlfm_gpu_state_set", C.c_int, [C.c_void_p, C.c_int, _P(RtlfmStreamState)]),
     ("rtlfm_gpu_reset", C.c_int, [C.c_void_p]),

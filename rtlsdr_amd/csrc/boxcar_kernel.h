@@ -393,7 +393,7 @@ inline bool supported(const rtlfm_cfg &c)
 	// at least two outputs per 4096-sample tile: a wave that starts mid-stream takes its first
 	// "previous output" from its warm-up tile
 	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > kMaxD) return false;
-	if (c.comp_fir_size || c.dc_block_raw || c.squelch_level) return false;
+	if (c.comp_fir_size || c.dc_block_raw || c.squelch_level || c.report_levels) return false;
 	if (c.block_len % kTileBytes) return false;
 	return true;
 }

@@ -948,7 +948,7 @@ inline bool supported_emit(const rtlfm_cfg &c)
 	if (c.downsample_passes < 1 || c.downsample_passes > RTLFM_MAX_PASSES) return false;
 	if (c.block_len % kTileBytes) return false;
 	if (c.dc_block_raw) return false;
-	return c.downsample_passes > kMaxP || c.mode == RTLFM_MODE_RAW || c.squelch_level != 0;
+	return c.downsample_passes > kMaxP || c.mode == RTLFM_MODE_RAW || c.squelch_level != 0 || c.report_levels != 0;
 }
 
 inline int ensure_dummy_tile(Workspace &ws)
@@ -965,7 +965,7 @@ inline bool supported(const rtlfm_cfg &c, int nblocks)
 		return false;
 	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
 	if (c.block_len % kTileBytes) return false;
-	if (c.dc_block_raw || c.squelch_level) return false;
+	if (c.dc_block_raw || c.squelch_level || c.report_levels) return false;
 	(void)nblocks;
 	return true;
 }

@@ -13,7 +13,8 @@
 // full, so the output is a deterministic function of the input file.
 //
 // Not restated (out of scope): frequency scanning / hopping,
-// the CSV command file, squelch-driven retuning.
+// the CSV command file, squelch-driven retuning.  -l / -t hold the output back as
+// demod_thread_fn does, -L prints full_demod()'s level lines.
 #include <getopt.h>
 #include <pthread.h>
 
@@ -69,6 +70,10 @@ struct App {
 	rtlamd_wave wave{};
 	int verbosity = 0;
 	int conseq_squelch = 10;
+	// -L (src/rtl_fm.c:109-113, 1217-1237)
+	int print_levels = 0, print_level_no = 1, level_max = 0, level_max_max = 0;
+	double level_sum = 0.0;
+	uint32_t user_freq = 0;
 	uint64_t blocks_in = 0, samples_out = 0, blocks_squelched = 0;
 };
 
@@ -135,6 +140,28 @@ void demod_thread(App *a)
 			break;
 		}
 		pcm.resize((size_t)n);
+		if (a->print_levels) {
+			// full_demod()'s level printing, src/rtl_fm.c:1217-1237, on the rms() the GPU layer kept
+			int32_t sr = 0;
+			int nl = 0;
+			if (rtlfm_gpu_levels(a->gpu, 0, &sr, 1, &nl) == 0 && nl == 1) {
+				--a->print_level_no;
+				if (sr >= 0) {
+					a->level_sum += sr;
+					if (a->level_max < sr) a->level_max = sr;
+					if (a->level_max_max < sr) a->level_max_max = sr;
+					if (!a->print_level_no) {
+						a->print_level_no = a->print_levels;
+						const double avg_rms = a->level_sum / a->print_levels;
+						fprintf(stderr, "%.3f kHz, %.1f avg rms, %d max rms, %d max max rms, %d squelch rms, %d rms, %.1f dB rms level, %.2f dB avg rms level\n",
+						        a->user_freq / 1000.0, avg_rms, a->level_max, a->level_max_max, a->cfg.squelch_level, (int)sr,
+						        20.0 * log10(1E-10 + sr), 20.0 * log10(1E-10 + avg_rms));
+						a->level_max = 0;
+						a->level_sum = 0;
+					}
+				}
+			}
+		}
 		if (a->cfg.squelch_level) {
 			// demod_thread_fn(), src/rtl_fm.c:1366-1370: while the squelch has been closed for more than
 			// conseq_squelch buffers nothing goes to the output thread, and the counter is held one above
@@ -188,6 +215,7 @@ void usage()
 	        "\t[-E enable_option]  edge, dc, rdc, deemp, offset\n"
 	        "\t[-c de-emphasis_time_constant in us: us (75), eu (50) or a number]\n"
 	        "\t[-o oversampling (default: 1)]  [-l squelch_level]  [-t squelch_delay (default: 10)]  [-q rdc_block_const]\n"
+	        "\t[-L N  prints levels every N calculations]\n"
 	        "\t[-W length of one buffer in units of 512 bytes (default: 32 = 16384 B)]\n"
 	        "\t[-H write a wave header with the auxi chunk SDR programs read the frequency from]\n"
 	        "\t[-d device_index] [-g gain] [-p ppm]  accepted and passed to the device layer\n"
@@ -210,7 +238,7 @@ int main(int argc, char **argv)
 	c.rate_out = 24000;
 	c.max_blocks = 8;
 	int opt;
-	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:t:r:p:E:F:A:M:hm:q:c:W:Hv")) != -1) {
+	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:t:r:p:E:F:A:M:hm:L:q:c:W:Hv")) != -1) {
 		switch (opt) {
 		case 'd': dev_index = atoi(optarg); break;
 		case 'f': freq = (uint32_t)atofs(optarg); have_freq = true; break;
@@ -218,6 +246,7 @@ int main(int argc, char **argv)
 		case 'p': ppm = (int)atof(optarg); break;
 		case 'm': min_capture = (int)atofs(optarg); break;
 		case 'l': c.squelch_level = (int)atof(optarg); break;
+		case 'L': a.print_levels = (int)atof(optarg); break;  // src/rtl_fm.c:1757-1759
 		case 't':  // src/rtl_fm.c:1774-1781 (a negative value also asks to terminate on squelch: not restated)
 			conseq_squelch = (int)atof(optarg);
 			if (conseq_squelch < 0) conseq_squelch = -conseq_squelch;
@@ -275,6 +304,8 @@ int main(int argc, char **argv)
 	if (wb_mode) freq += 16000;  // controller_thread_fn(), src/rtl_fm.c:1455-1460: "wbfm: adding 16000 Hz to every input frequency"
 	a.conseq_squelch = conseq_squelch;
 	if (c.squelch_level) c.max_blocks = 1;  // the squelch rule below is the reference's per-buffer rule
+	if (a.print_levels > 0) { c.report_levels = 1; c.max_blocks = 1; }
+	a.user_freq = freq;  // dongle.userFreq, src/rtl_fm.c:1440
 	rate_in *= c.post_downsample;  // src/rtl_fm.c:1886
 	const char *filename = optind < argc ? argv[optind] : "-";
 

@@ -75,6 +75,8 @@ struct rtlfm_gpu {
 	bool tail_overlap = true;
 	int32_t *d_lut = nullptr;
 	int32_t *d_mute = nullptr;        // [nstreams*cap_blocks]
+	int32_t *d_levels = nullptr;      // [nstreams*cap_blocks] rms() per buffer of the last run
+	int last_nblocks = 0;
 	long long *d_sums = nullptr;      // [nstreams*cap_blocks*2]  dc_block_raw (front end's stream)
 	long long *d_adc_sums = nullptr;  // [nstreams*cap_blocks]    dc_block_audio (the tail's stream)
 	int2 *d_rdc_avg = nullptr;        // [nstreams*cap_blocks]
@@ -297,6 +299,7 @@ static int create_body(rtlfm_gpu *h)
 	}
 	HIP_TRY(hipMalloc(&h->d_cnt2, S * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_mute, S * h->cap_blocks * sizeof(int32_t)));
+	HIP_TRY(hipMalloc(&h->d_levels, S * h->cap_blocks * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_sums, S * h->cap_blocks * 2 * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_adc_sums, S * h->cap_blocks * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_rdc_avg, S * h->cap_blocks * sizeof(int2)));
@@ -355,7 +358,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_deemph_fb, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
-	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
+	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	h->fws.release();
@@ -792,9 +795,10 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	r = timing_end(h, ev);
 	if (r < 0) return r;
 	// --- power squelch (src/rtl_fm.c:1204-1215)
-	if (c.squelch_level) {
+	if (c.squelch_level || c.report_levels)
 		k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->xstride, Nblk, D, nblocks, sin, c.squelch_level,
-		                                         c.dc_block_raw, h->d_mute);
+		                                         c.dc_block_raw, h->d_mute, h->d_levels);
+	if (c.squelch_level) {
 		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
 		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, Nblk, D, nblocks, S, T, sin,
 		                                                     h->d_mute);
@@ -956,9 +960,10 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 		k_fir9<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, oth, h->deep_stride, T, S, c.downsample_passes, sin, sout);
 		std::swap(cur, oth);
 	}
-	if (c.squelch_level) {
+	if (c.squelch_level || c.report_levels)
 		k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, Nblk, 1, nblocks, sin, c.squelch_level,
-		                                         c.dc_block_raw, h->d_mute);
+		                                         c.dc_block_raw, h->d_mute, h->d_levels);
+	if (c.squelch_level) {
 		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
 		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, Nblk, 1, nblocks, S, T, sin,
 		                                                     h->d_mute);
@@ -1056,6 +1061,22 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	HIP_TRY(hipGetLastError());
 	h->st_cur = (h->st_cur + 1) % 3;
 	h->step++;
+	h->last_nblocks = nblocks;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_levels(rtlfm_gpu *h, int stream, int32_t *rms, int cap, int *n)
+{
+	if (!h || !rms || !n || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	if (!h->cfg.squelch_level && !h->cfg.report_levels) return -ENODATA;
+	*n = h->last_nblocks;
+	if (h->last_nblocks > cap) return -ENOBUFS;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(sync_all(h));
+	// the kernels index the buffers of a run [stream][nblocks]
+	if (h->last_nblocks > 0)
+		HIP_TRY(hipMemcpy(rms, h->d_levels + (size_t)stream * h->last_nblocks, (size_t)h->last_nblocks * sizeof(int32_t),
+		                  hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -1231,6 +1252,7 @@ static rtlfm_gpu make_view(rtlfm_gpu *h, int s0, int ns, uint32_t block_len)
 	}
 	v.d_cnt2 = h->d_cnt2 + s0;
 	v.d_mute = h->d_mute + s0 * cb;
+	v.d_levels = h->d_levels + s0 * cb;
 	v.d_sums = h->d_sums + s0 * cb * 2;
 	v.d_adc_sums = h->d_adc_sums + s0 * cb;
 	v.d_rdc_avg = h->d_rdc_avg + s0 * cb;

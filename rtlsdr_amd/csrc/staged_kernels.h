@@ -291,7 +291,8 @@ __device__ __forceinline__ int dec_block_begin(int b, int N, int D, int p0)
 // mute[s*nblocks+b] = 1 when the block is to be zeroed.
 __global__ void __launch_bounds__(256)
 k_squelch_rms(const uint32_t *__restrict__ X, size_t xstride, int N, int D, int nblocks,
-              const state_t *__restrict__ sin, int level, int omit_dc_fix, int32_t *__restrict__ mute)
+              const state_t *__restrict__ sin, int level, int omit_dc_fix, int32_t *__restrict__ mute,
+              int32_t *__restrict__ rms_out)
 {
 	const int sb = blockIdx.x;
 	const int b = sb % nblocks;
@@ -336,6 +337,7 @@ k_squelch_rms(const uint32_t *__restrict__ X, size_t xstride, int N, int D, int 
 		// skips (sr >= 0, src/rtl_fm.c:1206); v_cvt_i32_f64 would turn the NaN into 0
 		const int sr = r == r ? (int)r : INT32_MIN;
 		mute[sb] = (sr >= 0 && sr < level) ? 1 : (sr >= 0 ? 0 : 2);
+		rms_out[sb] = sr;
 	}
 }
 

@@ -109,6 +109,13 @@ class GpuDemod:
         check(self.lib.rtlfm_gpu_release_to(self._h, ts), "rtlfm_gpu_release_to")
         return out, out_len
 
+    def levels(self, stream: int = 0) -> np.ndarray:
+        """rms() of the decimated IQ per buffer of the last run (needs squelch_level or report_levels)."""
+        out = np.zeros(max(1, self.cfg.max_blocks), dtype=np.int32)
+        n = C.c_int()
+        check(self.lib.rtlfm_gpu_levels(self._h, stream, out.ctypes.data, out.size, C.byref(n)), "rtlfm_gpu_levels")
+        return out[:n.value].copy()
+
     # -- state & plumbing ------------------------------------------------------
     def state_get(self, stream: int = 0) -> RtlfmStreamState:
         st = RtlfmStreamState()

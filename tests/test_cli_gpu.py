@@ -133,3 +133,46 @@ def test_cli_squelch_holds_output_back_like_demod_thread_fn(oracle_lib, tmp_path
     want = np.concatenate(want)
     assert 20 < held < nb - 10 and f"{held} buffers held back" in r.stderr
     assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_cli_prints_levels_like_full_demod(oracle_lib, tmp_path):
+    """-L n: the level line of full_demod() (src/rtl_fm.c:1217-1237) every n buffers — the first one
+    right away (printLevelNo starts at 1), averages over n."""
+    _, cli = hipbuild.build_host()
+    L, nb, n_every = 16384, 9, 4
+    cfg = RtlfmCfg.default(rate_out=150000)
+    cf, cr = C.c_uint32(), C.c_uint32()
+    oracle_lib.oracle().orc_optimal_settings(C.byref(cfg), 100000000, 150000, 1300000, 1, 0, C.byref(cf), C.byref(cr))
+    iq = synth.fm_iq_u8(1, L // 2 * nb, fs=2.4e6, dev_hz=75e3, amplitude=55.0, seed=12)[0]
+    src, out = tmp_path / "capture.bin", tmp_path / "audio.raw"
+    iq.tofile(src)
+    r = subprocess.run([cli, "-f", "100M", "-M", "fm", "-s", "150k", "-m", "1.3M", "-F", "0", "-L", str(n_every), str(out)],
+                       env=dict(os.environ, RTLSDR_FILE=str(src)), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stderr.splitlines() if " avg rms, " in ln]
+    # the same bookkeeping over the oracle's rms() of the decimated IQ
+    lib = oracle_lib.oracle()
+    lib.orc_rms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.orc_rms.restype = C.c_int
+    from rtlsdr_amd import capi
+    raw = RtlfmCfg.from_buffer_copy(bytes(cfg)); raw.mode = capi.MODE_RAW
+    st = oracle_lib.new_states(1)[0]
+    scratch = np.zeros(2 * L, dtype=np.int16)
+    want, no, lsum, lmax, lmaxmax = [], 1, 0.0, 0, 0
+    import math
+    for b in range(nb):
+        k = lib.orc_block(C.byref(raw), C.byref(st), np.ascontiguousarray(iq[b * L:(b + 1) * L]), L, scratch)
+        sr = lib.orc_rms(scratch.ctypes.data, k, 1, 0)
+        no -= 1
+        lsum += sr; lmax = max(lmax, sr); lmaxmax = max(lmaxmax, sr)
+        if no == 0:
+            no = n_every
+            avg = lsum / n_every
+            want.append("%.3f kHz, %.1f avg rms, %d max rms, %d max max rms, %d squelch rms, %d rms, %.1f dB rms level, %.2f dB avg rms level"
+                        % (100000.0, avg, lmax, lmaxmax, 0, sr, 20 * math.log10(1e-10 + sr), 20 * math.log10(1e-10 + avg)))
+            lmax, lsum = 0, 0.0
+    assert lines == want
+    # the PCM is what it is without -L
+    got = np.fromfile(out, dtype=np.int16)
+    ref, _ = oracle_lib.run_stream(cfg, iq)
+    assert got.shape == ref.shape and np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1

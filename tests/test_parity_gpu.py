@@ -858,3 +858,35 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates):
         for s in range(ns):
             assert np.array_equal(np.concatenate(outs[s]), want[s, :want_len[s]]), (a, rates, splits, s)
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (a, rates, splits, s)
+
+
+@pytest.mark.parametrize("ov", [dict(downsample=16, downsample_passes=4, report_levels=1),
+                                dict(downsample=16, downsample_passes=4, squelch_level=900),
+                                dict(downsample=42, rate_out=24000, report_levels=1, dc_block_raw=1),
+                                dict(downsample=128, downsample_passes=7, comp_fir_size=9, report_levels=1)])
+def test_per_buffer_levels(oracle_lib, ov):
+    """rtlfm_gpu_levels: `sr` of full_demod() (src/rtl_fm.c:1204-1237) — rms() of the decimated IQ of
+    every buffer, what the squelch compares and -L prints — against the oracle's rms() on the
+    decimated IQ it produces in raw mode for the same bytes."""
+    from rtlsdr_amd.demod import GpuDemod
+    lib = oracle_lib.oracle()
+    lib.orc_rms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.orc_rms.restype = C.c_int
+    L, nb, ns = 16384, 5, 4
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=606, amplitude=50.0)
+    iq[1, L:2 * L] = 127   # a silent buffer
+    iq[2] = synth.random_u8(1, L * nb, seed=9)[0]  # large samples: the uint32 sum of squares may wrap (rms() < 0)
+    raw_ov = {k: v for k, v in ov.items() if k not in ("squelch_level", "report_levels")}
+    raw_cfg = make_cfg(dict(raw_ov, mode=capi.MODE_RAW), L, 1)
+    with GpuDemod(cfg, ns, 0) as g:
+        o, n = g.run_torch(torch.from_numpy(iq).cuda()); g.sync()
+        got = [g.levels(s) for s in range(ns)]
+    for s in range(ns):
+        st = oracle_lib.new_states(1)[0]
+        scratch = np.zeros(2 * L + 64, dtype=np.int16)
+        want = []
+        for b in range(nb):
+            k = lib.orc_block(C.byref(raw_cfg), C.byref(st), np.ascontiguousarray(iq[s, b * L:(b + 1) * L]), L, scratch)
+            want.append(lib.orc_rms(scratch.ctypes.data, k, 1, int(cfg.dc_block_raw)))
+        assert list(got[s]) == want, (ov, s, list(got[s]), want)
