@@ -1005,7 +1005,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the MFMA
 	// form: its coalesced tile loads can be non-temporal (load_stream16), which removes the cost
 	// of mixing the PCM stores into the read stream, and with that it is the faster engine at
-	// every decimation depth on MI355X (tools/sweep_engines.sh, interleaved launches: 6 % at 4
+	// every decimation depth on MI355X (tools/ab_engines.py, interleaved launches: 6 % at 4
 	// passes, 11 % at 5).  The v_dot4 form needs no matrix pipe and no LDS staging.
 	int engine = ws.pass0_engine;
 	if (engine < 0) {

@@ -1,29 +1,46 @@
 #!/bin/bash
-# tools/collect_profiles.sh <tag> — on the GPU box: bench line, rocprofv3 kernel-trace stats
-# and PMC passes for the default workload; everything lands in gpurun_out/<tag>/ (copy the
-# summaries you want judged into profiles/ afterwards).
+# tools/collect_profiles.sh — on the GPU box: the bench lines, rocprofv3 kernel-trace stats and
+# PMC passes of every measured workload into gpurun_out/r02/ (copy what should be judged into
+# profiles/ afterwards).  One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
 set -u
-TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/$TAG
+OUT=$ROOT/gpurun_out/r02
 mkdir -p $OUT
 cd $ROOT
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-cat $OUT/bench.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 > $OUT/trace.log 2>&1
-cd $ROOT
-f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
-python3 - "$f" > $OUT/kernel_stats_top.txt <<'PY'
+python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+for w in ns4096 c1 c3 wbfm c4; do
+  python bench.py --workload $w --steps 100 --warmup 50 --cpu-seconds 6 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+done
+python bench.py --boxcar 10 --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_box10_std.json 2>/dev/null
+python bench.py --boxcar 6 --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_box6_std.json 2>/dev/null
+top() { # csv title
+python3 - "$1" "$2" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-print("rocprofv3 --kernel-trace --stats  (python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --check 0 --pmc 0 --sustain 0)")
-print(f"{'Name':70s} {'Calls':>6s} {'AvgNs':>12s} {'MinNs':>10s} {'MaxNs':>10s} {'Pct':>6s}")
-for r in rows[:12]:
-    print(f"{r['Name'][:70]:70s} {r['Calls']:>6s} {float(r['AverageNs']):12.0f} {r['MinNs']:>10s} {r['MaxNs']:>10s} {r['Percentage']:>6s}")
+print(sys.argv[2])
+print(f"{'Name':78s} {'Calls':>6s} {'AvgNs':>12s} {'MinNs':>10s} {'MaxNs':>10s} {'Pct':>6s}")
+for r in rows[:10]:
+    if r['Name'].startswith('void at::') or 'elementwise' in r['Name'] or 'distribution' in r['Name']:
+        continue
+    print(f"{r['Name'][:78]:78s} {r['Calls']:>6s} {float(r['AverageNs']):12.0f} {r['MinNs']:>10s} {r['MaxNs']:>10s} {r['Percentage']:>6s}")
 PY
-cat $OUT/kernel_stats_top.txt | grep -E "k_fused|Name"
-bash tools/prof_pmc.sh $TAG > $OUT/pmc.log 2>&1
-cp $ROOT/gpurun_out/pmc_$TAG/summary.txt $OUT/pmc_summary.txt
-cat $OUT/pmc_summary.txt
+}
+cd /tmp && export TMPDIR=/tmp
+# long enough that the clock ramp of the first launches after idle does not weigh on the averages
+COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0"
+for spec in "c2:" "ns4096:--workload ns4096" "box10:--boxcar 10" "box6:--boxcar 6" "c1:--workload c1" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
+  tag=${spec%%:*}; args=${spec#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 $ROOT/bench.py $COMMON $args > $OUT/trace_$tag.log 2>&1
+  f=$(find $OUT/trace_$tag -name "*kernel_stats.csv" | head -1)
+  top "$f" "rocprofv3 --kernel-trace --stats -- python3 bench.py $COMMON $args" > $OUT/kernel_stats_$tag.txt
+  rm -rf $OUT/trace_$tag
+done
+cd $ROOT
+bash tools/prof_pmc.sh r02_c2 > /dev/null 2>&1
+PMC_KERNEL=k_boxcar_scan bash tools/prof_pmc.sh r02_box10 --boxcar 10 > /dev/null 2>&1
+PMC_KERNEL=k_boxcar_scan bash tools/prof_pmc.sh r02_box6 --boxcar 6 > /dev/null 2>&1
+PMC_KERNEL=k_power_scan bash tools/prof_pmc.sh r02_c4 --workload c4 > /dev/null 2>&1
+for t in c2 box10 box6 c4; do cp $ROOT/gpurun_out/pmc_r02_$t/summary.txt $OUT/pmc_$t.txt; rm -rf $ROOT/gpurun_out/pmc_r02_$t; done
+du -sh $ROOT/gpurun_out
+head -3 $OUT/kernel_stats_*.txt
