@@ -171,6 +171,24 @@ __device__ __forceinline__ uint4 load_stream16(const uint8_t *p)
 	return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// With four or five passes the PCM (3-6 % of the bytes) leaves with the sc1 bit: written through
+// and dropped from the XCD's L2 instead of sitting there dirty until the read stream pushes it out
+// (interleaved A/B: -1.8 % at 4 passes, -1.4 % at 5, nothing at 6; nt stores +7 %; sc0 nothing;
+// where the PCM is a larger share - 2 passes, boxcar /6 - write-through costs 6-16 %).
+// Inline assembly, so the compiler's vmcnt bookkeeping does not see these stores: they are always
+// issued BEFORE the next tile's loads, and an older operation only makes an in-order vmcnt wait
+// wait for more, never for less.
+__device__ __forceinline__ void store_out8(void *p, uint32_t a, uint32_t b)
+{
+	typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+	const u32x2_t v = {a, b};
+	asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_out4(void *p, uint32_t a)
+{
+	asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(a) : "memory");
+}
+
 // dot4 / dot2 with a zero accumulator in the VOP3 form (inline constant 0):
 // hipcc otherwise emits v_mov 0 + the accumulate-in-place VOP2 form.
 __device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
@@ -496,9 +514,10 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	int16_t held[CZ];
 	int16_t *held_dst = nullptr;
 	auto flush_held = [&]() {
-		if (held_dst) {
-			int16_t *dst = held_dst;
+		if (held_dst && !(RTLFM_ABLATE & 16)) {
+			int16_t *dst = (RTLFM_ABLATE & 32) ? out_base + lane * CZ : held_dst;  // analysis builds (tools/ablate.sh): no stores / every tile to the same lines
 			if constexpr (CZ >= 8) {
+				// 1-3 passes: the PCM is 12-50 % of the bytes, and written through it costs (P = 2: +16 %)
 				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
 				for (int k = 0; k < CZ / 8; k++) {
@@ -508,9 +527,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					d4[k] = w;
 				}
 			} else if constexpr (CZ == 4) {
-				*reinterpret_cast<uint2 *>(dst) = make_uint2(pack_iq(held[0], held[1]), pack_iq(held[2], held[3]));
+				store_out8(dst, pack_iq(held[0], held[1]), pack_iq(held[2], held[3]));
 			} else if constexpr (CZ == 2) {
-				*reinterpret_cast<uint32_t *>(dst) = pack_iq(held[0], held[1]);
+				store_out4(dst, pack_iq(held[0], held[1]));
 			} else {
 				dst[0] = held[0];
 			}
