@@ -1,6 +1,10 @@
 #!/bin/bash
 # tools/ablate.sh build|run — cost attribution of the fused kernel by leaving parts out
 # (RTLFM_ABLATE, analysis only; results are wrong by construction, so bench runs with --check 0).
+# Bits: k_fused 1 no atan2, 2 / 4 / 8 no passes 1-3 / pass 0 / hand-offs, 16 no PCM stores, 32 PCM
+# stores to the same few lines (no write traffic leaves L2); k_boxcar_scan 1 no atan2, 2 no PCM
+# stores, 4 no outputs at all, 8 PCM stores to the same few lines.  For pairs of builds measured in
+# one process: tools/build_variant.sh + tools/ab_engines.py --libs.
 set -e
 cd "$(dirname "$0")/.."
 VARIANTS="0 1 2 4 8 3 6 7 15"
