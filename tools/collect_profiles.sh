@@ -1,18 +1,14 @@
 #!/bin/bash
-# tools/collect_profiles.sh — on the GPU box: the bench lines, rocprofv3 kernel-trace stats and
-# PMC passes of every measured workload into gpurun_out/r02/ (copy what should be judged into
-# profiles/ afterwards).  One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
+# tools/collect_profiles.sh — on the GPU box: for every measured workload the bench line, right
+# behind it the rocprofv3 kernel-trace stats of the same workload (the box drifts by a few per cent
+# over minutes at its power cap, so the two that have to agree are taken back to back), and PMC
+# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/r02/ (copy
+# what should be judged into profiles/ afterwards; the raw traces are deleted, they are large).
+# One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r02
 mkdir -p $OUT
-cd $ROOT
-python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-for w in ns4096 c1 c3 wbfm c4; do
-  python bench.py --workload $w --steps 100 --warmup 50 --cpu-seconds 6 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-done
-python bench.py --boxcar 10 --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_box10_std.json 2>/dev/null
-python bench.py --boxcar 6 --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_box6_std.json 2>/dev/null
 top() { # csv title
 python3 - "$1" "$2" <<'PY'
 import csv, sys
@@ -26,15 +22,21 @@ for r in rows[:10]:
     print(f"{r['Name'][:78]:78s} {r['Calls']:>6s} {float(r['AverageNs']):12.0f} {r['MinNs']:>10s} {r['MaxNs']:>10s} {r['Percentage']:>6s}")
 PY
 }
-cd /tmp && export TMPDIR=/tmp
 # long enough that the clock ramp of the first launches after idle does not weigh on the averages
 COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0"
-for spec in "c2:" "ns4096:--workload ns4096" "box10:--boxcar 10" "box6:--boxcar 6" "c1:--workload c1" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
+for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
   tag=${spec%%:*}; args=${spec#*:}
+  cd $ROOT
+  case $tag in
+    c2) python bench.py > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+    box*) python bench.py $args --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+    *) python bench.py $args --steps 100 --warmup 50 --cpu-seconds 6 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+  esac
+  cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 $ROOT/bench.py $COMMON $args > $OUT/trace_$tag.log 2>&1
   f=$(find $OUT/trace_$tag -name "*kernel_stats.csv" | head -1)
   top "$f" "rocprofv3 --kernel-trace --stats -- python3 bench.py $COMMON $args" > $OUT/kernel_stats_$tag.txt
-  rm -rf $OUT/trace_$tag
+  rm -rf $OUT/trace_$tag $OUT/trace_$tag.log
 done
 cd $ROOT
 bash tools/prof_pmc.sh r02_c2 > /dev/null 2>&1
