@@ -644,7 +644,6 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const int mcsp = T / Ls + 2;
 			const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
 			if (spec) HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
-			const bool skip_fb = spec && getenv("RTLFM_DEEMPH_NO_FALLBACK_MEASURE_ONLY");
 #define RTLFM_DEEMPH_SCAN(M)                                                                                        \
 	do {                                                                                                            \
 		RTLFM_DBG_SYNC("before deemph scan");                                                                          \
@@ -654,7 +653,6 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			k_lpr_fixup<<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcsp, Ls, h->d_lpr_chunks, lpr_dst, lpr_ds,       \
 			                               c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, nullptr, h->d_deemph_fb);   \
 			RTLFM_DBG_SYNC("one pass");                                                                                \
-			if (skip_fb) break; /* measurement only: silent streams would be left unfiltered */                      \
 		}                                                                                                            \
 		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
 		RTLFM_DBG_SYNC("a1");                                                                                          \
