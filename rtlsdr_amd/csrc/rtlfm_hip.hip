@@ -60,6 +60,8 @@ struct rtlfm_gpu {
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
 	int32_t *d_deemph_fb = nullptr;       // [nstreams] streams the one-pass filter hands to the four passes
+	double arb_rinv = 0;                  // k_deemph_spec_arb: RN(1 / len2) and whether it reproduces tick / len2
+	int arb_len2 = 0, arb_fast = 0;
 	int deemph_chunks = 0;
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
 	size_t deep_stride = 0;
@@ -639,14 +641,46 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			// W samples before it (staged_kernels.h, k_deemph_spec_lpr); the streams it cannot settle
 			// that way (silence) raise a flag and alone go through the four passes below.
 			const bool spec = fuse_lpr && !getenv("RTLFM_DEEMPH_FOUR_PASS");
-			const int32_t *only = spec ? h->d_deemph_fb : nullptr;
 			const int Ls = 2048, Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
+			// ... and where arbitrary_resample follows directly, on uniform buffers that it upsamples
+			// (config 3): one pass from the demodulated samples to the resampled output
+			// (staged_kernels.h, k_deemph_spec_arb), the same fall-back for the streams it flags
+			const int arb_l2 = (int)((long long)Nblk * c.rate_out2 / c.rate_out);
+			const size_t arb_lds = (size_t)(Ws / kArbChunk + 64) * kArbStride * sizeof(int16_t);
+			const bool spec_arb = tp.arb && !tp.adc && !tp.lpr && D == 1 && !varcnt && Nblk >= 2 && arb_l2 > Nblk &&
+			                      (long long)(Nblk + 1) * arb_l2 < (1ll << 31) && Ws <= 256 &&
+			                      (uintptr_t)cur % 16 == 0 && cur_stride % 8 == 0 && T == nblocks * Nblk &&
+			                      !getenv("RTLFM_DEEMPH_FOUR_PASS");
+			const int32_t *only = spec || spec_arb ? h->d_deemph_fb : nullptr;
+			int16_t *arb_dst = nullptr; size_t arb_ds = 0;
+			const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
+			if (spec_arb) {
+				if (h->arb_len2 != arb_l2) {
+					// frac = (double)tick / (double)len2 (src/rtl_fm.c:1122) as two fused multiply-adds with
+					// RN(1 / len2): used only if it is the division's result for every tick of this len2
+					h->arb_rinv = 1.0 / (double)arb_l2;
+					h->arb_fast = 1;
+					for (int t = 0; t <= arb_l2 && h->arb_fast; t++) {
+						const double dt = (double)t, q0 = dt * h->arb_rinv;
+						if (std::fma(std::fma(-q0, (double)arb_l2, dt), h->arb_rinv, q0) != dt / (double)arb_l2) h->arb_fast = 0;
+					}
+					h->arb_len2 = arb_l2;
+				}
+				next_dst(&arb_dst, &arb_ds);
+				HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
+			}
 			const int mcsp = T / Ls + 2;
 			const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
 			if (spec) HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
 #define RTLFM_DEEMPH_SCAN(M)                                                                                        \
 	do {                                                                                                            \
 		RTLFM_DBG_SYNC("before deemph scan");                                                                          \
+		if (spec_arb) {                                                                                              \
+			k_deemph_spec_arb<M><<<(unsigned)((size_t)S * arb_spans), 64, arb_lds, q>>>(                               \
+			    cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, h->arb_rinv, h->arb_fast, arb_dst,    \
+			    arb_ds, sin, sout, h->d_deemph_fb, h->d_cnt2);                                                         \
+			RTLFM_DBG_SYNC("one pass (arb)");                                                                          \
+		}                                                                                                            \
 		if (spec) {                                                                                                  \
 			k_deemph_spec_lpr<M><<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds,     \
 			                                         c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, h->d_deemph_fb); \
@@ -667,7 +701,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			k_lpr_fixup<<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
 			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, only);                        \
 		} else {                                                                                                     \
-			k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);     \
+			k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout, only); \
 		}                                                                                                            \
 		RTLFM_DBG_SYNC("c");                                                                                           \
 	} while (0)
@@ -675,6 +709,14 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			else if (magic) RTLFM_DEEMPH_SCAN(1);
 			else RTLFM_DEEMPH_SCAN(0);
 #undef RTLFM_DEEMPH_SCAN
+			if (spec_arb) {
+				k_arb_upsample_only<<<(unsigned)((size_t)S * nblocks), 256, 0, q>>>(cur, cur_stride, arb_dst, arb_ds, Nblk,
+				                                                                   arb_l2, nblocks, h->d_deemph_fb);
+				if (arb_dst != final_dst) return -EFAULT;  // routing bug
+				if (d_out_len)
+					HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt2, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+				return 0;
+			}
 		} else if (pow2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 		else if (magic) k_deemph<1><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);

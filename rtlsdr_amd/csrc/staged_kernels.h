@@ -736,12 +736,13 @@ k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout)
+                DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout,
+                const int32_t *__restrict__ only = nullptr)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams) return;
+	if (s >= (size_t)nstreams || (only && !only[s])) return;
 	if (incoming[s * max_chunks] == 0xffffffffu) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
@@ -1203,6 +1204,192 @@ k_arb_upsample(const int16_t *__restrict__ A, size_t astride, int16_t *__restric
 		if (i >= len1) { i = len1 - 1; tick = len2; }
 		double frac = (double)tick / (double)len2;
 		B[s * bstride + (size_t)e.out0 + j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
+	}
+}
+
+// ---- deemph_filter + arbitrary_upsample in one pass (config 3's audio tail) ---------------------
+// deemph_filter in place (four passes: the run is read twice and written once) followed by
+// k_arb_upsample (read again, written at len2 / len1) moves 5.4 bytes per demodulated sample; this
+// moves 3.4: the run is read once and only the resampled output is written.  A one-wave workgroup
+// takes a span of 64 chunks of 32 samples of one stream, plus the W samples before it, into LDS
+// with 16-byte loads; lane l settles the filter state at the start of chunk l from the W samples
+// before it as k_deemph_spec_lpr does (both extreme states walked until they meet; a stream where
+// they do not raises fallback[] and goes through the separate kernels afterwards), filters its
+// chunk in place in LDS, and then all lanes produce the span's outputs, coalesced: output j of a
+// buffer needs the filtered samples i - 1 and i with (i, tick) as the reference's loop has them
+// after j rounds, here advanced by 64 outputs at a time per lane.  frac = tick / len2 without a
+// division: q0 = tick * rinv, q = fma(fma(-q0, len2, tick), rinv, q0) with rinv = RN(1 / len2) is
+// the correctly rounded quotient - the host checks that against the division for every tick of
+// this len2 before it passes `fast` (0: divide).  Uniform buffers only (N samples each).
+// LDS: (W / 32 + 64) chunks at a stride of 40 int16 (16-byte accesses of 16 consecutive lanes fall
+// on different banks); 5.4 KB at W = 96, little enough to find room on a CU next to the front
+// end's waves, which hold nearly all of its LDS (a first form with 64 x 128 samples and a table of
+// fractions, 40 KB, waited for the front end to finish instead of running beside it).
+constexpr int kArbChunk = 32, kArbStride = 40;
+__device__ __forceinline__ int arb_first_output(int i, int len1, int len2)
+{
+	// first output whose left neighbour index is i - 1 (i.e. that reads samples i - 1 and i)
+	if (i <= 1) return 0;
+	if (i >= len1) return len2;
+	return (int)(((uint32_t)(i - 1) * (uint32_t)len2) / (uint32_t)len1) + 1;
+}
+
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
+                  int N, int len2, int nblocks, double rinv, int fast, int16_t *__restrict__ B, size_t bstride,
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ fallback,
+                  int32_t *__restrict__ cnt_out)
+{
+	extern __shared__ uint4 arb_lds[];
+	int16_t *y = reinterpret_cast<int16_t *>(arb_lds);
+	const int lane = (int)threadIdx.x;
+	const size_t s = blockIdx.x / (unsigned)spans;
+	const int sp = (int)(blockIdx.x % (unsigned)spans);
+	constexpr int C = kArbChunk, Cp = kArbStride, span = 64 * C;
+	const int pre = W / C;  // chunks before the span
+	const int k0 = sp * span, k1 = min(k0 + span, T);
+	const int16_t *r = R + s * rstride;
+	const int carried = sin[s].deemph_avg;
+	if (sp == 0 && lane == 0) cnt_out[s] = nblocks * len2;
+	if ((uint32_t)(carried + 32768) > 65535u) {  // only rtlfm_gpu_state_set can do that: deemph_plain in the separate kernels
+		if (sp == 0 && lane == 0) fallback[s] = 1;
+		return;
+	}
+	// samples [k0 - W, k0 + span), zero outside the run
+	for (int g = lane; g < (pre + 64) * (C / 8); g += 64) {
+		const int q = g >> 2, w = g & 3;
+		const int k = k0 - W + g * 8;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (k >= 0 && k + 8 <= T) v = *reinterpret_cast<const uint4 *>(r + k);
+		else if (k + 8 > 0 && k < T) {
+			uint32_t t[4] = {0, 0, 0, 0};
+			for (int j = 0; j < 8; j++)
+				if (k + j >= 0 && k + j < T) t[j >> 1] |= (uint32_t)(uint16_t)r[k + j] << (16 * (j & 1));
+			v = make_uint4(t[0], t[1], t[2], t[3]);
+		}
+		*reinterpret_cast<uint4 *>(y + q * Cp + w * 8) = v;
+	}
+	__syncthreads();
+	// the state at the start of this lane's chunk (chunk pre + lane of the array): from the `pre` chunks before it
+	const int begin = k0 + lane * C, end = min(begin + C, T);
+	uint32_t v = (uint32_t)(carried + 32768);
+	if (begin > 0 && begin < T) {
+		uint32_t lo = 0, hi = 65535;
+		if (begin < W) lo = hi = v;  // the run starts inside the window: from the carried state, over the samples there are
+		for (int c = 0; c < pre; c++) {
+			if (begin - (pre - c) * C < 0) continue;
+			const uint4 *wp = reinterpret_cast<const uint4 *>(y + (lane + c) * Cp);
+#pragma unroll
+			for (int g = 0; g < C / 8; g++) {
+				const uint4 q4 = wp[g];
+				const uint32_t w4[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const uint32_t b2 = w4[i] ^ 0x80008000u;
+					lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
+					lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
+				}
+			}
+		}
+		if (lo != hi) fallback[s] = 1;  // what this workgroup writes for the stream is replaced afterwards
+		v = lo;
+	}
+	__syncthreads();
+	// the filtered sample before the span (left neighbour of its first sample), then the chunk in place
+	if (lane == 0) y[pre * Cp - (Cp - C) - 1] = (int16_t)(uint16_t)(v ^ 0x8000u);
+	if (begin < T) {
+		int16_t *cp = y + (pre + lane) * Cp;
+		const int cntc = end - begin;
+		int k = 0;
+		for (; k + 8 <= cntc; k += 8) {
+			uint4 q4 = *reinterpret_cast<uint4 *>(cp + k);
+			uint32_t w4[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const uint32_t b2 = w4[i] ^ 0x80008000u;
+				v = ds.step<MAGIC>(b2 & 0xffffu, v);
+				const uint32_t l16 = v;
+				v = ds.step<MAGIC>(b2 >> 16, v);
+				w4[i] = ((l16 & 0xffffu) | (v << 16)) ^ 0x80008000u;
+			}
+			*reinterpret_cast<uint4 *>(cp + k) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+		}
+		for (; k < cntc; k++) {
+			v = ds.step<MAGIC>((uint32_t)(uint16_t)cp[k] ^ 0x8000u, v);
+			cp[k] = (int16_t)(uint16_t)(v ^ 0x8000u);
+		}
+		if (end == T) sout[s].deemph_avg = (int)v - 32768;
+	}
+	__syncthreads();
+	// arbitrary_upsample (src/rtl_fm.c:1114-1135) of the buffers that intersect the span
+	const int poff = pre * C;
+	auto at = [&](int rel) {  // filtered sample k0 + rel, rel >= -1
+		const int p = rel + poff;
+		return (int)y[(p >> 5) * Cp + (p & (C - 1))];
+	};
+	const int len1 = N;
+	const double dlen2 = (double)len2;
+	const uint32_t step_i = (64u * (uint32_t)len1) / (uint32_t)len2, step_t = (64u * (uint32_t)len1) % (uint32_t)len2;
+	for (int b = k0 / N; b <= (k1 - 1) / N; b++) {
+		const int base = b * N;
+		const int ia = max(k0, base) - base, ib = min(k1, base + N) - base;
+		const int j0 = arb_first_output(ia, len1, len2), j1 = arb_first_output(ib, len1, len2);
+		int j = j0 + lane;
+		if (j >= j1) continue;
+		int i, tick;
+		if (j == 0) { i = 1; tick = 0; }
+		else {
+			const uint32_t adv = (uint32_t)j * (uint32_t)len1;
+			const uint32_t q = (adv - 1u) / (uint32_t)len2;
+			i = 1 + (int)q;
+			tick = (int)(adv - q * (uint32_t)len2);
+		}
+		int16_t *bo = B + s * bstride + (size_t)b * len2;
+		const int rel0 = base - k0;
+		for (; j < j1; j += 64) {
+			int ii = i, tt = tick;
+			if (ii >= len1) { ii = len1 - 1; tt = len2; }
+			const double dt = (double)tt;
+			double frac;
+			if (fast) {
+				const double q0 = dt * rinv;
+				frac = fma(fma(-q0, dlen2, dt), rinv, q0);
+			} else {
+				frac = dt / dlen2;
+			}
+			bo[j] = (int16_t)(at(rel0 + ii - 1) * (1 - frac) + at(rel0 + ii) * frac);
+			// 64 outputs on: j * len1 = (i - 1) * len2 + tick with 0 < tick <= len2 (tick == 0 only at j == 0)
+			if (tick == 0) { i = 0; tick = len2; }
+			i += (int)step_i; tick += (int)step_t;
+			if (tick > len2) { tick -= len2; i++; }
+		}
+	}
+}
+
+// k_arb_upsample for the streams of a list (the ones k_deemph_spec_arb gave up on): one workgroup
+// per (stream, buffer), uniform buffers
+__global__ void __launch_bounds__(256)
+k_arb_upsample_only(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride, int N, int len2,
+                    int nblocks, const int32_t *__restrict__ only)
+{
+	const size_t s = blockIdx.x / (unsigned)nblocks;
+	const int b = (int)(blockIdx.x % (unsigned)nblocks);
+	if (!only[s]) return;
+	const int len1 = N;
+	const int16_t *a = A + s * astride + (size_t)b * N;
+	int16_t *bo = B + s * bstride + (size_t)b * len2;
+	for (int j = (int)threadIdx.x; j < len2; j += 256) {
+		int i = 1, tick = 0;
+		if (j) {
+			const uint32_t adv = (uint32_t)j * (uint32_t)len1;
+			const uint32_t q = (adv - 1u) / (uint32_t)len2;
+			i = 1 + (int)q;
+			tick = (int)(adv - q * (uint32_t)len2);
+		}
+		if (i >= len1) { i = len1 - 1; tick = len2; }
+		const double frac = (double)tick / (double)len2;
+		bo[j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
 	}
 }
 

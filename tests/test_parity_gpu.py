@@ -860,6 +860,49 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (a, rates, splits, s)
 
 
+@pytest.mark.parametrize("passes,L,nb,a,rates", [(6, 262144, 4, 2, (16000, 22050)),     # config 3: a span per buffer
+                                                 (5, 98304, 12, 2, (16000, 22050)),     # buffers of 1536 straddle the spans of 2048
+                                                 (6, 262144, 3, 5, (16000, 16100)),     # len2 = len1 + 12
+                                                 (4, 32768, 9, 12, (48000, 96000)),     # W = 256, the longest settling window it takes
+                                                 (4, 32768, 9, 13, (48000, 96000))])    # W = 320: the separate kernels
+def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
+    """deemph_filter followed directly by arbitrary_resample on uniform buffers (config 3's tail): one
+    pass from the demodulated samples to the resampled output (k_deemph_spec_arb).  Carried / injected
+    filter state (one stream outside int16: the plain form), a silent stream and one that falls silent
+    half way (flagged: the separate kernels redo them), runs split over launches."""
+    from rtlsdr_amd.demod import GpuDemod
+    ns = 6
+    ov = dict(downsample=1 << passes, downsample_passes=passes, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],
+              resampler=capi.RESAMPLE_ARBITRARY)
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=5100 + a, fs=1.024e6, dev_hz=5e3, amplitude=40.0)
+    iq[1] = 127
+    iq[2, L:L * 2] = 127
+    st0 = oracle_lib.new_states(ns)
+    for s in range(ns):
+        st0[s].deemph_avg = 1234 * s - 3000
+    st0[ns - 1].deemph_avg = -70000
+    st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
+    for splits in (None, [(0, 1), (1, nb)]):
+        outs = [[] for _ in range(ns)]
+        with GpuDemod(cfg, ns, 0) as g:
+            for s in range(ns):
+                g.state_set(s, st_copy[s])
+            d = torch.from_numpy(iq).cuda()
+            for b0, b1 in (splits or [(0, nb)]):
+                o, n = g.run_torch(d[:, b0 * L:b1 * L].contiguous()); g.sync()
+                o = o.cpu().numpy(); n = n.cpu().numpy()
+                for s in range(ns):
+                    outs[s].append(o[s, :n[s]].copy())
+            sts = [g.state_get(s) for s in range(ns)]
+        for s in range(ns):
+            got = np.concatenate(outs[s])
+            assert got.shape[0] == want_len[s], (splits, s)
+            assert_parity(got, want[s, :want_len[s]], cfg, f"{splits} stream {s}")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (splits, s)
+
+
 @pytest.mark.parametrize("ov", [dict(downsample=16, downsample_passes=4, report_levels=1),
                                 dict(downsample=16, downsample_passes=4, squelch_level=900),
                                 dict(downsample=42, rate_out=24000, report_levels=1, dc_block_raw=1),
