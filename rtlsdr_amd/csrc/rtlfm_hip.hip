@@ -632,6 +632,8 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			// resampler's accumulator instead of writing the filtered samples (staged_kernels.h)
 			fuse_lpr = tp.lpr && !tp.adc && !getenv("RTLFM_LPR_SEPARATE");
 			if (fuse_lpr) next_dst(&lpr_dst, &lpr_ds);
+			// outputs leave in 16-byte groups where the rows allow it (staged_kernels.h, LprSink)
+			const int lpr_vec = fuse_lpr && (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !getenv("RTLFM_LPR_SCALAR_STORES");
 			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
 			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
 			const size_t per_wave = 64 / lpc;
@@ -641,7 +643,19 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			// W samples before it (staged_kernels.h, k_deemph_spec_lpr); the streams it cannot settle
 			// that way (silence) raise a flag and alone go through the four passes below.
 			const bool spec = fuse_lpr && !getenv("RTLFM_DEEMPH_FOUR_PASS");
-			const int Ls = 2048, Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
+			const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
+			// chunk length of the one-pass form: about 2720 samples (2040: +1 %, 1360: +2 % on the wbfm step),
+			// and a multiple of the resampler's period fast / gcd(fast, slow) where that is short - then all
+			// chunks of a stream start at the same phase, the lanes of a wave emit at the same samples and
+			// the emission branch is taken by whole waves instead of by a few lanes every sample
+			int Ls = 2720;
+			if (tp.lpr && c.rate_out2 > 0) {
+				long long g = c.rate_out, b = c.rate_out2;
+				while (b) { const long long t = g % b; g = b; b = t; }
+				long long per = c.rate_out / g;
+				while (per % 8) per *= 2;
+				if (per <= 2720) Ls = (int)(per * ((2720 + per / 2) / per));
+			}
 			// ... and where arbitrary_resample follows directly, on uniform buffers that it upsamples
 			// (config 3): one pass from the demodulated samples to the resampled output
 			// (staged_kernels.h, k_deemph_spec_arb), the same fall-back for the streams it flags
@@ -683,7 +697,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		}                                                                                                            \
 		if (spec) {                                                                                                  \
 			k_deemph_spec_lpr<M><<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds,     \
-			                                         c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, h->d_deemph_fb); \
+			                                         c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, h->d_deemph_fb); \
 			k_lpr_fixup<<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcsp, Ls, h->d_lpr_chunks, lpr_dst, lpr_ds,       \
 			                               c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, nullptr, h->d_deemph_fb);   \
 			RTLFM_DBG_SYNC("one pass");                                                                                \
@@ -697,7 +711,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		RTLFM_DBG_SYNC("b");                                                                                           \
 		if (fuse_lpr) {                                                                                              \
 			k_deemph_scan_c_lpr<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst,  \
-			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, only); \
+			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, only); \
 			k_lpr_fixup<<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
 			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, only);                        \
 		} else {                                                                                                     \

@@ -799,19 +799,22 @@ __device__ __forceinline__ uint32_t deemph_walk_sink(const int16_t *r, int n, ui
 			sink((int)(int16_t)(uint16_t)(avgb ^ 0x8000u));
 		}
 	};
-	if (k + 64 <= n) {
-		uint4 cur[8], nxt[8];
+	// 16-byte groups / samples in flight ahead of the walk.  (With four groups and 62 registers a wave of
+	// this fits beside four waves of k_boxcar_scan<true> on a SIMD: 1 % on the wbfm step, and slower alone.)
+	constexpr int NG = 8, NS = 8 * NG;
+	if (k + NS <= n) {
+		uint4 cur[NG], nxt[NG];
 #pragma unroll
-		for (int j = 0; j < 8; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
-		for (; k + 64 <= n; k += 64) {
-			const bool more = k + 128 <= n;
-			const uint4 *np = reinterpret_cast<const uint4 *>(r + (more ? k + 64 : k));
+		for (int j = 0; j < NG; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
+		for (; k + NS <= n; k += NS) {
+			const bool more = k + 2 * NS <= n;
+			const uint4 *np = reinterpret_cast<const uint4 *>(r + (more ? k + NS : k));
 #pragma unroll
-			for (int j = 0; j < 8; j++) nxt[j] = np[j];
+			for (int j = 0; j < NG; j++) nxt[j] = np[j];
 #pragma unroll
-			for (int j = 0; j < 8; j++) group(cur[j]);
+			for (int j = 0; j < NG; j++) group(cur[j]);
 #pragma unroll
-			for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+			for (int j = 0; j < NG; j++) cur[j] = nxt[j];
 		}
 	}
 	for (; k + 8 <= n; k += 8) group(*reinterpret_cast<const uint4 *>(r + k));
@@ -819,10 +822,87 @@ __device__ __forceinline__ uint32_t deemph_walk_sink(const int16_t *r, int n, ui
 	return avgb;
 }
 
+// C's int / d for a divisor fixed over a walk (low_pass_real's fast / slow): the magic number of
+// d for 31-bit magnitudes, one v_mul_hi per quotient instead of the ~40 instructions of the
+// expanded division
+struct ConstDiv {
+	uint32_t M;
+	int sh, d;
+	__device__ __forceinline__ explicit ConstDiv(int d_) : M(0), sh(0), d(d_)
+	{
+		if (d >= 2) {
+			const int l = 32 - __clz(d - 1);  // ceil(log2 d)
+			M = (uint32_t)(((1ull << (31 + l)) + (unsigned)d - 1u) / (unsigned)d);
+			sh = l - 1;
+		}
+	}
+	__device__ __forceinline__ int operator()(int n) const
+	{
+		if (d < 2) return n;  // fast / slow >= 1
+		if (n == INT32_MIN) return n / d;
+		const uint32_t a = n < 0 ? 0u - (uint32_t)n : (uint32_t)n;
+		const uint32_t q = __umulhi(a, M) >> sh;
+		return n < 0 ? (int)(0u - q) : (int)q;
+	}
+};
+
 struct LprChunk {
 	uint32_t head;   // accumulator at the chunk's first emission (the part of the straddling output that lies in this chunk)
 	uint32_t tail;   // accumulator at the chunk's end
 	int32_t mfirst;  // index of the output of the first emission, -1: the chunk emitted nothing
+};
+
+// The reference's accumulator (now_lpr += y; prev_lpr_index += slow; emit when it reaches fast,
+// src/rtl_fm.c:755-775) fed by the lane that walks a chunk.  Every lane of a wave writes a row of
+// its own, so a 2-byte store per output is 64 partial writes to 64 different lines per
+// instruction, and a line collects its 64 outputs over ~20000 cycles - long enough to be evicted
+// half written again and again (the emission was 60 % of the one-pass kernel's time).  Outputs are
+// therefore shifted into a 16-byte register group and stored eight at a time (`vec`: the output
+// rows are 16-byte aligned); the outputs before the chunk's first multiple of eight and after its
+// last one go out one by one.  The first emission of a chunk other than the stream's first belongs
+// to an output that began in the chunk before: its value is put together by k_lpr_fixup from
+// head, what is stored for it here is overwritten there.
+struct LprSink {
+	int16_t *bo;
+	int m, phi, sl, fa, first_full;
+	uint32_t acc;
+	uint32_t p0, p1, p2, p3;  // the last eight outputs, oldest in the low half of p0
+	ConstDiv cdiv;
+	LprChunk out;
+	__device__ __forceinline__ LprSink(int16_t *bo_, int m_, int phi_, int slow, int fast, uint32_t acc_, bool vec)
+	    : bo(bo_), m(m_), phi(phi_), sl(slow), fa(fast), first_full(vec ? ((m_ + 7) & ~7) : INT32_MAX), acc(acc_), p0(0), p1(0),
+	      p2(0), p3(0), cdiv(fast / slow)
+	{
+		out.mfirst = -1; out.head = 0; out.tail = 0;
+	}
+	__device__ __forceinline__ void operator()(int y)
+	{
+		acc += (uint32_t)y;
+		phi += sl;
+		if (phi >= fa) {
+			if (out.mfirst < 0) { out.mfirst = m; out.head = acc; }
+			const uint32_t q = (uint32_t)cdiv((int)acc);
+			p0 = __builtin_amdgcn_alignbit(p1, p0, 16);
+			p1 = __builtin_amdgcn_alignbit(p2, p1, 16);
+			p2 = __builtin_amdgcn_alignbit(p3, p2, 16);
+			p3 = (p3 >> 16) | (q << 16);
+			if (m < first_full) bo[m] = (int16_t)q;
+			m++;
+			if ((m & 7) == 0 && m > first_full) *reinterpret_cast<uint4 *>(bo + m - 8) = make_uint4(p0, p1, p2, p3);
+			phi -= fa;
+			acc = 0;
+		}
+	}
+	__device__ __forceinline__ void finish()  // the outputs after the last full group
+	{
+		out.tail = acc;
+		const int nrem = m & 7;
+		if (m - nrem < first_full) return;  // written one by one already (or `vec` is off)
+		const uint32_t p[4] = {p0, p1, p2, p3};
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if (j >= 8 - nrem) bo[m - 8 + j] = (int16_t)(p[j >> 1] >> (16 * (j & 1)));
+	}
 };
 
 template <int MAGIC>
@@ -830,7 +910,7 @@ __global__ void __launch_bounds__(64)
 k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                     DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, int16_t *__restrict__ B,
                     size_t bstride, int fast, int slow, const state_t *__restrict__ sin, state_t *__restrict__ sout,
-                    LprChunk *__restrict__ lc, const int32_t *__restrict__ only = nullptr)
+                    LprChunk *__restrict__ lc, int vec, const int32_t *__restrict__ only = nullptr)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
@@ -845,31 +925,13 @@ k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const 
 	deemph_chunk_range(c, n, head, L, begin, end);
 	// a stream whose carried deemph state lay outside int16 was filtered in place by pass B (plain form)
 	const bool filter = incoming[s * max_chunks] != 0xffffffffu;
-	const int div = fast / slow;
 	const long long p0 = sin[s].prev_lpr_index;
 	const long long idx0 = p0 + (long long)begin * slow;
-	int m = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
-	long long ph = idx0 - (long long)m * fast;
-	uint32_t acc = c == 0 ? (uint32_t)sin[s].now_lpr : 0u;
-	LprChunk out;
-	out.mfirst = -1; out.head = 0;
-	int16_t *bo = B + s * bstride;
-	const int sl = slow, fa = fast;
-	int phi = (int)ph;  // < fast + slow
-	auto sink = [&](int y) {
-		acc += (uint32_t)y;
-		phi += sl;
-		if (phi >= fa) {
-			if (out.mfirst < 0 && c > 0) { out.mfirst = m; out.head = acc; }
-			else { if (out.mfirst < 0) out.mfirst = m; bo[m] = (int16_t)((int)acc / div); }
-			m++;
-			phi -= fa;
-			acc = 0;
-		}
-	};
+	const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
+	LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
 	const uint32_t v = deemph_walk_sink<MAGIC>(r + begin, end - begin, filter ? incoming[s * max_chunks + c] : 0u, ds, filter, sink);
-	out.tail = acc;
-	lc[s * max_chunks + c] = out;
+	sink.finish();
+	lc[s * max_chunks + c] = sink.out;
 	if (filter && c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
 
@@ -911,7 +973,7 @@ template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_spec_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                   DeemphStep ds, int max_chunks, int L, int W, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
-                  const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *__restrict__ lc,
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *__restrict__ lc, int vec,
                   int32_t *__restrict__ fallback)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -945,30 +1007,13 @@ k_deemph_spec_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const in
 			v = lo;
 		}
 	}
-	const int div = fast / slow;
 	const long long p0 = sin[s].prev_lpr_index;
 	const long long idx0 = p0 + (long long)begin * slow;
-	int m = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
-	uint32_t acc = c == 0 ? (uint32_t)sin[s].now_lpr : 0u;
-	LprChunk out;
-	out.mfirst = -1; out.head = 0;
-	int16_t *bo = B + s * bstride;
-	const int sl = slow, fa = fast;
-	int phi = (int)(idx0 - (long long)m * fast);
-	auto sink = [&](int y) {
-		acc += (uint32_t)y;
-		phi += sl;
-		if (phi >= fa) {
-			if (out.mfirst < 0 && c > 0) { out.mfirst = m; out.head = acc; }
-			else { if (out.mfirst < 0) out.mfirst = m; bo[m] = (int16_t)((int)acc / div); }
-			m++;
-			phi -= fa;
-			acc = 0;
-		}
-	};
+	const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
+	LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
 	v = deemph_walk_sink<MAGIC>(r + begin, end - begin, v, ds, true, sink);
-	out.tail = acc;
-	lc[s * max_chunks + c] = out;
+	sink.finish();
+	lc[s * max_chunks + c] = sink.out;
 	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
 }
 

@@ -819,15 +819,19 @@ def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
         assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
 
 
-@pytest.mark.parametrize("a,rates", [(13, (170000, 32000)), (2, (48000, 11025)), (30, (240000, 96000)), (9, (170000, 169999))])
-def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates):
+@pytest.mark.parametrize("a,rates,scalar", [(13, (170000, 32000), 0), (2, (48000, 11025), 0), (30, (240000, 96000), 0),
+                                            (9, (170000, 169999), 0), (13, (170000, 32000), 1)])
+def test_deemph_replay_feeds_low_pass_real(oracle_lib, monkeypatch, a, rates, scalar):
     """deemph_filter followed directly by low_pass_real on long runs (-M wbfm's tail): the time-parallel
     filter's replay pass feeds the resampler's accumulator itself; outputs that straddle chunk
     boundaries are put together afterwards.  Carried / injected accumulator, phase and filter state
     (one stream with a filter state outside int16: the plain form), a silent stream and one that falls
     silent half way (there the one-pass filter cannot settle its chunks and hands the stream to the
-    four passes), runs split over launches."""
+    four passes), runs split over launches.  The resampler's outputs leave in 16-byte groups
+    (LprSink); `scalar`: one by one, as for output rows that are not 16-byte aligned."""
     from rtlsdr_amd.demod import GpuDemod
+    if scalar:
+        monkeypatch.setenv("RTLFM_LPR_SCALAR_STORES", "1")
     L, nb, ns = 32768, 6, 6
     ov = dict(downsample=6, custom_atan=1, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],
               resampler=capi.RESAMPLE_LOW_PASS_REAL)
