@@ -427,7 +427,7 @@ class FmJob:
                                            amplitude=amp, first_stream=rank * S)
         self.g = GpuDemod(self.cfg, S, local_rank)
         self.g.set_path(a.path)
-        cap = self.g.result_cap(NB)
+        cap = self.g.result_cap(NB) + int(os.environ.get("RTLFM_BENCH_ROW_PAD", "0"))  # experiments: rows off the 128-byte lines
         self.out = torch.empty((S, cap), dtype=torch.int16, device=dev)
         self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
         self.local_rank = local_rank

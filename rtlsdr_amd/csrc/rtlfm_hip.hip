@@ -297,7 +297,7 @@ static int create_body(rtlfm_gpu *h)
 		const size_t n0 = L / 2;
 		const size_t per = cfg->downsample_passes > 0 ? n0 >> cfg->downsample_passes
 		                                              : (cfg->downsample > 1 ? n0 / cfg->downsample + 1 : n0);
-		h->tstride = ((size_t)h->cap_blocks * per + 64 + 7) & ~(size_t)7;
+		h->tstride = ((size_t)h->cap_blocks * per + 64 + 63) & ~(size_t)63;
 	}
 	HIP_TRY(hipMalloc(&h->d_cnt2, S * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_mute, S * h->cap_blocks * sizeof(int32_t)));
@@ -1203,7 +1203,7 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 	const size_t S = (size_t)h->nstreams;
 	const size_t bytes = S * h->cap_blocks * h->cfg.block_len;
 	HIP_TRY(hipSetDevice(h->device));
-	in->ostride = ((size_t)rtlfm_result_cap(&h->cfg) * h->cap_blocks + 16 + 7) & ~(size_t)7;
+	in->ostride = ((size_t)rtlfm_result_cap(&h->cfg) * h->cap_blocks + 16 + 63) & ~(size_t)63;
 	HIP_TRY(hipStreamCreateWithFlags(&in->copy_stream, hipStreamNonBlocking));
 	for (int k = 0; k < 2; k++) {
 		HIP_TRY(hipHostMalloc(&in->h_stage[k], bytes, hipHostMallocDefault));

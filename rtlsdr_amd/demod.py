@@ -77,7 +77,7 @@ class GpuDemod:
     # -- device-resident form ------------------------------------------------
     def result_cap(self, nblocks: int) -> int:
         c = self.lib.rtlfm_result_cap(C.byref(self.cfg)) * nblocks + 16
-        return (c + 7) & ~7
+        return (c + 63) & ~63  # rows start on 128-byte lines: the front end's tile stores then cover whole lines
 
     def run_device(self, d_iq_ptr: int, stream_stride: int, nblocks: int, d_out_ptr: int,
                    out_stride: int, d_out_len_ptr: int = 0):
