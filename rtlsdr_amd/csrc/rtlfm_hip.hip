@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -60,6 +61,7 @@ struct rtlfm_gpu {
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
 	int32_t *d_deemph_fb = nullptr;       // [nstreams] streams the one-pass filter hands to the four passes
+	int32_t *d_deemph_list = nullptr;     // [1 + nstreams] ... compacted: count, then indices (k_flag_list)
 	double arb_rinv = 0;                  // k_deemph_spec_arb: RN(1 / len2) and whether it reproduces tick / len2
 	int arb_len2 = 0, arb_fast = 0;
 	int deemph_chunks = 0;
@@ -358,7 +360,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_deemph_fb, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_deemph_fb, h->d_deemph_list, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -626,6 +628,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				h->deemph_chunks = mc;
 			}
 			if (!h->d_deemph_fb) HIP_TRY(hipMalloc(&h->d_deemph_fb, (size_t)S * sizeof(int32_t)));
+			if (!h->d_deemph_list) HIP_TRY(hipMalloc(&h->d_deemph_list, ((size_t)S + 1) * sizeof(int32_t)));
 			const int mcs = mc;
 			const bool dbg_sync = getenv("RTLFM_TAIL_SYNC") != nullptr;
 			// deemph_filter followed directly by low_pass_real (-M wbfm): the replay pass feeds the
@@ -665,7 +668,9 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			                      (long long)(Nblk + 1) * arb_l2 < (1ll << 31) && Ws <= 256 &&
 			                      (uintptr_t)cur % 16 == 0 && cur_stride % 8 == 0 && T == nblocks * Nblk &&
 			                      !getenv("RTLFM_DEEMPH_FOUR_PASS");
-			const int32_t *only = spec || spec_arb ? h->d_deemph_fb : nullptr;
+			// the four passes (and the separate resampler) afterwards: for every stream, or - behind a
+			// one-pass kernel - for the streams it flagged, listed by k_flag_list and walked by small grids
+			const int32_t *only = spec || spec_arb ? h->d_deemph_list : nullptr;
 			int16_t *arb_dst = nullptr; size_t arb_ds = 0;
 			const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
 			if (spec_arb) {
@@ -686,6 +691,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const int mcsp = T / Ls + 2;
 			const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
 			if (spec) HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
+			const unsigned gcl = only ? std::min(gc, 1024u) : gc, gal = only ? std::min(ga, 1024u) : ga;
 #define RTLFM_DEEMPH_SCAN(M)                                                                                        \
 	do {                                                                                                            \
 		RTLFM_DBG_SYNC("before deemph scan");                                                                          \
@@ -702,20 +708,21 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			                               c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, nullptr, h->d_deemph_fb);   \
 			RTLFM_DBG_SYNC("one pass");                                                                                \
 		}                                                                                                            \
-		k_deemph_scan_a1<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
+		if (only) k_flag_list<<<1, 256, 0, q>>>(h->d_deemph_fb, S, h->d_deemph_list);                               \
+		k_deemph_scan_a1<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
 		RTLFM_DBG_SYNC("a1");                                                                                          \
-		k_deemph_scan_a2<M><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
+		k_deemph_scan_a2<M><<<gal, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
 		RTLFM_DBG_SYNC("a2");                                                                                          \
-		k_deemph_scan_b<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
+		k_deemph_scan_b<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
 		                                       h->d_deemph_inc, sin, sout, only);                                   \
 		RTLFM_DBG_SYNC("b");                                                                                           \
 		if (fuse_lpr) {                                                                                              \
-			k_deemph_scan_c_lpr<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst,  \
+			k_deemph_scan_c_lpr<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst,  \
 			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, only); \
-			k_lpr_fixup<<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
+			k_lpr_fixup<<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
 			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, only);                        \
 		} else {                                                                                                     \
-			k_deemph_scan_c<M><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout, only); \
+			k_deemph_scan_c<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout, only); \
 		}                                                                                                            \
 		RTLFM_DBG_SYNC("c");                                                                                           \
 	} while (0)
@@ -724,8 +731,8 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			else RTLFM_DEEMPH_SCAN(0);
 #undef RTLFM_DEEMPH_SCAN
 			if (spec_arb) {
-				k_arb_upsample_only<<<(unsigned)((size_t)S * nblocks), 256, 0, q>>>(cur, cur_stride, arb_dst, arb_ds, Nblk,
-				                                                                   arb_l2, nblocks, h->d_deemph_fb);
+				k_arb_upsample_only<<<(unsigned)std::min((size_t)S * nblocks, (size_t)1024), 256, 0, q>>>(
+				    cur, cur_stride, arb_dst, arb_ds, Nblk, arb_l2, nblocks, h->d_deemph_list);
 				if (arb_dst != final_dst) return -EFAULT;  // routing bug
 				if (d_out_len)
 					HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt2, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));

@@ -587,6 +587,40 @@ __device__ __forceinline__ int deemph_chunks(int n, int head, int L)
 	return m <= L ? 1 : (m + L - 1) / L;
 }
 
+// (stream, chunk) pairs for the kernels of the four-pass filter.  Without a list: every stream of
+// the handle, one pair per lane (or per `lanes` lanes), the grid covers nstreams * max_chunks
+// pairs.  With a list (list[0] = count, then stream indices: the streams the one-pass kernels
+// flagged, k_flag_list): only those, walked grid-stride by whatever small grid was launched - the
+// host does not know the count, and a full grid of workgroups that look at a flag and leave costs
+// 0.04-0.3 ms per run of the wbfm tail (175 000 workgroups for pass A2 alone).
+template <class Body>
+__device__ __forceinline__ void for_stream_chunks(int nstreams, int max_chunks, const int32_t *__restrict__ list, int lanes, Body body)
+{
+	const int per_wg = 64 / lanes;
+	const int sub = (int)threadIdx.x % lanes, slot = (int)threadIdx.x / lanes;
+	if (!list) {
+		const size_t g = (size_t)blockIdx.x * per_wg + slot;
+		const size_t s = g / max_chunks;
+		if (s < (size_t)nstreams) body(s, (int)(g % max_chunks), sub);
+		return;
+	}
+	const size_t total = (size_t)list[0] * max_chunks;
+	for (size_t g = (size_t)blockIdx.x * per_wg + slot; g < total; g += (size_t)gridDim.x * per_wg)
+		body((size_t)list[1 + g / max_chunks], (int)(g % max_chunks), sub);
+}
+
+// the streams with a raised flag, compacted: list[0] = count, list[1..] = indices (any order)
+__global__ void __launch_bounds__(256) k_flag_list(const int32_t *__restrict__ flags, int nstreams, int32_t *__restrict__ list)
+{
+	__shared__ int n;
+	if (threadIdx.x == 0) n = 0;
+	__syncthreads();
+	for (int s = (int)threadIdx.x; s < nstreams; s += 256)
+		if (flags[s]) list[1 + atomicAdd(&n, 1)] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) list[0] = n;
+}
+
 // A1: one lane per chunk walks the two extreme states through the whole chunk.  It records where
 // the interval first fits a lane group of pass A2 (k, lo_k, hi_k) and whether the two states have
 // merged by the end of the chunk - then the outgoing state does not depend on the incoming one
@@ -597,10 +631,7 @@ k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
                  DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab,
                  const int32_t *__restrict__ only = nullptr)
 {
-	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams || (only && !only[s])) return;
+	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -655,6 +686,7 @@ k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
 	} else {
 		t->lo = (int32_t)lo_k; t->k = kfit; t->n = kfit < 0 ? 0 : (int32_t)(hi_k - lo_k + 1);
 	}
+	});
 }
 
 // A2: for the chunks A1 left unmerged, lpc lanes per chunk (a power of two >= 2a + 3), one lane per
@@ -665,11 +697,7 @@ k_deemph_scan_a2(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
                  DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab,
                  const int32_t *__restrict__ only = nullptr)
 {
-	const int sub = threadIdx.x & (lpc - 1);
-	const size_t g = (size_t)blockIdx.x * (64 / lpc) + threadIdx.x / lpc;  // (stream, chunk) index
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams || (only && !only[s])) return;
+	for_stream_chunks(nstreams, max_chunks, only, lpc, [&](const size_t s, const int c, const int sub) {
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -682,6 +710,7 @@ k_deemph_scan_a2(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
 	uint32_t v = (uint32_t)t->lo + (uint32_t)(sub < nc ? sub : nc - 1);
 	v = deemph_walk<MAGIC, false>(r + begin + k, end - begin - k, v, ds);
 	if (sub < nc) t->table[sub] = (int16_t)(uint16_t)(v ^ 0x8000u);
+	});
 }
 
 // B: the incoming state of every chunk, one lane per chunk.  A merged chunk fixes its successor's
@@ -695,10 +724,7 @@ k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
                 DeemphStep ds, int max_chunks, int L, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
                 const state_t *__restrict__ sin, state_t *__restrict__ sout, const int32_t *__restrict__ only = nullptr)
 {
-	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams || (only && !only[s])) return;
+	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	uint32_t *inc = incoming + s * max_chunks;
@@ -731,6 +757,7 @@ k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 		}
 	}
 	inc[c] = v;
+	});
 }
 
 template <int MAGIC>
@@ -739,10 +766,7 @@ k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
                 DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout,
                 const int32_t *__restrict__ only = nullptr)
 {
-	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams || (only && !only[s])) return;
+	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
 	if (incoming[s * max_chunks] == 0xffffffffu) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
@@ -753,6 +777,7 @@ k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 	deemph_chunk_range(c, n, head, L, begin, end);
 	const uint32_t v = deemph_walk<MAGIC, true>(r + begin, end - begin, incoming[s * max_chunks + c], ds);
 	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+	});
 }
 
 // floor(a / b) for 0 <= a < 2^52, 0 < b < 2^31: the operands are exact in fp64, the correctly
@@ -912,10 +937,7 @@ k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const 
                     size_t bstride, int fast, int slow, const state_t *__restrict__ sin, state_t *__restrict__ sout,
                     LprChunk *__restrict__ lc, int vec, const int32_t *__restrict__ only = nullptr)
 {
-	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams || (only && !only[s])) return;
+	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	const int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -933,6 +955,7 @@ k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const 
 	sink.finish();
 	lc[s * max_chunks + c] = sink.out;
 	if (filter && c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+	});
 }
 
 // ---- one pass instead of A1 / A2 / B / C --------------------------------------------------------
@@ -1024,10 +1047,8 @@ k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t 
             const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out,
             const int32_t *__restrict__ only = nullptr, const int32_t *__restrict__ skip = nullptr)
 {
-	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams || (only && !only[s]) || (skip && skip[s])) return;
+	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
+	if (skip && skip[s]) return;
 	const int n = cnt ? cnt[s] : T;
 	const int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -1053,6 +1074,7 @@ k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t 
 		sout[s].prev_lpr_index = (int)(tot - (long long)E * fast);
 		cnt_out[s] = E;
 	}
+	});
 }
 
 // dc_block_audio_filter (src/rtl_fm.c:1028-1041) works on whatever result_len a buffer has.
@@ -1412,29 +1434,31 @@ k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstr
 	}
 }
 
-// k_arb_upsample for the streams of a list (the ones k_deemph_spec_arb gave up on): one workgroup
-// per (stream, buffer), uniform buffers
+// k_arb_upsample for the streams of a list (the ones k_deemph_spec_arb gave up on, k_flag_list):
+// a workgroup per (listed stream, buffer), grid-stride; uniform buffers
 __global__ void __launch_bounds__(256)
 k_arb_upsample_only(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride, int N, int len2,
-                    int nblocks, const int32_t *__restrict__ only)
+                    int nblocks, const int32_t *__restrict__ list)
 {
-	const size_t s = blockIdx.x / (unsigned)nblocks;
-	const int b = (int)(blockIdx.x % (unsigned)nblocks);
-	if (!only[s]) return;
-	const int len1 = N;
-	const int16_t *a = A + s * astride + (size_t)b * N;
-	int16_t *bo = B + s * bstride + (size_t)b * len2;
-	for (int j = (int)threadIdx.x; j < len2; j += 256) {
-		int i = 1, tick = 0;
-		if (j) {
-			const uint32_t adv = (uint32_t)j * (uint32_t)len1;
-			const uint32_t q = (adv - 1u) / (uint32_t)len2;
-			i = 1 + (int)q;
-			tick = (int)(adv - q * (uint32_t)len2);
+	const size_t total = (size_t)list[0] * nblocks;
+	for (size_t w = blockIdx.x; w < total; w += gridDim.x) {
+		const size_t s = (size_t)list[1 + w / nblocks];
+		const int b = (int)(w % nblocks);
+		const int len1 = N;
+		const int16_t *a = A + s * astride + (size_t)b * N;
+		int16_t *bo = B + s * bstride + (size_t)b * len2;
+		for (int j = (int)threadIdx.x; j < len2; j += 256) {
+			int i = 1, tick = 0;
+			if (j) {
+				const uint32_t adv = (uint32_t)j * (uint32_t)len1;
+				const uint32_t q = (adv - 1u) / (uint32_t)len2;
+				i = 1 + (int)q;
+				tick = (int)(adv - q * (uint32_t)len2);
+			}
+			if (i >= len1) { i = len1 - 1; tick = len2; }
+			const double frac = (double)tick / (double)len2;
+			bo[j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
 		}
-		if (i >= len1) { i = len1 - 1; tick = len2; }
-		const double frac = (double)tick / (double)len2;
-		bo[j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
 	}
 }
 
