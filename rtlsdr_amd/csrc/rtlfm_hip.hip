@@ -708,7 +708,10 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			                               c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, nullptr, h->d_deemph_fb);   \
 			RTLFM_DBG_SYNC("one pass");                                                                                \
 		}                                                                                                            \
-		if (only) k_flag_list<<<1, 256, 0, q>>>(h->d_deemph_fb, S, h->d_deemph_list);                               \
+		if (only) {                                                                                                  \
+			HIP_TRY(hipMemsetAsync(h->d_deemph_list, 0, sizeof(int32_t), q));                                          \
+			k_flag_list<<<(unsigned)((S + 255) / 256), 64, 0, q>>>(h->d_deemph_fb, S, h->d_deemph_list);               \
+		}                                                                                                            \
 		k_deemph_scan_a1<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
 		RTLFM_DBG_SYNC("a1");                                                                                          \
 		k_deemph_scan_a2<M><<<gal, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \

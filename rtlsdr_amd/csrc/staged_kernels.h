@@ -609,16 +609,15 @@ __device__ __forceinline__ void for_stream_chunks(int nstreams, int max_chunks, 
 		body((size_t)list[1 + g / max_chunks], (int)(g % max_chunks), sub);
 }
 
-// the streams with a raised flag, compacted: list[0] = count, list[1..] = indices (any order)
-__global__ void __launch_bounds__(256) k_flag_list(const int32_t *__restrict__ flags, int nstreams, int32_t *__restrict__ list)
+// the streams with a raised flag, compacted: list[0] = count (zeroed by the host), list[1..] =
+// indices in any order.  One-wave workgroups of 256 streams each: a wave finds a slot beside the
+// front end's waves at once, a 256-thread workgroup waited 0.14 ms for four on one CU.
+__global__ void __launch_bounds__(64) k_flag_list(const int32_t *__restrict__ flags, int nstreams, int32_t *__restrict__ list)
 {
-	__shared__ int n;
-	if (threadIdx.x == 0) n = 0;
-	__syncthreads();
-	for (int s = (int)threadIdx.x; s < nstreams; s += 256)
-		if (flags[s]) list[1 + atomicAdd(&n, 1)] = s;
-	__syncthreads();
-	if (threadIdx.x == 0) list[0] = n;
+	for (int k = 0; k < 4; k++) {
+		const int s = ((int)blockIdx.x * 4 + k) * 64 + (int)threadIdx.x;
+		if (s < nstreams && flags[s]) list[1 + atomicAdd(&list[0], 1)] = s;
+	}
 }
 
 // A1: one lane per chunk walks the two extreme states through the whole chunk.  It records where

@@ -26,6 +26,7 @@ PY
 COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0"
 for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
   tag=${spec%%:*}; args=${spec#*:}
+  if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $tag "; then continue; fi
   cd $ROOT
   case $tag in
     c2) python bench.py > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
@@ -39,6 +40,7 @@ for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--box
   rm -rf $OUT/trace_$tag $OUT/trace_$tag.log
 done
 cd $ROOT
+if [ -n "${ONLY:-}" ]; then du -sh $ROOT/gpurun_out; exit 0; fi  # ONLY="wbfm c3": those workloads again, no PMC passes
 bash tools/prof_pmc.sh r02_c2 > /dev/null 2>&1
 PMC_KERNEL=k_boxcar_scan bash tools/prof_pmc.sh r02_box10 --boxcar 10 > /dev/null 2>&1
 PMC_KERNEL=k_boxcar_scan bash tools/prof_pmc.sh r02_box6 --boxcar 6 > /dev/null 2>&1
