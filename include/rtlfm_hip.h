@@ -260,6 +260,9 @@ int rtlfm_gpu_clock_read(rtlfm_gpu *h, double *shader_mhz, double *span_ms);
 int rtlfm_gpu_selftest_atan2(int device, const int32_t *yx, int n, int32_t *q14, int32_t *q14_libm);
 /* The kernels' fast_atan2 (src/rtl_fm.c:851-872, incl. its 32-bit wrap-around) on n host pairs. */
 int rtlfm_gpu_selftest_fast_atan2(int device, const int32_t *yx, int n, int32_t *q14);
+/* q[i] = nd[2i] / nd[2i+1] (C's truncating division, divisor >= 1) as the resampler's walk
+ * divides by fast / slow (src/rtl_fm.c:769): the magic-number form of staged_kernels.h */
+int rtlfm_gpu_selftest_const_div(int device, const int32_t *nd, int n, int32_t *q);
 
 /*
  * rotate_90 on raw u8 IQ (src/rtl_fm.c:437-447, NEG_U8(x) = 255 - x, :375-392): sample n

@@ -1483,6 +1483,31 @@ __global__ void k_selftest_fast_atan2(const int32_t *yx, int n, int32_t *a)
 	RTLFM_GRID_STRIDE(i, n) a[i] = fast_atan2_q14(yx[2 * i], yx[2 * i + 1]);
 }
 
+__global__ void k_selftest_const_div(const int32_t *nd, int n, int32_t *q)
+{
+	RTLFM_GRID_STRIDE(i, n) {
+		const ConstDiv cd(nd[2 * i + 1]);
+		q[i] = cd(nd[2 * i]);
+	}
+}
+
+extern "C" int rtlfm_gpu_selftest_const_div(int device, const int32_t *nd, int n, int32_t *q)
+{
+	if (!nd || !q || n < 1) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	int32_t *d_in = nullptr, *d_q = nullptr;
+	HIP_TRY(hipMalloc(&d_in, (size_t)n * 8));
+	HIP_TRY(hipMalloc(&d_q, (size_t)n * 4));
+	HIP_TRY(hipMemcpy(d_in, nd, (size_t)n * 8, hipMemcpyHostToDevice));
+	k_selftest_const_div<<<grid_for((size_t)n), 256>>>(d_in, n, d_q);
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(q, d_q, (size_t)n * 4, hipMemcpyDeviceToHost));
+	hipFree(d_in); hipFree(d_q);
+	return 0;
+}
+
 extern "C" int rtlfm_gpu_selftest_fast_atan2(int device, const int32_t *yx, int n, int32_t *q14)
 {
 	if (!yx || !q14 || n < 1) return -EINVAL;

@@ -662,6 +662,26 @@ def test_atan_lut_equals_atan2_q14_for_every_entry(oracle_lib):
     assert np.array_equal(a, lut), np.flatnonzero(a != lut)[:10]
 
 
+def test_resampler_division_by_magic_number():
+    """`now_lpr / (fast / slow)` (src/rtl_fm.c:769) in the resampler's walk is a multiplication by the
+    divisor's magic number (ConstDiv): C's truncating quotient for every int32 dividend, divisors 1
+    ... 2^31 - 1."""
+    lib = capi.load()
+    rng = np.random.default_rng(77)
+    ds = np.concatenate([np.arange(1, 300), 2 ** np.arange(1, 31), 2 ** np.arange(2, 31) - 1, 2 ** np.arange(1, 31) + 1,
+                         rng.integers(1, (1 << 31) - 1, size=500), [(1 << 31) - 1, 5, 6, 170000 // 32000]]).astype(np.int64)
+    ns = np.concatenate([rng.integers(-(1 << 31), 1 << 31, size=3000), np.arange(-70, 71), [-(1 << 31), (1 << 31) - 1, -(1 << 31) + 1],
+                         rng.integers(-400000, 400000, size=2000)]).astype(np.int64)
+    n, d = np.meshgrid(ns, ds)
+    n = n.ravel(); d = d.ravel()
+    nd = np.ascontiguousarray(np.stack([n, d], axis=1).astype(np.int32))
+    got = np.empty(nd.shape[0], dtype=np.int32)
+    assert lib.rtlfm_gpu_selftest_const_div(0, nd.ctypes.data, nd.shape[0], got.ctypes.data) == 0
+    want = (np.abs(n) // d) * np.sign(n)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad[:5], n[bad[:5]], d[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
 def test_atan2_q14_against_libm_and_oracle(oracle_lib):
     """The kernels' 45-instruction atan2->Q14 against the device libm chain and
     the host (glibc) chain of polar_discriminant, on 6e6 pairs incl. every
