@@ -305,8 +305,41 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
     L = a.block_len
     cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
     cfg.max_blocks = 1
+    nbytes = S * L
+
+    def h2d_ceiling():  # the same bytes, pinned host -> device, nothing else
+        pin = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=job.iq.device)
+        dst.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dst.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        return 5 * nbytes / (time.perf_counter() - t1) / 1e9
+
+    # native threads (rtlsdr_amd/csrc/host/ingest_bench.cpp, a child process: nothing here execs);
+    # the Python threads below top out on the interpreter lock at ~8 and are only the fall-back
+    native = os.path.join(ROOT, "rtlsdr_amd", "csrc", "host", "ingest_bench")
+    if os.path.exists(native) and not os.environ.get("RTLFM_E2E_PYTHON"):
+        import subprocess
+        import tempfile
+        nthreads = int(os.environ.get("RTLFM_E2E_THREADS", "8"))  # 8: 46 GB/s, 16-128: 37-43 on the box it was tried on
+        with tempfile.NamedTemporaryFile(suffix=".cfg") as tf:
+            tf.write(bytes(cfg)); tf.flush()
+            try:
+                p = subprocess.run([native, tf.name, str(S), str(nthreads), str(seconds), str(local_rank)], capture_output=True,
+                                   text=True, timeout=120)
+                res = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else None
+            except Exception:  # noqa: BLE001 - fall back to the Python threads
+                res = None
+        if res:
+            return {"value": res["Msamples/s"], "unit": "Msamples/s", "GB/s_in": res["GB/s_in"],
+                    "pinned_h2d_GB/s": round(h2d_ceiling(), 1), "harness": "native",
+                    "what": f"{S} streams x 1 buffer x {L} B per run, {res['runs']} pipelined runs in {res['seconds']:.2f} s: {nthreads} "
+                            f"native threads rtlfm_gpu_push (pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | "
+                            f"rtlfm_gpu_fetch_all; bounded by the host memcpy into the ring and PCIe, not by the kernels"}
     host = job.iq[:S, :L].contiguous().cpu().numpy()  # pageable, as a driver's transfer buffers are
-    nthreads = 16
+    nthreads = int(os.environ.get("RTLFM_E2E_THREADS", "16"))
     with GpuDemod(cfg, S, local_rank) as g, ThreadPoolExecutor(max_workers=nthreads) as pool:
         lib, hnd = g.lib, g._h
         cap = lib.rtlfm_result_cap(C.byref(cfg)) + 16
@@ -333,18 +366,8 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
             if time.perf_counter() - t0 > seconds and runs >= 3:
                 break
         dt = time.perf_counter() - t0
-    nbytes = S * L
-    # the ceiling: the same bytes, pinned host -> device, nothing else
-    pin = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    dst = torch.empty(nbytes, dtype=torch.uint8, device=job.iq.device)
-    dst.copy_(pin, non_blocking=True); torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        dst.copy_(pin, non_blocking=True)
-    torch.cuda.synchronize()
-    h2d = 5 * nbytes / (time.perf_counter() - t1) / 1e9
     return {"value": round(runs * S * (L // 2) / dt / 1e6, 1), "unit": "Msamples/s",
-            "GB/s_in": round(runs * nbytes / dt / 1e9, 2), "pinned_h2d_GB/s": round(h2d, 1),
+            "GB/s_in": round(runs * nbytes / dt / 1e9, 2), "pinned_h2d_GB/s": round(h2d_ceiling(), 1), "harness": "python",
             "what": f"{S} streams x 1 buffer x {L} B per run, {runs} pipelined runs in {dt:.2f} s: {nthreads} threads rtlfm_gpu_push "
                     f"(pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | rtlfm_gpu_fetch_all; "
                     f"bounded by the host memcpy into the ring and PCIe, not by the kernels"}

@@ -48,6 +48,7 @@ HOST = os.path.join(CSRC, "host")
 SHIM_OUT = os.path.join(HOST, "librtlsdr_file.so")
 CLI_OUT = os.path.join(HOST, "rtl_fm_hip")
 POWER_CLI_OUT = os.path.join(HOST, "rtl_power_hip")
+INGEST_OUT = os.path.join(HOST, "ingest_bench")
 
 
 def build_shim(force: bool = False, verbose: bool = False) -> str:
@@ -90,6 +91,14 @@ def build_host(force: bool = False, verbose: bool = False) -> tuple[str, str]:
                "-L" + HOST, "-L" + CSRC, "-lrtlsdr_file", "-lrtlfm_hip", "-lm",
                "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib",
                "-Wl,--allow-shlib-undefined"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    ib_src = os.path.join(HOST, "ingest_bench.cpp")
+    if stale(INGEST_OUT, [ib_src, OUT, os.path.join(inc, "rtlfm_hip.h")]):
+        # the PCIe-inclusive rate of the callback boundary from native threads (bench.py's e2e leg)
+        cmd = ["g++", "-O2", "-std=c++20", "-Wall", "-o", INGEST_OUT, ib_src, "-L" + CSRC, "-lrtlfm_hip", "-lpthread",
+               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

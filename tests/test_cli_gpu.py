@@ -176,3 +176,20 @@ def test_cli_prints_levels_like_full_demod(oracle_lib, tmp_path):
     got = np.fromfile(out, dtype=np.int16)
     ref, _ = oracle_lib.run_stream(cfg, iq)
     assert got.shape == ref.shape and np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+
+
+def test_ingest_bench_runs(tmp_path):
+    """The native harness of bench.py's e2e leg (host/ingest_bench.cpp): T threads push, the main
+    thread runs and fetches; every run must bring back the whole audio of every stream."""
+    import json
+    from rtlsdr_amd.capi import RtlfmCfg
+    hipbuild.build_host()
+    exe = os.path.join(os.path.dirname(hipbuild.CLI_OUT), "ingest_bench")
+    cfg = RtlfmCfg.default(downsample=16, downsample_passes=4, rate_out=150000, block_len=65536, max_blocks=1)
+    f = tmp_path / "c.cfg"
+    f.write_bytes(bytes(cfg))
+    p = subprocess.run([exe, str(f), "24", "5", "0.3"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["runs"] >= 3 and d["streams"] == 24 and d["threads"] == 5
+    assert d["pcm_per_run"] == 24 * (65536 // 2 // 16)
