@@ -5,6 +5,7 @@ different libm) and the arbitrary resamplers within 1 LSB on at most 1e-4 of
 the samples — in practice these come out bit-exact as well and the test says
 so when they do not."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -439,7 +440,7 @@ def _skip_only_outside_reference_domain(oracle_lib, cfg, L, err):
     raise AssertionError(f"the library rejects a configuration the reference runs: {err}")
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP", "48"))))
 def test_random_configurations_vs_oracle(oracle_lib, seed):
     """Seeded random configurations through the automatic path selection (fused fifth_order /
     fused boxcar / staged, + tail) and through the staged kernels only, against the oracle:
@@ -603,7 +604,7 @@ def test_fast_atan2_against_oracle(oracle_lib):
     assert np.array_equal(got[idx], want2)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_CB", "16"))))
 def test_callback_path_random_configurations(oracle_lib, seed):
     """push / run / fetch (the rtlsdr_read_async callback boundary) on random configurations:
     one pushing thread per stream, a random number of queued buffers per run, results and the

@@ -1,5 +1,7 @@
 """rtl_power rows p1-p5 through the C ABI on a real MI355X: int64 accumulators
 and sample counts bit-exact against the reference's golden output and the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -61,7 +63,7 @@ def test_power_batched_vs_oracle(oracle_lib, kw):
             assert np.array_equal(res[s][0], want[s]), (kw, s, split)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_POWER", "40"))))
 def test_power_random_configurations(oracle_lib, seed):
     """Seeded random rtl_power configurations (bin size, window, boxcar / fifth_order + FIR
     decimation, peak hold, read size, streams, reads split over launches) against the oracle."""
