@@ -180,6 +180,10 @@ int rtlfm_gpu_run(rtlfm_gpu *h);
  *   d_out_len   device pointer to nstreams int32 (total samples per stream),
  *               may be NULL
  * Asynchronous on the handle's stream.
+ * Any d_out / out_stride gives the same samples.  Rows that start on 128-byte lines (d_out 128-byte
+ * aligned, out_stride a multiple of 64) let the front end's tile stores cover whole lines (1 % of the
+ * launch); rows that are at least 16-byte aligned (out_stride a multiple of 8) let the resampler of
+ * the -M wbfm tail store eight outputs at a time (17 % of that step).
  */
 int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq,
                          size_t stream_stride, int nblocks, int16_t *d_out,
