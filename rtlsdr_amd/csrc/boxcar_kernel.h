@@ -140,7 +140,10 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fu
 #define RTLFM_BOXSCAN_WAVES_PER_SIMD 4
 #endif
 
-template <bool STD>
+// V: 1 = -M fm -A std, 2 = -M fm -A fast (each with its discriminator compiled in: as run-time
+// choices inside the output loop they cost ~40 scalar instructions per output), 0 = everything else
+// (-A lut, AM / USB / LSB), chosen at run time
+template <int V>
 __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_scan(const Params p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -321,8 +324,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				const int cj = fused::dot2_first(z, bx);
 				int v;
 				if (RTLFM_ABLATE & 1) v = cj ^ cr;  // analysis builds only (tools/ablate.sh)
-				else if (!STD && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
-				else if (STD || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
+				else if (V == 0 && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
+				else if (V == 1 || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
+				else if (V == 2) v = fast_atan2_q14(cj, cr);
 				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
 				pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v;
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		sout->now_r = carry_r;
 		sout->now_j = carry_j;
 		const iq16 w = unpack_iq(last_out);
-		if (STD || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
+		if (V != 0 || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
 		p.cnt[s] = kb;
 	}
 }
@@ -425,8 +429,10 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.has_first = (p.D & 1) ? 1 : 0;
 	p.R = (p.q4096 + 1 + 63) / 64;
 	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0) * 4;
-	if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<true>), dim3(waves), dim3(64), lds_bytes, q, p);
-	else hipLaunchKernelGGL((k_boxcar_scan<false>), dim3(waves), dim3(64), lds_bytes, q, p);
+	const bool fast_fm = c.custom_atan == RTLFM_ATAN_FAST && c.mode == RTLFM_MODE_FM;
+	if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1>), dim3(waves), dim3(64), lds_bytes, q, p);
+	else if (fast_fm) hipLaunchKernelGGL((k_boxcar_scan<2>), dim3(waves), dim3(64), lds_bytes, q, p);
+	else hipLaunchKernelGGL((k_boxcar_scan<0>), dim3(waves), dim3(64), lds_bytes, q, p);
 	if (p.D > 256) hipLaunchKernelGGL(k_boxcar_partial32, dim3((nstreams + 63) / 64), dim3(64), 0, q, p);
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }

@@ -195,22 +195,21 @@ __device__ __forceinline__ int sdiv_trunc(int n, int d)
 // exactly as the x86 build does.
 __device__ __forceinline__ int fast_atan2_q14(int y, int x)
 {
-	if (x == 0 && y == 0)
-		return 0;
-	int ay = y < 0 ? (int)(0u - (uint32_t)y) : y;
-	int num, den, base;
-	if (x >= 0) {
-		num = (int)((uint32_t)x - (uint32_t)ay);
-		den = (int)((uint32_t)x + (uint32_t)ay);
-		base = 4096;
-	} else {
-		num = (int)((uint32_t)x + (uint32_t)ay);
-		den = (int)((uint32_t)ay - (uint32_t)x);
-		base = 12288;
-	}
-	int prod = (int)(4096u * (uint32_t)num);
-	int angle = base - (den != 0 ? sdiv_trunc(prod, den) : 0);
-	return y < 0 ? -angle : angle;
+	// Without branches: the reference's two arms differ in the sign of yabs in the numerator and in
+	// the constant, and both denominators are |x| + yabs.  (As `if`s, with the division under one of
+	// them, the function cost 41 scalar instructions of exec-mask handling per call and made the
+	// -A fast front ends slower than -A std.)  x == y == 0 returns 0 (src/rtl_fm.c:855); a zero
+	// denominator otherwise needs yabs and |x| to wrap to 2^31 each, where the reference divides by zero.
+	const uint32_t ay = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
+	const bool neg = x < 0;
+	const uint32_t ax = neg ? 0u - (uint32_t)x : (uint32_t)x;
+	const int num = (int)((uint32_t)x + (neg ? ay : 0u - ay));
+	const int den = (int)(ax + ay);
+	const int prod = (int)(4096u * (uint32_t)num);
+	const int q = sdiv_trunc(prod, den);  // den == 0: no trap on the GPU, the value is dropped
+	const int angle = (neg ? 12288 : 4096) - (den != 0 ? q : 0);
+	const int r = y < 0 ? -angle : angle;
+	return (x | y) == 0 ? 0 : r;
 }
 
 // polar_disc_fast (src/rtl_fm.c:874-879)
