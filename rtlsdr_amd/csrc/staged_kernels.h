@@ -824,7 +824,7 @@ __device__ __forceinline__ uint32_t deemph_walk_sink(const int16_t *r, int n, ui
 		}
 	};
 	// 16-byte groups / samples in flight ahead of the walk.  (With four groups and 62 registers a wave of
-	// this fits beside four waves of k_boxcar_scan<true> on a SIMD: 1 % on the wbfm step, and slower alone.)
+	// this fits beside four waves of k_boxcar_scan<1> on a SIMD: 1 % on the wbfm step, and slower alone.)
 	constexpr int NG = 8, NS = 8 * NG;
 	if (k + NS <= n) {
 		uint4 cur[NG], nxt[NG];
