@@ -30,6 +30,12 @@ Besides the contract fields the line carries
                        (FETCH_SIZE, WRITE_SIZE; separate runs, no tracing) made by this very
                        invocation on this box before the timed run (N = 1; --pmc 0 skips them)
   roofline.shader_mhz  mean shader clock of the waves of a launch, stamped in the kernel
+  roofline.ceiling     THIS box's streaming ceilings, measured by this invocation with the front end's access
+                       pattern and none of its arithmetic (rtlfm_gpu_bw_probe): read only, and read + write at the
+                       workload's own byte ratio; roofline.frac_of_ceiling = achieved / that read+write ceiling.
+                       `frac` stays against the nominal 8 TB/s; the two together tell box from code.
+  also                 (default workload) north_star's shape through the same kernel in the same invocation:
+                       4096 streams x 4 buffers and x 1 buffer of 262144 B per launch
   e2e                  host buffers through rtlfm_gpu_push / _run / _fetch_all (PCIe-inclusive; never `value`)
   cpu_baseline         the reference's own code (oracle/_ref) or the oracle port on the host cores
 """
@@ -83,6 +89,8 @@ def parse():
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the sustained leg after the K timed steps (0: skip)")
     ap.add_argument("--pmc", type=int, default=-1, help="rocprofv3 PMC passes for roofline.traffic: 1 on, 0 off, -1 on for N = 1 when rocprofv3 exists")
     ap.add_argument("--e2e", type=int, default=1, help="1: also time the PCIe-inclusive push / run / fetch path (N = 1)")
+    ap.add_argument("--ceiling", type=int, default=1, help="1: measure this box's streaming ceilings (roofline.ceiling)")
+    ap.add_argument("--also", type=int, default=1, help="1: default workload also times north_star's 4096-stream shapes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scatter", action="store_true",
                     help="N > 1: also time shard.scatter_streams (root GPU -> its owner GPUs) of one step's IQ over RCCL")
@@ -263,14 +271,49 @@ def cpu_baseline(cfg, iq_host_sample, seconds, gate=None):
 
 
 def cpu_baseline_power(cfg, sample, seconds, gate=None):
-    """rtl_power's scanner() on the host cores: the oracle port (pinned function by function to
-    the reference's rtl_power.c compiled in place), one pthread per stream, bounded."""
+    """rtl_power's scanner() on the host cores, bounded.
+
+    kind "reference": the reference's own scanner() (src/rtl_power.c:642-720) compiled in place into
+    oracle/_ref/libref_rtlpower.so, one private copy of the library per thread (scanner() keeps its
+    tuning state, FFT buffer and tables in globals), every thread on its own file-backed device that
+    serves one looped capture (the product's librtlsdr_file.so is what scanner()'s rtlsdr_read_sync binds to).
+    kind "port": the oracle's restatement, one pthread per stream - when oracle/_ref is absent."""
+    import ctypes as C
+    import tempfile
+
     import numpy as np
     from oracle import pyoracle as po
     if gate is not None:
         giq, gavg, gsamples = gate
         want, wn = po.power_scan_batch(cfg, giq, nthreads=4)
         assert np.array_equal(wn, gsamples) and np.array_equal(want, gavg), "parity gate failed (rtl_power)"
+    L = int(cfg.buf_len)
+    cores = os.cpu_count() or 1
+    if po.have_power_reference():
+        from rtlsdr_amd import build as product_build
+        C.CDLL(product_build.SHIM_OUT, mode=C.RTLD_GLOBAL)  # the device layer scanner() reads through
+        ld = C.CDLL(po.LOADER_SO)
+        ld.ref_power_bench_mt.restype = C.c_double
+        ld.ref_power_bench_mt.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        with tempfile.NamedTemporaryFile(prefix="rtlpower_cap_", suffix=".bin") as tf:
+            sample[0].tofile(tf); tf.flush()
+            os.environ["RTLSDR_FILE"] = tf.name
+            os.environ["RTLSDR_FILE_LOOP"] = "1"
+            try:
+                t1 = ld.ref_power_bench_mt(po.REF_POWER_SO.encode(), C.byref(cfg), 1, 8)
+                tc = ld.ref_power_bench_mt(po.REF_POWER_SO.encode(), C.byref(cfg), cores, 8)
+                dt, nscans = -1.0, 0
+                if t1 > 0 and tc > 0:
+                    nscans = max(8, int(8 * seconds / tc))
+                    dt = ld.ref_power_bench_mt(po.REF_POWER_SO.encode(), C.byref(cfg), cores, nscans)
+            finally:
+                os.environ.pop("RTLSDR_FILE", None)
+                os.environ.pop("RTLSDR_FILE_LOOP", None)
+        if dt > 0:
+            samples = cores * nscans * (L // 2)
+            return {"value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                    "sample": f"reference rtl_power.c (gcc -O3) scanner(): {cores} threads x 1 tuning state x {nscans} reads x {L} B "
+                              f"({samples / 1e6:.0f} Msamples in {dt:.1f} s); one thread alone: {8 * (L // 2) / t1 / 1e6:.1f} Msamples/s"}
     cs = sample.shape[0]
     t1 = time.perf_counter()
     po.power_scan_batch(cfg, sample, nthreads=cs)
@@ -280,7 +323,6 @@ def cpu_baseline_power(cfg, sample, seconds, gate=None):
     for _ in range(reps):
         po.power_scan_batch(cfg, sample, nthreads=cs)
     dt = time.perf_counter() - t1
-    L = int(cfg.buf_len)
     nreads = sample.shape[1] // L
     samples = reps * cs * nreads * (L // 2)
     return {"value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "cores": cs, "kind": "port",
@@ -371,6 +413,81 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
             "what": f"{S} streams x 1 buffer x {L} B per run, {runs} pipelined runs in {dt:.2f} s: {nthreads} threads rtlfm_gpu_push "
                     f"(pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | rtlfm_gpu_fetch_all; "
                     f"bounded by the host memcpy into the ring and PCIe, not by the kernels"}
+
+
+def ceiling_leg(job, local_rank):
+    """This box's own HBM ceilings (nominal 8 TB/s AND a measured ceiling), same invocation:
+    the front end's access pattern without its arithmetic (rtlfm_gpu_bw_probe, bw_probe_kernel.h) over
+    4 GiB - read only, and read + write at the workload's byte ratio (the PCM is 1/16 of the input bytes
+    at /16: one byte stored per 16 read)."""
+    import ctypes as C
+    from rtlsdr_amd.capi import load
+    lib = load()
+    wd = max(1, int(round(2.0 / max(job.alg_bytes_per_sample - 2.0, 2.0 / 64))))
+    rd, rw, wf = C.c_double(), C.c_double(), C.c_double()
+    r = lib.rtlfm_gpu_bw_probe(local_rank, 4 << 30, wd, 20, C.byref(rd), C.byref(rw), C.byref(wf))
+    if r < 0:
+        return None
+    return {"read_only": round(rd.value, 1), "read_write": round(rw.value, 1), "unit": "GB/s",
+            "write_fraction": round(wf.value, 5), "workload_write_fraction": round((job.alg_bytes_per_sample - 2.0) / 2.0, 5),
+            "how": "rtlfm_gpu_bw_probe: 8192 waves x 8 KiB tiles, non-temporal coalesced dwordx4 loads with the next "
+                   "tile in flight, 4 waves/SIMD, 4 GiB, 20 launches each, HIP events; read_write = (read + written bytes) / time"}
+
+
+def also_leg(a, job, local_rank, ceiling):
+    """north_star's shape ("4096 batched 2.4 MS/s streams") through the same kernel, same invocation, same
+    bytes: the resident 4 GiB of IQ re-read as 4096 streams x 4 buffers of 262144 B per launch, and as
+    4096 x 1 buffer per launch (what a live capture delivers per callback round, src/rtl_fm.c:1339-1343)."""
+    import torch
+    from rtlsdr_amd.capi import RtlfmCfg
+    from rtlsdr_amd.demod import GpuDemod
+    L = a.block_len
+    total = job.iq.numel()
+    S = 4096
+    if total % (S * L) or total // (S * L) < 4:
+        return None
+    per_stream = total // S
+    out = []
+    for nb in (4, 1):
+        cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
+        cfg.max_blocks = nb
+        with GpuDemod(cfg, S, local_rank) as g:
+            cap = g.result_cap(nb)
+            o = torch.empty((S, cap), dtype=torch.int16, device=job.iq.device)
+            n = torch.zeros(S, dtype=torch.int32, device=job.iq.device)
+
+            def step():
+                g.run_device(job.iq.data_ptr(), per_stream, nb, o.data_ptr(), o.stride(0), n.data_ptr())
+            for _ in range(100 if nb == 4 else 400):
+                step()
+            g.sync()
+            g.timing_enable(True); g.timing_read()
+            K = 200 if nb == 4 else 800
+            t0 = time.perf_counter()
+            for _ in range(K):
+                step()
+            g.sync()
+            dt = time.perf_counter() - t0
+            ms, cnt = g.timing_read()
+            segs = None
+            g.clock_probe(True)
+            step()
+            st = g.clock_stamps()
+            g.clock_probe(False)
+            if st is not None:
+                segs = len(st) // S
+        samples = S * nb * L // 2
+        alg = job.alg_bytes_per_sample * samples
+        launch_ms = ms / max(cnt, 1)
+        ach = alg / (launch_ms * 1e-3) / 1e9
+        e = {"workload": f"ns4096x{nb}: 4096 streams x {nb} buffer(s) x {L} B per launch, same chain",
+             "launch_ms": round(launch_ms, 4), "ms_per_step": round(dt / K * 1e3, 4), "steps": K,
+             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+             "value": round(samples * K / dt / 1e6, 1), "waves_per_stream": segs}
+        if ceiling:
+            e["frac_of_ceiling"] = round(ach / ceiling["read_write"], 4)
+        out.append(e)
+    return out
 
 
 def time_scatter(dist, rank, world, dev, streams_per_rank, bytes_per_stream, reps=3):
@@ -567,12 +684,23 @@ def main():
 
     # Before this process touches the GPU: build (hipcc / gcc children) and the PMC child runs.
     traffic = None
-    if not a.pmc_child:
+    under_profiler = any("ROCPROF" in k for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if under_profiler:
+        # rocprofv3's preloaded library has initialised the GPU in this process already: nothing here may
+        # start compilers, shells or other children that exec onward (the pool forbids that hop), and the
+        # PCIe leg's child process would inherit the profiler.  Stale artefacts are an error, not a build.
+        a.e2e = 0
+        if not a.pmc_child:
+            from rtlsdr_amd import build as b
+            if b.needs_build():
+                print("bench.py: librtlfm_hip.so is stale and this process runs under rocprofv3: build first "
+                      "(python -c 'import __graft_entry__ as g; g.build()'), then profile", file=sys.stderr)
+                sys.exit(3)
+    elif not a.pmc_child:
         import __graft_entry__ as ge
         if rank == 0:
             ge.build()
-        under_profiler = any("ROCPROF" in k for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not under_profiler)
+        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1)
         if want_pmc and rank == 0 and world == 1:
             traffic = pmc_traffic(a)
 
@@ -653,6 +781,12 @@ def main():
         clock = job.g.clock_read()
         job.g.clock_probe(False)
 
+    ceiling, also = None, None
+    if rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child and a.ceiling:
+        ceiling = ceiling_leg(job, local_rank)
+        if a.workload == "c2" and a.also and not a.boxcar:
+            also = also_leg(a, job, local_rank, ceiling)
+
     e2e = None
     if a.e2e and rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child:
         e2e = e2e_leg(a, job, local_rank)
@@ -709,6 +843,11 @@ def main():
         if clock:
             roof["shader_mhz"] = round(clock[0], 0)
             roof["kernel_span_ms"] = round(clock[1], 4)
+        if ceiling and achieved:
+            roof["ceiling"] = ceiling
+            roof["frac_of_ceiling"] = round(achieved / ceiling["read_write"], 4)
+            if sustained:
+                roof["sustained"]["frac_of_ceiling"] = round(roof["sustained"]["achieved"] / ceiling["read_write"], 4)
         res = {
             "metric": "IQ Msamples/s demodulated (whole node)",
             "value": round(value, 1),
@@ -734,6 +873,8 @@ def main():
             },
             "roofline": roof,
         }
+        if also:
+            res["also"] = also
         if e2e:
             res["e2e"] = e2e
         if not a.no_cpu_baseline and world == 1:

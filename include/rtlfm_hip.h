@@ -141,6 +141,10 @@ int rtlfm_result_len(const rtlfm_cfg *cfg);
 /* Upper bound of output samples per block (always defined). */
 int rtlfm_result_cap(const rtlfm_cfg *cfg);
 
+/* What rtlfm_gpu_create() accepts, without a GPU: 0, or the error it would return (-EINVAL, or -EDOM
+ * where the reference itself leaves its domain: see rtlfm_gpu_strerror). */
+int rtlfm_cfg_validate(const rtlfm_cfg *cfg);
+
 /* ---- the GPU layer ------------------------------------------------------ */
 
 /* Allocates per-stream state (demod_init() values) and work buffers on
@@ -212,7 +216,12 @@ int rtlfm_gpu_state_set(rtlfm_gpu *h, int stream, const rtlfm_stream_state *st);
 int rtlfm_gpu_reset(rtlfm_gpu *h);
 
 int rtlfm_gpu_sync(rtlfm_gpu *h);
-/* Launch on a caller-owned hipStream_t (NULL = the handle's own stream). */
+/* Launch on a caller-owned hipStream_t (NULL = the handle's own stream).  On a caller-owned stream
+ * EVERYTHING the handle launches is ordered on that stream, the audio tail (deemph, DC block,
+ * resamplers) included: work the caller enqueues on it behind rtlfm_gpu_run_device() sees the
+ * finished d_out / d_out_len.  (On its own stream the handle runs the audio tail of a step on a
+ * second internal stream, overlapped with the next step's front end; rtlfm_gpu_sync /
+ * _release_to / _state_get / _fetch* wait for both.) */
 int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *hip_stream);
 /*
  * Ordering against another HIP stream without a host synchronisation.  The library launches on
@@ -226,11 +235,32 @@ int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *hip_stream);
 int rtlfm_gpu_wait_for(rtlfm_gpu *h, void *producer_stream);
 int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
 
+/*
+ * Tunables and A/B switches of one handle, by name (none of them changes a result; the parity
+ * suite runs under several).  The library reads no environment variable while samples flow:
+ * RTLFM_OPTIONS="name=value,name=value" is applied once, inside rtlfm_gpu_create().
+ *   fused_waves          waves a front-end launch aims for (default 8192 = twice the GPU's wave slots);
+ *                        a stream's run is cut into that many segments / nstreams
+ *   fused_min_tiles      shortest segment in 8 KiB tiles (default 8: each segment but a stream's first
+ *                        re-runs one warm-up tile); not applied while the launch cannot fill the GPU
+ *   fused_tiles_per_seg  > 0: exactly this segment length (tests)
+ *   pass0_engine         -1 compiled default, 0 v_dot4, 1 int8 MFMA (as rtlfm_gpu_set_path 3 / 4)
+ *   tail_serial          1: audio tail on the front end's stream, no overlap with the next step
+ *   deemph_sequential    1: deemph_filter one lane per stream, never parallel over time
+ *   deemph_four_pass     1: no one-pass (speculative) deemph kernels
+ *   lpr_separate         1: low_pass_real as a kernel of its own behind deemph_filter
+ *   lpr_scalar_stores    1: the resampler's outputs one by one
+ *   tail_sync            1: synchronise and report after every tail kernel (debugging)
+ *   fused_debug          clock-stamp experiments (2 / 18 / 4, see fused_kernel.h)
+ * Returns -ENOENT for an unknown name, -EINVAL for a value out of range.
+ */
+int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value);
+int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value);
+
 /* 0 = automatic, 1 = staged reference kernels, 2 = fused streaming kernel
  * (fails with -ENOTSUP at run time when the configuration has no fused
  * form); 3 / 4 = fused with the first decimation pass forced onto v_dot4 /
- * onto the int8 MFMA pipe (2 takes the engine from RTLFM_PASS0 or the
- * compiled default).  For tests and A/B measurement. */
+ * onto the int8 MFMA pipe (2 takes the compiled default).  For tests and A/B measurement. */
 int rtlfm_gpu_set_path(rtlfm_gpu *h, int path);
 /* Which path the last run took (1 or 2). */
 int rtlfm_gpu_last_path(rtlfm_gpu *h);
@@ -254,6 +284,24 @@ int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches);
  */
 int rtlfm_gpu_clock_probe(rtlfm_gpu *h, int on);
 int rtlfm_gpu_clock_read(rtlfm_gpu *h, double *shader_mhz, double *span_ms);
+/* The raw stamps of that launch: out[4 w .. 4 w + 3] = wave w's shader clock at its first / last
+ * instruction and the 100 MHz counter at its first / last instruction.  *waves = waves of the launch
+ * (out may be NULL to ask); -ENOBUFS when cap_waves is smaller. */
+int rtlfm_gpu_clock_stamps(rtlfm_gpu *h, uint64_t *out, int cap_waves, int *waves);
+
+/*
+ * The box's own HBM streaming ceilings (SURVEY.md §8d asks for a measured ceiling next to the
+ * nominal 8 TB/s): the front-end kernels' skeleton - one wave per contiguous segment, 8 KiB tiles,
+ * non-temporal coalesced 16-byte loads with the next tile in flight, the same LDS footprint - and
+ * none of their arithmetic, over `bytes` (>= 64 MiB) of device memory, `reps` launches each:
+ *   *read_gbs        read only
+ *   *rw_gbs          the same with one byte stored per ~write_div bytes read (16 = the /16 chain's PCM);
+ *                    (bytes read + bytes written) / time
+ *   *write_fraction  the share actually stored (2, 4, 8 or 16 bytes per lane and tile: 1/64 ... 1/8)
+ * Allocates and frees its own buffers; no handle needed.
+ */
+int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int reps, double *read_gbs, double *rw_gbs,
+                       double *write_fraction);
 
 /*
  * Diagnostic: evaluates the kernels' atan2 -> Q14 routine (the arithmetic of

@@ -91,6 +91,10 @@ int rtlpower_csv_dbm(const rtlpower_plan *plan, int tune, int64_t *avg, int32_t 
 /* window_coefs[i] = (int)(256 * window_fn(i, length)) (src/rtl_power.c:985-988); host only */
 int rtlpower_window_coefs(int window, int length, int32_t *out);
 
+/* What rtlpower_gpu_create() accepts, without a GPU: 0, or the error it would return (-EINVAL; -ENOTSUP
+ * for bin_e 15..21).  Outside scanner()'s own domain - a trailing FFT frame that reaches past the read,
+ * where the reference transforms whatever its static fft_buf still holds (src/rtl_power.c:695) - is refused. */
+int rtlpower_cfg_validate(const rtlpower_cfg *cfg);
 int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int device, rtlpower_gpu **out);
 int rtlpower_gpu_destroy(rtlpower_gpu *h);
 
@@ -113,6 +117,9 @@ int rtlpower_gpu_set_stream(rtlpower_gpu *h, void *hip_stream);
 /* Cross-stream ordering as rtlfm_gpu_wait_for / rtlfm_gpu_release_to (include/rtlfm_hip.h). */
 int rtlpower_gpu_wait_for(rtlpower_gpu *h, void *producer_stream);
 int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream);
+/* Tunables by name, as rtlfm_gpu_set_option: "groups" = workgroups per stream of the FFT kernel
+ * (0 = automatic: enough to fill the 256 CUs).  -ENOENT for an unknown name. */
+int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long value);
 /* HIP-event timing of the FFT kernel, as rtlfm_gpu_timing_*. */
 int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on);
 int rtlpower_gpu_timing_read(rtlpower_gpu *h, double *ms, int *launches);

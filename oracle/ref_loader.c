@@ -121,3 +121,63 @@ double ref_bench_mt(const char *so_path, const void *cfg, const uint8_t *iq, siz
 	free(w); free(tid);
 	return secs;
 }
+
+/* ------------------------------------------------------------------------
+ * The same for rtl_power: scanner() (src/rtl_power.c:642-720) keeps its tuning state, FFT buffer
+ * and tables in file-scope globals, so every thread gets a private copy of
+ * oracle/_ref/libref_rtlpower.so.  scanner() reads through rtlsdr_read_sync(): the device layer
+ * (the product's file-backed librtlsdr_file.so, loaded RTLD_GLOBAL by the caller) serves one
+ * looped capture from the page cache to every thread - a memcpy of buf_len bytes per 2^bin_e-point
+ * transform.  RTLSDR_FILE / RTLSDR_FILE_LOOP are set by the caller before this is called.
+ * ---------------------------------------------------------------------- */
+struct refp_worker {
+	void *handle;
+	int (*setup)(const void *cfg);
+	int (*scan_env)(int nscans);
+	const void *cfg;
+	int nscans, rc;
+	pthread_barrier_t *start;
+};
+
+static void *refp_worker_main(void *arg)
+{
+	struct refp_worker *w = (struct refp_worker *)arg;
+	w->setup(w->cfg);
+	pthread_barrier_wait(w->start);
+	w->rc = w->scan_env(w->nscans);
+	return NULL;
+}
+
+double ref_power_bench_mt(const char *so_path, const void *cfg, int nthreads, int nscans)
+{
+	struct refp_worker *w = (struct refp_worker *)calloc((size_t)nthreads, sizeof(*w));
+	pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof(*tid));
+	pthread_barrier_t start;
+	char name[256];
+	pthread_barrier_init(&start, NULL, (unsigned)nthreads + 1);
+	for (int t = 0; t < nthreads; t++) {
+		snprintf(name, sizeof(name), "/tmp/refp_bench_%d_%d.so", (int)getpid(), t);
+		if (copy_file(so_path, name) != 0) return -1.0;
+		w[t].handle = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
+		unlink(name);
+		if (!w[t].handle) { fprintf(stderr, "ref_power_bench_mt: %s\n", dlerror()); return -2.0; }
+		w[t].setup = (int (*)(const void *))dlsym(w[t].handle, "ref_power_setup");
+		w[t].scan_env = (int (*)(int))dlsym(w[t].handle, "ref_power_scan_env");
+		if (!w[t].setup || !w[t].scan_env) return -3.0;
+		w[t].cfg = cfg; w[t].nscans = nscans; w[t].start = &start;
+		pthread_create(&tid[t], NULL, refp_worker_main, &w[t]);
+	}
+	struct timespec a, b;
+	pthread_barrier_wait(&start);
+	clock_gettime(CLOCK_MONOTONIC, &a);
+	for (int t = 0; t < nthreads; t++) pthread_join(tid[t], NULL);
+	clock_gettime(CLOCK_MONOTONIC, &b);
+	double secs = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+	for (int t = 0; t < nthreads; t++) {
+		if (w[t].rc != 0) secs = -4.0;
+		dlclose(w[t].handle);
+	}
+	pthread_barrier_destroy(&start);
+	free(w); free(tid);
+	return secs;
+}

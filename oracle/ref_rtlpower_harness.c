@@ -83,6 +83,23 @@ int ref_power_scan_file(const char *iq_path, int nreads)
 	return 0;
 }
 
+/* The same for the CPU baseline's worker threads (oracle/ref_loader.c: ref_power_bench_mt, one
+ * private copy of this object per thread): RTLSDR_FILE / RTLSDR_FILE_LOOP are set ONCE by the caller
+ * before the threads start (setenv is not thread-safe), every thread opens its own device on that
+ * file and calls scanner() `nscans` times. */
+int ref_power_scan_env(int nscans)
+{
+	struct tuning_state *ts = &tunes[0];
+	if (rtlsdr_open(&dev, 0) < 0 || !dev)
+		return -1;
+	rtlsdr_set_center_freq(dev, (uint32_t)ts->freq);
+	for (int r = 0; r < nscans; r++)
+		scanner();
+	rtlsdr_close(dev);
+	dev = NULL;
+	return 0;
+}
+
 int ref_power_get(int64_t *avg, int32_t *samples)
 {
 	int bins = 1 << tunes[0].bin_e;

@@ -167,6 +167,7 @@ _SIGNATURES = [
     ("rtlfm_deemph_a", C.c_int32, [C.c_int32, C.c_int32]),
     ("rtlfm_result_len", C.c_int, [_P(RtlfmCfg)]),
     ("rtlfm_result_cap", C.c_int, [_P(RtlfmCfg)]),
+    ("rtlfm_cfg_validate", C.c_int, [_P(RtlfmCfg)]),
     ("rtlfm_gpu_create", C.c_int, [_P(RtlfmCfg), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("rtlfm_gpu_destroy", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_push", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]),
@@ -189,6 +190,10 @@ _SIGNATURES = [
     ("rtlfm_gpu_timing_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int)]),
     ("rtlfm_gpu_clock_probe", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlfm_gpu_clock_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double)]),
+    ("rtlfm_gpu_clock_stamps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),
+    ("rtlfm_gpu_bw_probe", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    ("rtlfm_gpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    ("rtlfm_gpu_get_option", C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_long)]),
     ("rtlfm_gpu_selftest_atan2", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("rtlfm_gpu_selftest_fast_atan2", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("rtlfm_gpu_selftest_const_div", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -216,6 +221,7 @@ _POWER_SIGNATURES = [
     ("rtlpower_plan_cfg", None, [_P(RtlpowerPlan), C.c_int, C.c_int, C.c_int, C.c_int, _P(RtlpowerCfg)]),
     ("rtlpower_csv_dbm", C.c_int, [_P(RtlpowerPlan), C.c_int, C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]),
     ("rtlpower_window_coefs", C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    ("rtlpower_cfg_validate", C.c_int, [_P(RtlpowerCfg)]),
     ("rtlpower_gpu_create", C.c_int, [_P(RtlpowerCfg), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("rtlpower_gpu_destroy", C.c_int, [C.c_void_p]),
     ("rtlpower_gpu_scan_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
@@ -226,6 +232,7 @@ _POWER_SIGNATURES = [
     ("rtlpower_gpu_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rtlpower_gpu_wait_for", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rtlpower_gpu_release_to", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rtlpower_gpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     ("rtlpower_gpu_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlpower_gpu_timing_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int)]),
 ]

@@ -42,7 +42,7 @@ struct Params {
 	int mode, output_scale;
 	int D, q4096, r4096;  // 4096 = q4096 * D + r4096
 	int out_cap;          // 4096 / D + 2
-	int segs, blocks_per_seg;
+	int segs, tiles_per_seg;    // as in fused_kernel.h: runs of tiles, not of whole buffers
 	const uint8_t *dummy_tile;  // what the reload reads after a segment's last tile (fused_kernel.h)
 	int has_first;              // k_boxcar_scan: the LDS copy of each dword's first sample exists (odd D)
 	int R;                      // k_boxcar_scan: outputs per lane and tile, ceil((4096 / D + 1) / 64)
@@ -153,12 +153,13 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	const int s = wave / p.segs;
 	if (s >= p.nstreams) return;
 	const int tpb = (int)(p.block_len / kTileBytes);
-	const int b0 = seg * p.blocks_per_seg;
-	int b1 = b0 + p.blocks_per_seg;
-	if (b1 > p.nblocks) b1 = p.nblocks;
-	if (b0 >= b1) return;
-	const bool from_state = (b0 == 0);
-	const bool writes_state = (b1 == p.nblocks);
+	const int total_tiles = p.nblocks * tpb;
+	const int t0 = seg * p.tiles_per_seg;
+	int t1 = t0 + p.tiles_per_seg;
+	if (t1 > total_tiles) t1 = total_tiles;
+	if (t0 >= t1) return;
+	const bool from_state = (t0 == 0);
+	const bool writes_state = (t1 == total_tiles);
 	const state_t *sin = p.sin + s;
 	state_t *sout = p.sout + s;
 	const int D = p.D;
@@ -172,9 +173,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	}
 	if (lane < 17) reinterpret_cast<double *>(lds + ScanLds::atan)[lane] = k_atan_nodes[lane];
 	const int p0 = sin->prev_index;
-	const int gt_first = b0 * tpb;
+	const int gt_first = t0;
 	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
-	const int gt_end = b1 * tpb;
+	const int gt_end = t1;
 	int ph, kb;
 	{
 		const long long n = (long long)p0 + (long long)gt_begin * kTileSamples;
@@ -417,14 +418,9 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.mode = c.mode; p.output_scale = c.output_scale;
 	p.D = c.downsample; p.q4096 = kTileSamples / p.D; p.r4096 = kTileSamples % p.D;
 	p.out_cap = kTileSamples / p.D + 2;
-	int target_waves = 8192;
-	int segs = (target_waves + nstreams - 1) / nstreams;
-	if (segs > nblocks) segs = nblocks;
-	if (segs < 1) segs = 1;
-	const int bps = (nblocks + segs - 1) / segs;
-	segs = (nblocks + bps - 1) / bps;
-	p.segs = segs; p.blocks_per_seg = bps;
-	const int waves = nstreams * segs;
+	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, nblocks * (int)(c.block_len / kTileBytes));
+	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg;
+	const int waves = nstreams * sp.segs;
 	const bool std_fm = c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM;
 	p.has_first = (p.D & 1) ? 1 : 0;
 	p.R = (p.q4096 + 1 + 63) / 64;

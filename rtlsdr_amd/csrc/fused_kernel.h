@@ -221,7 +221,7 @@ struct Params {
 	uint32_t *emit_iq;
 	size_t emit_iq_stride;  // dwords between streams
 	const uint8_t *dummy_tile;  // 8 KiB, what the reload reads after a segment's last tile
-	int segs, blocks_per_seg;
+	int segs, tiles_per_seg;    // a segment is a run of tiles of one stream; it may begin and end inside a buffer
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps (printed per launch; +16 = 18:
 	            // only on timing_read, i.e. for the last launch of an uninterrupted run), 4 = reload one (cached) tile
@@ -420,12 +420,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	const int s = wave / p.segs;
 	if (s >= p.nstreams) return;
 	const int tpb = (int)(p.block_len / kTileBytes);
-	const int b0 = seg * p.blocks_per_seg;
-	int b1 = b0 + p.blocks_per_seg;
-	if (b1 > p.nblocks) b1 = p.nblocks;
-	if (b0 >= b1) return;
-	const bool from_state = (b0 == 0);
-	const bool writes_state = (b1 == p.nblocks);
+	const int total_tiles = p.nblocks * tpb;
+	const int t0 = seg * p.tiles_per_seg;
+	int t1 = t0 + p.tiles_per_seg;
+	if (t1 > total_tiles) t1 = total_tiles;
+	if (t0 >= t1) return;
+	const bool from_state = (t0 == 0);
+	const bool writes_state = (t1 == total_tiles);
 	const state_t *sin = p.sin + s;
 	state_t *sout = p.sout + s;
 	const int rotate = p.rotate;
@@ -469,9 +470,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	__builtin_amdgcn_wave_barrier();
 	const AtanNodesLds nodes{reinterpret_cast<const double *>(lds + L::atan)};
 
-	const int gt_first = b0 * tpb;
+	// A segment that starts behind the run's first tile runs the tile before it as a warm-up (outputs
+	// discarded) - the last tile of the previous buffer or an earlier tile of the same buffer alike:
+	// bs / next_bs below follow from the tile's position, so the buffer-boundary rules apply where
+	// they belong whatever the segmentation is.
+	const int gt_first = t0;
 	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
-	const int gt_end = b1 * tpb;
+	const int gt_end = t1;
 	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
 	const int out_per_tile = 64 * CZ;
 	int16_t *out_base = p.out + (size_t)s * p.out_stride;
@@ -945,11 +950,17 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 
 struct Workspace {
 	unsigned long long *stamps = nullptr;
-	int stamp_waves = 0;
+	int stamp_waves = 0;                          // capacity of stamps[]
+	int stamp_last = 0;                           // waves of the last launch that stamped
 	uint32_t *mfma_taps[2] = {nullptr, nullptr};  // [rotate]
 	uint8_t *dummy_tile = nullptr;
-	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = automatic (see launch)
+	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = the compiled default (see launch)
 	bool want_stamps = false;                     // rtlfm_gpu_clock_probe(): every wave leaves its clock stamps
+	// segmentation (rtlfm_gpu_set_option: fused_waves, fused_min_tiles, fused_tiles_per_seg)
+	int target_waves = 8192;                      // enough waves to fill the 4096 wave slots of 256 CUs twice
+	int min_tiles = 8;                            // a segment pays one warm-up tile: at most 1/8 on top
+	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
+	int debug = 0;                                // fused_debug: 2 = clock stamps per launch (+16: only on timing_read), 4 = reload a cached tile
 	void release()
 	{
 		if (stamps) hipFree(stamps);
@@ -959,6 +970,34 @@ struct Workspace {
 		dummy_tile = nullptr;
 	}
 };
+
+// How a run of `total_tiles` tiles per stream is cut into segments (one wave each).  Every segment
+// but a stream's first re-reads and recomputes one warm-up tile, so segments are kept at
+// min_tiles or more - unless the launch cannot fill the GPU's wave slots anyway: then the extra
+// waves run where nothing else would, and shorter segments only shorten the launch (one callback
+// buffer of one stream, the reference's own shape, gets a wave per tile).
+constexpr int kWaveSlots = 256 * 4 * 4;  // CUs x SIMDs x resident waves of these kernels
+struct SegPlan { int segs, tiles_per_seg; };
+inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
+{
+	SegPlan sp{1, total_tiles};
+	if (ws.tiles_per_seg > 0) {
+		sp.tiles_per_seg = ws.tiles_per_seg < total_tiles ? ws.tiles_per_seg : total_tiles;
+	} else {
+		int segs = (ws.target_waves + nstreams - 1) / nstreams;
+		int cap = total_tiles / (ws.min_tiles > 0 ? ws.min_tiles : 1);
+		if (cap < 1) cap = 1;
+		if ((long long)nstreams * cap < kWaveSlots) {
+			cap = (kWaveSlots + nstreams - 1) / nstreams;
+			if (cap > total_tiles) cap = total_tiles;
+		}
+		if (segs > cap) segs = cap;
+		if (segs < 1) segs = 1;
+		sp.tiles_per_seg = (total_tiles + segs - 1) / segs;
+	}
+	sp.segs = (total_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
+	return sp;
+}
 
 // What the front end in emit mode plus staged kernels covers beyond supported(): 7..10 passes,
 // -M raw, and the squelch (rtlfm_hip.hip: run_fused_emit)
@@ -1021,19 +1060,13 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.mode = c.mode; p.output_scale = c.output_scale;
 	if (c.mode != RTLFM_MODE_FM) p.variant = RTLFM_ATAN_FAST;  // any value but STD: the run-time kernels carry the mode switch
 	p.taps = make_taps(p.rotate != 0);
-	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) or RTLFM_PASS0=valu|mfma, else the MFMA
+	// Pass-0 engine: forced by rtlfm_gpu_set_path(3|4) / the pass0_engine option, else the MFMA
 	// form: its coalesced tile loads can be non-temporal (load_stream16), which removes the cost
 	// of mixing the PCM stores into the read stream, and with that it is the faster engine at
 	// every decimation depth on MI355X (tools/ab_engines.py, interleaved launches: 6 % at 4
 	// passes, 11 % at 5).  The v_dot4 form needs no matrix pipe and no LDS staging.
 	int engine = ws.pass0_engine;
-	if (engine < 0) {
-		const char *e = getenv("RTLFM_PASS0");
-		if (e && !strcmp(e, "mfma")) engine = 1;
-		else if (e && !strcmp(e, "valu")) engine = 0;
-		else if (!RTLFM_PASS0_DEFAULT) engine = 0;
-		else engine = 1;
-	}
+	if (engine < 0) engine = RTLFM_PASS0_DEFAULT ? 1 : 0;
 	if (engine == 1) {
 		uint32_t *&t = ws.mfma_taps[p.rotate];
 		if (!t) {
@@ -1044,21 +1077,15 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 		}
 		p.mfma_taps = t;
 	}
-	// enough waves to fill 256 CUs several times over; a segment is a run of whole buffers
-	if (const char *e = getenv("RTLFM_FUSED_DEBUG")) p.debug = atoi(e);
+	p.debug = ws.debug;
 	if (ws.want_stamps) p.debug |= 2;
-	int target_waves = 8192;
-	if (const char *e = getenv("RTLFM_FUSED_WAVES")) target_waves = atoi(e);
-	int segs = (target_waves + nstreams - 1) / nstreams;
-	if (segs > nblocks) segs = nblocks;
-	if (segs < 1) segs = 1;
-	int bps = (nblocks + segs - 1) / segs;
-	segs = (nblocks + bps - 1) / bps;
-	p.segs = segs; p.blocks_per_seg = bps;
-	const int waves = nstreams * segs;
+	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)(c.block_len / kTileBytes));
+	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg;
+	const int waves = nstreams * sp.segs;
 	if (p.debug & 2) {
-		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
+		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; ws.stamp_waves = 0; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
 		p.stamps = ws.stamps;
+		ws.stamp_last = waves;
 	}
 	if (emit_iq) p.variant = RTLFM_ATAN_FAST;  // the emit path lives in the run-time-discriminator kernels
 	if (emit_iq && c.downsample_passes > kMaxP) return launch_one<6, false>(p, waves, q);  // the rest is staged

@@ -16,12 +16,14 @@
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/rtlfm_hip.h"
 #include "staged_kernels.h"
 #include "fused_kernel.h"
 #include "boxcar_kernel.h"
+#include "bw_probe_kernel.h"
 
 using namespace rtlfm;
 
@@ -77,6 +79,7 @@ struct rtlfm_gpu {
 	hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
 	bool tail_pending[2] = {false, false};  // ev_tail[p] has been recorded and not yet waited for
 	bool tail_overlap = true;
+	bool tail_serial_asked = false;         // option tail_serial: never overlap, whatever the stream
 	int32_t *d_lut = nullptr;
 	int32_t *d_mute = nullptr;        // [nstreams*cap_blocks]
 	int32_t *d_levels = nullptr;      // [nstreams*cap_blocks] rms() per buffer of the last run
@@ -88,6 +91,10 @@ struct rtlfm_gpu {
 	struct Ingest *ing = nullptr;     // the callback side (push / run / fetch), allocated on first use
 	bool no_deemph_scan = false;      // stream-range views (ragged runs) keep to the sequential filter
 	fused::Workspace fws;
+	// A/B switches (rtlfm_gpu_set_option); none of them changes a result
+	struct Options {
+		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
+	} opt;
 
 	// timing of the decimating front end
 	bool timing = false;
@@ -222,6 +229,8 @@ static int validate_cfg(const rtlfm_cfg *c)
 	return 0;
 }
 
+extern "C" int rtlfm_cfg_validate(const rtlfm_cfg *cfg) { return cfg ? validate_cfg(cfg) : -EINVAL; }
+
 // ----------------------------------------------------------------- handle ----
 
 static void init_states_host(std::vector<state_t> &v)
@@ -233,6 +242,7 @@ static void init_states_host(std::vector<state_t> &v)
 }
 
 static int create_body(rtlfm_gpu *h);
+static int options_from_env(rtlfm_gpu *h);
 static void ingest_destroy(rtlfm_gpu *h);
 static void ingest_reset(rtlfm_gpu *h);
 
@@ -292,7 +302,7 @@ static int create_body(rtlfm_gpu *h)
 		HIP_TRY(hipEventCreateWithFlags(&h->ev_tail[k], hipEventDisableTiming));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
-	h->tail_overlap = !getenv("RTLFM_TAIL_SERIAL");
+	h->tail_overlap = true;
 	{
 		// what mode_demod() can leave per stream and run: the decimated count (+1 per buffer behind a
 		// boxcar that does not divide it); every later stage but the last one only shrinks it
@@ -317,6 +327,8 @@ static int create_body(rtlfm_gpu *h)
 		HIP_TRY(hipMalloc(&h->d_lut, lut.size() * sizeof(int32_t)));
 		HIP_TRY(hipMemcpy(h->d_lut, lut.data(), lut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
+	int r = options_from_env(h);
+	if (r < 0) return r;
 	return rtlfm_gpu_reset(h);
 }
 
@@ -416,6 +428,10 @@ extern "C" int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *s)
 	if (!h) return -EINVAL;
 	HIP_TRY(sync_all(h));
 	h->stream = s ? (hipStream_t)s : h->own_stream;
+	// On a caller-owned stream everything the handle launches is ordered on THAT stream: the audio
+	// tail does not move to the handle's second stream, so a consumer enqueued on the caller's stream
+	// behind rtlfm_gpu_run_device() sees the finished d_out / d_out_len without any further call.
+	h->tail_overlap = h->stream == h->own_stream && !h->tail_serial_asked;
 	return 0;
 }
 
@@ -449,11 +465,77 @@ extern "C" int rtlfm_gpu_set_path(rtlfm_gpu *h, int path)
 {
 	if (!h || path < 0 || path > 4) return -EINVAL;
 	h->path = path > 2 ? 2 : path;
-	if (path == 2) h->fws.pass0_engine = -1;  // RTLFM_PASS0 / compiled default
+	if (path == 2) h->fws.pass0_engine = -1;  // the compiled default
 	if (path > 2) h->fws.pass0_engine = path - 3;
 	return 0;
 }
 extern "C" int rtlfm_gpu_last_path(rtlfm_gpu *h) { return h ? h->last_path : -EINVAL; }
+
+// The one place the library's tunables and A/B switches live (no environment look-ups on the
+// launch path).  RTLFM_OPTIONS="name=value,..." is applied once, by rtlfm_gpu_create.
+static int *option_slot(rtlfm_gpu *h, const char *name)
+{
+	struct { const char *n; int *p; } tab[] = {
+		{"fused_waves", &h->fws.target_waves}, {"fused_min_tiles", &h->fws.min_tiles},
+		{"fused_tiles_per_seg", &h->fws.tiles_per_seg}, {"fused_debug", &h->fws.debug},
+		{"pass0_engine", &h->fws.pass0_engine},
+		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
+		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores},
+		{"tail_sync", &h->opt.tail_sync},
+	};
+	for (auto &t : tab)
+		if (!strcmp(t.n, name)) return t.p;
+	return nullptr;
+}
+
+extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
+{
+	if (!h || !name) return -EINVAL;
+	if (!strcmp(name, "tail_serial")) {
+		// the audio tail on the front end's stream instead of its own
+		HIP_TRY(sync_all(h));
+		h->tail_overlap = value == 0 && h->stream == h->own_stream;
+		h->tail_serial_asked = value != 0;
+		return 0;
+	}
+	int *slot = option_slot(h, name);
+	if (!slot) return -ENOENT;
+	if (!strcmp(name, "fused_waves") && value < 1) return -EINVAL;
+	if (!strcmp(name, "pass0_engine") && (value < -1 || value > 1)) return -EINVAL;
+	if ((!strcmp(name, "fused_min_tiles") || !strcmp(name, "fused_tiles_per_seg")) && value < 0) return -EINVAL;
+	*slot = (int)value;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
+{
+	if (!h || !name || !value) return -EINVAL;
+	if (!strcmp(name, "tail_serial")) { *value = h->tail_overlap ? 0 : 1; return 0; }
+	int *slot = option_slot(h, name);
+	if (!slot) return -ENOENT;
+	*value = *slot;
+	return 0;
+}
+
+static int options_from_env(rtlfm_gpu *h)
+{
+	const char *e = getenv("RTLFM_OPTIONS");
+	if (!e || !*e) return 0;
+	std::string all(e);
+	size_t at = 0;
+	while (at < all.size()) {
+		size_t end = all.find(',', at);
+		if (end == std::string::npos) end = all.size();
+		const std::string kv = all.substr(at, end - at);
+		const size_t eq = kv.find('=');
+		if (eq != std::string::npos) {
+			int r = rtlfm_gpu_set_option(h, kv.substr(0, eq).c_str(), atol(kv.c_str() + eq + 1));
+			if (r < 0) { fprintf(stderr, "rtlfm_hip: RTLFM_OPTIONS: '%s' not accepted (%d)\n", kv.c_str(), r); return r; }
+		}
+		at = end + 1;
+	}
+	return 0;
+}
 
 extern "C" int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on)
 {
@@ -462,7 +544,6 @@ extern "C" int rtlfm_gpu_timing_enable(rtlfm_gpu *h, int on)
 	return 0;
 }
 
-static int fused_debug();
 static int report_clock_stamps(rtlfm_gpu *h);
 
 extern "C" int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launches)
@@ -470,7 +551,7 @@ extern "C" int rtlfm_gpu_timing_read(rtlfm_gpu *h, double *front_ms, int *launch
 	if (!h) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
 	HIP_TRY(sync_all(h));
-	if (h->fws.stamps && (fused_debug() & 16)) {
+	if (h->fws.stamps && (h->fws.debug & 16)) {
 		int r2 = report_clock_stamps(h);
 		if (r2 < 0) return r2;
 	}
@@ -578,6 +659,11 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		HIP_TRY(hipEventRecord(h->ev_front[par], h->stream));
 		HIP_TRY(hipStreamWaitEvent(h->tail_stream, h->ev_front[par], 0));
 		q = h->tail_stream;
+		// The front end copied the whole record sin -> sout while the previous step's tail may still
+		// have been writing the tail's fields of sin.  The tail stream is in order, so here those are
+		// final: carry them over before any stage of this tail runs (a stage that leaves a field
+		// alone - a skipped stream, an early return - then leaves the right value behind).
+		k_tail_state_copy<<<grid_for(S, 64), 64, 0, q>>>(sin, sout, S);
 	}
 	struct Done {  // whatever path leaves: mark the end of this step's tail
 		rtlfm_gpu *h; int par; bool on;
@@ -613,7 +699,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		// few, long streams: parallel over time (staged_kernels.h, k_deemph_scan_*); the interval
 		// of candidate states must fit a wave (2a + 2 <= kDeemphGap)
 		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan &&
-		                  !getenv("RTLFM_DEEMPH_SEQUENTIAL");
+		                  !h->opt.deemph_sequential;
 		if (scan) {
 			// chunk length: each of the passes A1 and C is one chunk long in time; a chunk must be
 			// long enough for the interval to contract (~100 samples) and, normally, to merge
@@ -630,13 +716,13 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			if (!h->d_deemph_fb) HIP_TRY(hipMalloc(&h->d_deemph_fb, (size_t)S * sizeof(int32_t)));
 			if (!h->d_deemph_list) HIP_TRY(hipMalloc(&h->d_deemph_list, ((size_t)S + 1) * sizeof(int32_t)));
 			const int mcs = mc;
-			const bool dbg_sync = getenv("RTLFM_TAIL_SYNC") != nullptr;
+			const bool dbg_sync = h->opt.tail_sync != 0;
 			// deemph_filter followed directly by low_pass_real (-M wbfm): the replay pass feeds the
 			// resampler's accumulator instead of writing the filtered samples (staged_kernels.h)
-			fuse_lpr = tp.lpr && !tp.adc && !getenv("RTLFM_LPR_SEPARATE");
+			fuse_lpr = tp.lpr && !tp.adc && !h->opt.lpr_separate;
 			if (fuse_lpr) next_dst(&lpr_dst, &lpr_ds);
 			// outputs leave in 16-byte groups where the rows allow it (staged_kernels.h, LprSink)
-			const int lpr_vec = fuse_lpr && (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !getenv("RTLFM_LPR_SCALAR_STORES");
+			const int lpr_vec = fuse_lpr && (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
 			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
 			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
 			const size_t per_wave = 64 / lpc;
@@ -645,7 +731,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			// One pass where the resampler follows directly: every chunk finds its incoming state from the
 			// W samples before it (staged_kernels.h, k_deemph_spec_lpr); the streams it cannot settle
 			// that way (silence) raise a flag and alone go through the four passes below.
-			const bool spec = fuse_lpr && !getenv("RTLFM_DEEMPH_FOUR_PASS");
+			const bool spec = fuse_lpr && !h->opt.deemph_four_pass;
 			const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
 			// chunk length of the one-pass form: about 2720 samples (2040: +1 %, 1360: +2 % on the wbfm step),
 			// and a multiple of the resampler's period fast / gcd(fast, slow) where that is short - then all
@@ -667,7 +753,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const bool spec_arb = tp.arb && !tp.adc && !tp.lpr && D == 1 && !varcnt && Nblk >= 2 && arb_l2 > Nblk &&
 			                      (long long)(Nblk + 1) * arb_l2 < (1ll << 31) && Ws <= 256 &&
 			                      (uintptr_t)cur % 16 == 0 && cur_stride % 8 == 0 && T == nblocks * Nblk &&
-			                      !getenv("RTLFM_DEEMPH_FOUR_PASS");
+			                      !h->opt.deemph_four_pass;
 			// the four passes (and the separate resampler) afterwards: for every stream, or - behind a
 			// one-pass kernel - for the streams it flagged, listed by k_flag_list and walked by small grids
 			const int32_t *only = spec || spec_arb ? h->d_deemph_list : nullptr;
@@ -898,22 +984,17 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, Nblk, D, d_out, out_stride, d_out_len);
 }
 
-static int fused_debug()
-{
-	const char *e = getenv("RTLFM_FUSED_DEBUG");
-	return e ? atoi(e) : 0;
-}
 
 // shader clock held during the last fused fifth_order launch: every wave stamps s_memtime (shader
 // clock) and s_memrealtime (100 MHz) at its first and last instruction
 static int read_clock_stamps(rtlfm_gpu *h, double *mhz, double *span_ms, int *waves)
 {
 	HIP_TRY(sync_all(h));
-	if (!h->fws.stamps || h->fws.stamp_waves <= 0) return -ENODATA;
-	std::vector<unsigned long long> st((size_t)h->fws.stamp_waves * 4);
+	if (!h->fws.stamps || h->fws.stamp_last <= 0) return -ENODATA;
+	std::vector<unsigned long long> st((size_t)h->fws.stamp_last * 4);
 	HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
 	double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
-	for (int w = 0; w < h->fws.stamp_waves; w++) {
+	for (int w = 0; w < h->fws.stamp_last; w++) {
 		double dc = (double)(st[w * 4 + 1] - st[w * 4]), dr = (double)(st[w * 4 + 3] - st[w * 4 + 2]);
 		if (dr > 0) { sum += dc / dr * 100.0; n++; }
 		if (st[w * 4 + 2] < t0) t0 = st[w * 4 + 2];
@@ -972,7 +1053,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	// bit 2 with bit 8: report the stamps of every launch (synchronises, so the GPU idles between
 	// launches and clocks up); bit 2 alone with bit 16: only when timing_read() asks, i.e. the last
 	// launch of an uninterrupted sequence
-	if (h->fws.stamps && (fused_debug() & 2) && !(fused_debug() & 16)) {
+	if (h->fws.stamps && (h->fws.debug & 2) && !(h->fws.debug & 16)) {
 		int r2 = report_clock_stamps(h);
 		if (r2 < 0) return r2;
 	}
@@ -1268,6 +1349,15 @@ extern "C" int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint3
 	if (!h || !iq || stream < 0 || stream >= h->nstreams) return -EINVAL;
 	// actual_length of a bulk transfer: whole 512-byte USB packets, at most the buffer
 	if (len == 0 || len > h->cfg.block_len || len % 512) return -EINVAL;
+	if (len != h->cfg.block_len) {
+		// a short buffer is demodulated as a buffer of that length: refuse here, before anything is
+		// queued, what the chain cannot take (e.g. a length the fifth_order passes do not divide)
+		rtlfm_cfg c = h->cfg;
+		c.block_len = len;
+		c.max_blocks = 1;
+		const int v = validate_cfg(&c);
+		if (v < 0) return v;
+	}
 	int r = ingest_ensure(h);
 	if (r < 0) return r;
 	Ingest *in = h->ing;
@@ -1341,6 +1431,14 @@ static int run_ragged(rtlfm_gpu *h, Ingest *in, int f, int nb)
 		HIP_TRY(hipMalloc(&in->d_tmp, (size_t)S * in->ostride * sizeof(int16_t)));
 		HIP_TRY(hipMalloc(&in->d_tmp_len, (size_t)S * sizeof(int32_t)));
 	}
+	// The views run their audio tail on the handle's main stream: the tails of the two previous
+	// (batched) steps may still be running on the tail stream, writing the state copy and the res[]
+	// sets the views are about to read.  Order the main stream behind both, on the handle itself.
+	for (int p = 0; p < 2; p++)
+		if (h->tail_pending[p]) {
+			HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_tail[p], 0));
+			h->tail_pending[p] = false;
+		}
 	HIP_TRY(hipMemsetAsync(in->d_result_len[f], 0, (size_t)S * sizeof(int32_t), h->stream));
 	for (int j = 0; j < nb; j++) {
 		// every range of this buffer reads st[cur] and writes the next copy; the rotation advances once
@@ -1578,6 +1676,77 @@ extern "C" int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void 
 	if (n16) k_rotate_90_u8<<<grid_for(n16), 256, 0, q>>>((uint4 *)d_buf, n16);
 	if (len & 8) k_rotate_90_u8_tail<<<1, 1, 0, q>>>((uint2 *)((uint8_t *)d_buf + len - 8));
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// The box's own streaming ceilings, measured with the front end's access pattern and none of its
+// arithmetic (bw_probe_kernel.h).  bench.py puts them next to the nominal 8 TB/s.
+extern "C" int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int reps, double *read_gbs, double *rw_gbs,
+                                  double *write_fraction)
+{
+	if (bytes < ((size_t)64 << 20) || reps < 1 || write_div < 1) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	const int waves = 8192;
+	const size_t seg = (bytes / waves) & ~(size_t)8191;
+	if (seg < 8192) return -EINVAL;
+	const size_t total = seg * waves;
+	// bytes stored per lane and tile: the power of two nearest to 128 / write_div
+	int W = 2;
+	for (int w : {2, 4, 8, 16})
+		if (fabs(128.0 / write_div - w) < fabs(128.0 / write_div - W)) W = w;
+	uint8_t *d_in = nullptr, *d_wr = nullptr;
+	uint32_t *d_sink = nullptr;
+	hipEvent_t a = nullptr, b = nullptr;
+	int rc = 0;
+	auto fail = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = e == hipErrorOutOfMemory ? -ENOMEM : -EIO; return e != hipSuccess; };
+	do {
+		if (fail(hipMalloc(&d_in, total)) || fail(hipMalloc(&d_wr, total / 8192 * 64 * 16 + 4096)) || fail(hipMalloc(&d_sink, (size_t)waves * 256))) break;
+		if (fail(hipMemset(d_in, 0x5a, total))) break;
+		if (fail(hipEventCreate(&a)) || fail(hipEventCreate(&b))) break;
+		double out[2] = {0, 0};
+		for (int leg = 0; leg < 2 && !rc; leg++) {
+			auto go = [&]() {
+				if (leg == 0) hipLaunchKernelGGL((bwprobe::k_stream<0>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
+				else if (W == 2) hipLaunchKernelGGL((bwprobe::k_stream<2>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
+				else if (W == 4) hipLaunchKernelGGL((bwprobe::k_stream<4>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
+				else if (W == 8) hipLaunchKernelGGL((bwprobe::k_stream<8>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
+				else hipLaunchKernelGGL((bwprobe::k_stream<16>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
+			};
+			for (int i = 0; i < 3; i++) go();  // clocks, TLBs
+			if (fail(hipEventRecord(a, 0))) break;
+			for (int i = 0; i < reps; i++) go();
+			if (fail(hipEventRecord(b, 0)) || fail(hipEventSynchronize(b))) break;
+			float ms = 0;
+			if (fail(hipEventElapsedTime(&ms, a, b))) break;
+			const double moved = (double)total * (leg ? 1.0 + W / 128.0 : 1.0);
+			out[leg] = moved * reps / (ms * 1e-3) / 1e9;
+		}
+		if (read_gbs) *read_gbs = out[0];
+		if (rw_gbs) *rw_gbs = out[1];
+		if (write_fraction) *write_fraction = W / 128.0;
+	} while (0);
+	if (a) hipEventDestroy(a);
+	if (b) hipEventDestroy(b);
+	if (d_in) hipFree(d_in);
+	if (d_wr) hipFree(d_wr);
+	if (d_sink) hipFree(d_sink);
+	return rc;
+}
+
+// the raw stamps of the last stamped launch: per wave {shader clock at start, at end, 100 MHz
+// real-time counter at start, at end}
+extern "C" int rtlfm_gpu_clock_stamps(rtlfm_gpu *h, uint64_t *out, int cap_waves, int *waves)
+{
+	if (!h || !waves) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(sync_all(h));
+	if (!h->fws.stamps || h->fws.stamp_last <= 0) return -ENODATA;
+	*waves = h->fws.stamp_last;
+	if (!out) return 0;
+	if (cap_waves < h->fws.stamp_last) return -ENOBUFS;
+	HIP_TRY(hipMemcpy(out, h->fws.stamps, (size_t)h->fws.stamp_last * 32, hipMemcpyDeviceToHost));
 	return 0;
 }
 

@@ -41,6 +41,7 @@ struct rtlpower_gpu {
 	size_t dec_cap_reads = 0;
 	uint8_t *d_one = nullptr;  // landing zone of rtlpower_gpu_scan()
 	bool timing = false;
+	int groups = 0;  // option "groups": workgroups per stream of the FFT kernel (0 = automatic)
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
 
@@ -215,6 +216,8 @@ static int validate(const rtlpower_cfg *c)
 	return 0;
 }
 
+extern "C" int rtlpower_cfg_validate(const rtlpower_cfg *cfg) { return cfg ? validate(cfg) : -EINVAL; }
+
 static int power_create_body(rtlpower_gpu *h);
 
 extern "C" int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int device, rtlpower_gpu **out)
@@ -353,6 +356,17 @@ extern "C" int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream)
 	return 0;
 }
 
+extern "C" int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long value)
+{
+	if (!h || !name) return -EINVAL;
+	if (!strcmp(name, "groups")) {
+		if (value < 0) return -EINVAL;
+		h->groups = (int)value;
+		return 0;
+	}
+	return -ENOENT;
+}
+
 extern "C" int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on)
 {
 	if (!h) return -EINVAL;
@@ -469,7 +483,7 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		int groups = (want + S - 1) / S;
 		if (groups > nreads) groups = nreads;
 		if (groups < 1) groups = 1;
-		if (const char *e = getenv("RTLPOWER_GROUPS")) groups = atoi(e) > 0 ? (atoi(e) < nreads ? atoi(e) : nreads) : groups;
+		if (h->groups > 0) groups = h->groups < nreads ? h->groups : nreads;
 		p.groups = groups;
 	}
 	const unsigned grid = (unsigned)S * (unsigned)p.groups;

@@ -1523,4 +1523,18 @@ __global__ void k_scale_cnt(int32_t *cnt, int nstreams, int mul, int div)
 	RTLFM_GRID_STRIDE(s, nstreams) cnt[s] = cnt[s] * mul / div;
 }
 
+// The fields the audio tail owns (low_pass_real, deemph_filter, dc_block_audio_filter), carried
+// from the previous state copy at the start of a tail that runs on its own stream (rtlfm_hip.hip,
+// run_tail): the front end's whole-record copy may have read them while the previous tail was
+// still writing.
+__global__ void k_tail_state_copy(const state_t *__restrict__ sin, state_t *__restrict__ sout, int nstreams)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) {
+		sout[s].now_lpr = sin[s].now_lpr;
+		sout[s].prev_lpr_index = sin[s].prev_lpr_index;
+		sout[s].deemph_avg = sin[s].deemph_avg;
+		sout[s].dc_avg = sin[s].dc_avg;
+	}
+}
+
 }  // namespace rtlfm

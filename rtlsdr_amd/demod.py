@@ -19,7 +19,8 @@ from .capi import RtlfmCfg, RtlfmStreamState, check
 class GpuDemod:
     """``nstreams`` independent rtl_fm demodulators sharing one configuration."""
 
-    def __init__(self, cfg: RtlfmCfg, nstreams: int = 1, device: int = 0, lib_path: str | None = None):
+    def __init__(self, cfg: RtlfmCfg, nstreams: int = 1, device: int = 0, lib_path: str | None = None,
+                 options: dict | None = None):
         self.lib = capi.load(lib_path)  # lib_path: another build of the library (A/B measurements)
         self.cfg = cfg
         self.nstreams = nstreams
@@ -27,6 +28,8 @@ class GpuDemod:
         h = C.c_void_p()
         check(self.lib.rtlfm_gpu_create(C.byref(cfg), nstreams, device, C.byref(h)), "rtlfm_gpu_create")
         self._h = h
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -133,6 +136,24 @@ class GpuDemod:
 
     def set_stream(self, hip_stream_ptr: int):
         check(self.lib.rtlfm_gpu_set_stream(self._h, hip_stream_ptr or None), "rtlfm_gpu_set_stream")
+
+    def set_option(self, name: str, value: int):
+        """rtlfm_gpu_set_option: tunables and A/B switches by name (include/rtlfm_hip.h)."""
+        check(self.lib.rtlfm_gpu_set_option(self._h, name.encode(), int(value)), f"rtlfm_gpu_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_long()
+        check(self.lib.rtlfm_gpu_get_option(self._h, name.encode(), C.byref(v)), f"rtlfm_gpu_get_option({name})")
+        return v.value
+
+    def clock_stamps(self):
+        """uint64 [waves, 4] of the last stamped launch: shader clock first / last, 100 MHz counter first / last."""
+        n = C.c_int()
+        if self.lib.rtlfm_gpu_clock_stamps(self._h, None, 0, C.byref(n)) < 0:
+            return None
+        out = np.zeros((n.value, 4), dtype=np.uint64)
+        check(self.lib.rtlfm_gpu_clock_stamps(self._h, out.ctypes.data, n.value, C.byref(n)), "rtlfm_gpu_clock_stamps")
+        return out
 
     def set_path(self, path: int):
         check(self.lib.rtlfm_gpu_set_path(self._h, path), "rtlfm_gpu_set_path")

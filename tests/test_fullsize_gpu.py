@@ -15,13 +15,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def _run(cfg, iq, path, splits=None):
+def _run(cfg, iq, path, splits=None, options=None):
     from rtlsdr_amd.demod import GpuDemod
     ns = iq.shape[0]
     L = int(cfg.block_len)
     nb = iq.shape[1] // L
     outs, lens = [], []
-    with GpuDemod(cfg, ns, 0) as g:
+    with GpuDemod(cfg, ns, 0, options=options) as g:
         g.set_path(path)
         for (b0, b1) in (splits or [(0, nb)]):
             o, n = g.run_torch(iq[:, b0 * L:b1 * L] if (b0, b1) != (0, nb) else iq)
@@ -155,6 +155,14 @@ def test_north_star_shape_4096_streams(oracle_lib):
         d = np.abs(got[s].cpu().numpy().astype(np.int32) - want.astype(np.int32))
         assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()))
         assert gu.state_dict(fst[s], False) == gu.state_dict(st, False)
+    # ONE buffer per stream and launch - what a live capture hands over (src/rtl_fm.c:1339-1343): each
+    # buffer is cut into segments inside the buffer (2 waves per stream by default, 4 when asked)
+    for opts in (None, dict(fused_waves=16384)):
+        po_, pl_, pst, used = _run(cfg, iq, 2, splits=[(0, 1), (1, 2), (2, 3), (3, 4)], options=opts)
+        assert used == 2
+        assert torch.equal(_concat(po_, pl_), got), f"one buffer per launch, {opts}"
+        for s in fst:
+            assert gu.state_dict(pst[s], False) == gu.state_dict(fst[s], False)
 
 
 def test_wbfm_shape_full_size(oracle_lib):
@@ -170,11 +178,7 @@ def test_wbfm_shape_full_size(oracle_lib):
     iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0), fs=1.02e6, dev_hz=75e3, amplitude=30.0)
     fo, fl, fst, used = _run(cfg, iq, 2)
     assert used == 2
-    os.environ["RTLFM_DEEMPH_SEQUENTIAL"] = "1"
-    try:
-        so, sl, sst, used1 = _run(cfg, iq, 1)
-    finally:
-        del os.environ["RTLFM_DEEMPH_SEQUENTIAL"]
+    so, sl, sst, used1 = _run(cfg, iq, 1, options=dict(deemph_sequential=1))
     assert used1 == 1 and torch.equal(fl[0], sl[0])
     n = int(fl[0].max())
     mask = torch.arange(n, device=iq.device)[None, :] < fl[0][:, None]

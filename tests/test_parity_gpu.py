@@ -37,8 +37,9 @@ def assert_parity(got, want, cfg, what=""):
     assert nbad <= max(1, int(1e-4 * got.size)), f"{what}: {nbad}/{got.size} differ by 1 LSB"
 
 
-def gpu_run(cfg, iq2d, path=0, splits=None):
-    """iq2d: uint8 [ns, nb*L].  Returns (list of per-stream outputs, states, path used)."""
+def gpu_run(cfg, iq2d, path=0, splits=None, options=None):
+    """iq2d: uint8 [ns, nb*L].  Returns (list of per-stream outputs, states, path used).
+    options: rtlfm_gpu_set_option name -> value (segmentation of the front end, A/B switches)."""
     from rtlsdr_amd.demod import GpuDemod
     ns = iq2d.shape[0]
     L = int(cfg.block_len)
@@ -46,7 +47,7 @@ def gpu_run(cfg, iq2d, path=0, splits=None):
     cfg = RtlfmCfg.from_buffer_copy(bytes(cfg))
     cfg.max_blocks = nb
     outs = [[] for _ in range(ns)]
-    with GpuDemod(cfg, ns, 0) as g:
+    with GpuDemod(cfg, ns, 0, options=options) as g:
         g.set_path(path)
         d = torch.from_numpy(np.ascontiguousarray(iq2d)).cuda()
         for (b0, b1) in (splits or [(0, nb)]):
@@ -230,6 +231,86 @@ def test_fused_fullscale_random_bytes(oracle_lib, engine):
         assert used == 2
         for s in range(ns):
             assert np.array_equal(outs[s], want[s, :want_len[s]]), (passes, fir9, s)
+
+
+@pytest.mark.parametrize("atan", [0, 1])
+@pytest.mark.parametrize("front", ["p1", "p3", "p4", "p4fir", "p6fir", "box2", "box5", "box10", "box64"])
+def test_fullscale_random_bytes_std_and_fast_end_to_end(oracle_lib, front, atan):
+    """Full-scale random bytes through the one-launch front ends WITH `-A std` and `-A fast`, end to
+    end: at this amplitude polar_disc_fast's 4096 * (x -/+ |y|) wraps in 32 bits (src/rtl_fm.c:851-872;
+    the oracle spells the wrap out as the gcc build of the reference behaves, pinned per function by
+    test_fast_atan2_against_oracle) and the conjugate products of polar_discriminant reach 2 * 2^30.
+    k_fused / k_boxcar_scan must agree sample for sample, and so must the carried state."""
+    if front.startswith("box"):
+        D = int(front[3:])
+        ov = dict(downsample=D, downsample_passes=0, custom_atan=atan)
+    else:
+        passes = int(front[1])
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if front.endswith("fir") else 0,
+                  custom_atan=atan)
+    L, nb, ns = 16384, 3, 12
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.random_u8(ns, L * nb, seed=900 + len(front) + atan)
+    iq[ns - 1] = np.where(np.arange(L * nb) % 2 == 0, 255, 0)  # I = +128, Q = -127 throughout
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for opts in (None, dict(fused_waves=1)):
+        outs, sts, used = gpu_run(cfg, iq, path=2, options=opts)
+        assert used == 2
+        for s in range(ns):
+            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{front} atan={atan} stream {s} {opts}")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+
+
+SEGMENTATIONS = [dict(fused_waves=1), dict(fused_tiles_per_seg=1), dict(fused_tiles_per_seg=3), dict(fused_tiles_per_seg=5),
+                 dict(fused_min_tiles=2, fused_waves=100000)]
+
+
+@pytest.mark.parametrize("seg", SEGMENTATIONS, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+@pytest.mark.parametrize("front", ["p2", "p4", "p5fir", "p6fir", "box6fast", "box10", "box334"])
+def test_segments_inside_buffers(oracle_lib, front, seg):
+    """A front-end wave owns a run of 8 KiB tiles that may begin and end anywhere inside a callback
+    buffer (one 262144-byte buffer per stream and launch is what a live capture delivers: the launch
+    still has to fill the GPU).  Every segmentation - one wave per stream, a wave per tile, segments of
+    3 and 5 tiles that straddle the buffer boundaries differently in every buffer - gives the
+    reference's samples and state: the buffer-boundary rules of fifth_order (src/rtl_fm.c:782-787,
+    800-805), of rotate16_neg90's phase and of fm_demod's first sample follow from a tile's position
+    in its buffer, not from where a wave happens to start."""
+    if front.startswith("box"):
+        D = int(front[3:].replace("fast", ""))
+        ov = dict(downsample=D, downsample_passes=0, custom_atan=1 if "fast" in front else 0)
+        amp = 60.0 if "fast" not in front else 60.0 / D * 8
+    else:
+        passes = int(front[1])
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if front.endswith("fir") else 0)
+        amp = 60.0
+    L, nb, ns = 65536, 3, 5  # 8 tiles per buffer
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=3100 + len(front), fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    iq[ns - 1] = synth.random_u8(1, L * nb, seed=5)[0] if "fast" not in front else iq[ns - 1]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits in (None, [(0, 1), (1, 2), (2, 3)]):
+        outs, sts, used = gpu_run(cfg, iq, path=2, splits=splits, options=seg)
+        assert used == 2
+        for s in range(ns):
+            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{front} {seg} {splits} stream {s}")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
+
+
+def test_options_by_name():
+    """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
+    from rtlsdr_amd.demod import GpuDemod
+    cfg = make_cfg(dict(downsample=16, downsample_passes=4), 16384, 2)
+    with GpuDemod(cfg, 2, 0) as g:
+        assert g.get_option("fused_waves") == 8192 and g.get_option("fused_min_tiles") == 8
+        g.set_option("fused_waves", 100)
+        assert g.get_option("fused_waves") == 100
+        g.set_option("tail_serial", 1)
+        assert g.get_option("tail_serial") == 1
+        with pytest.raises(capi.RtlfmError) as e:
+            g.set_option("no_such_option", 1)
+        assert e.value.code == -2  # -ENOENT
+        with pytest.raises(capi.RtlfmError):
+            g.set_option("fused_waves", 0)
 
 
 @pytest.mark.parametrize("engine", ENGINES)
@@ -804,6 +885,143 @@ def test_short_callback_buffers(oracle_lib, name):
         assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (name, s)
 
 
+@pytest.mark.parametrize("name", ["wbfm_preset", "c3_p6_fir9_deemph_up22050", "box42_dc"])
+def test_ragged_run_right_behind_a_batched_run(oracle_lib, name):
+    """A run with a short buffer takes its audio tail on the main stream; the tail of the batched run
+    before it may still be running on the tail stream, writing the state copy and the work buffers the
+    short-buffer run reads.  No host synchronisation between the two runs here (fetch would hide it):
+    run (full buffers) -> push short -> run -> fetch, several rounds; the second run's audio depends on
+    the filter / resampler state the first one's tail leaves."""
+    from rtlsdr_amd.demod import GpuDemod
+    ov, sig = [(o, s) for n, o, s in CASES if n == name][0]
+    L, ns, depth, rounds = 16384, 96, 4, 4
+    cfg = make_cfg(ov, L, depth)
+    nb = rounds * (depth + 1)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=8181, **sig)
+    iq[3] = 127  # a silent stream: the one-pass deemph kernels hand it to the fall-back passes
+    lens = np.full((ns, nb), L, dtype=np.int64)
+    for r in range(rounds):
+        lens[:, r * (depth + 1) + depth] = 8192 if r % 2 == 0 else 4096
+    blocks = [[iq[s, b * L:b * L + lens[s, b]] for b in range(nb)] for s in range(ns)]
+    want, wst = _oracle_ragged(oracle_lib, cfg, blocks)
+    # the oracle's output per buffer, to pick the short-buffer runs' share
+    lib = oracle_lib.oracle()
+    got = [[] for _ in range(ns)]
+    expect = [[] for _ in range(ns)]
+    for s in range(ns):
+        st = oracle_lib.new_states(1)[0]
+        scratch = np.zeros(2 * 262144 + 64, dtype=np.int16)
+        for b in range(nb):
+            n = lib.orc_block(C.byref(cfg), C.byref(st), np.ascontiguousarray(blocks[s][b]), blocks[s][b].size, scratch)
+            if b % (depth + 1) == depth:
+                expect[s].append(scratch[:n].copy())
+    with GpuDemod(cfg, ns, 0) as g:
+        for r in range(rounds):
+            b0 = r * (depth + 1)
+            for b in range(b0, b0 + depth):
+                for s in range(ns):
+                    g.rtlsdr_callback(blocks[s][b], s)
+            g.full_demod()                       # batched: tail on its own stream
+            for s in range(ns):
+                g.rtlsdr_callback(blocks[s][b0 + depth], s)
+            g.full_demod()                       # short buffers: views, tail on the main stream
+            o, n = g.fetch_all()
+            for s in range(ns):
+                got[s].append(o[s, :n[s]].copy())
+        sts = [g.state_get(s) for s in range(ns)]
+    for s in range(ns):
+        assert_parity(np.concatenate(got[s]), np.concatenate(expect[s]), cfg, f"{name} stream {s}")
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (name, s)
+
+
+@pytest.mark.parametrize("name", ["wbfm_preset", "c3_p6_fir9_deemph_up22050", "box6_wbfm_dc"])
+def test_tail_overlap_is_deterministic_over_many_steps(oracle_lib, name):
+    """The audio tail of step k runs on its own stream beside the front end of step k + 1, and the
+    front end copies the whole state record while that tail may still be writing its fields.  Twelve
+    steps back to back without a host synchronisation, silent and half-silent streams included (the
+    one-pass filter kernels skip those and the fall-back passes return early for everyone else):
+    outputs of every step and the final state equal the serial (tail_serial = 1) run and the oracle."""
+    from rtlsdr_amd.demod import GpuDemod
+    ov, sig = [(o, s) for n, o, s in CASES if n == name][0]
+    L, ns, depth, steps = 65536, 48, 2, 12
+    cfg = make_cfg(ov, L, depth)
+    iq = synth.fm_iq_u8(ns, L // 2 * depth * steps, seed=9292, **sig)
+    iq[1] = 127
+    iq[2, L * 5:L * 11] = 127
+    iq[5, :L * 7] = 127
+    want, want_len, wst = oracle_lib.run_batch(make_cfg(ov, L, depth * steps), iq, nthreads=4)
+    d = torch.from_numpy(iq).cuda()
+    res = {}
+    for serial in (0, 1):
+        with GpuDemod(cfg, ns, 0, options=dict(tail_serial=serial)) as g:
+            cap = g.result_cap(depth)
+            outs = [torch.zeros((ns, cap), dtype=torch.int16, device="cuda") for _ in range(steps)]
+            lens = [torch.zeros(ns, dtype=torch.int32, device="cuda") for _ in range(steps)]
+            parts = [d[:, k * depth * L:(k + 1) * depth * L].contiguous() for k in range(steps)]
+            torch.cuda.synchronize()
+            for k in range(steps):  # no synchronisation in between
+                g.run_device(parts[k].data_ptr(), parts[k].stride(0), depth, outs[k].data_ptr(), outs[k].stride(0),
+                             lens[k].data_ptr())
+            g.sync()
+            cat = [np.concatenate([outs[k][s, :int(lens[k][s])].cpu().numpy() for k in range(steps)]) for s in range(ns)]
+            res[serial] = (cat, [g.state_get(s) for s in range(ns)])
+    for s in range(ns):
+        assert np.array_equal(res[0][0][s], res[1][0][s]), (name, s)
+        assert_parity(res[0][0][s], want[s, :want_len[s]], cfg, f"{name} stream {s}")
+        for serial in (0, 1):
+            assert gu.state_dict(res[serial][1][s], False) == gu.state_dict(wst[s], False), (name, s, serial)
+
+
+def test_push_rejects_lengths_the_chain_cannot_take():
+    """A short buffer is demodulated as a buffer of that length; a length the configured chain cannot
+    take (here: 512 bytes through 10 fifth_order passes need a multiple of 2048) is refused by push()
+    itself, before anything is queued - not by the run that would have to undo half of its work."""
+    from rtlsdr_amd.demod import GpuDemod
+    cfg = make_cfg(dict(downsample=1024, downsample_passes=10), 16384, 2)
+    with GpuDemod(cfg, 2, 0) as g:
+        buf = np.full(16384, 127, np.uint8)
+        g.rtlsdr_callback(buf, 0)
+        with pytest.raises(capi.RtlfmError) as e:
+            g.rtlsdr_callback(buf[:512], 0)
+        assert e.value.code == -22
+        g.rtlsdr_callback(buf[:4096], 0)   # a multiple of 2 << 10: fine
+        g.rtlsdr_callback(buf, 1); g.rtlsdr_callback(buf[:4096], 1)
+        g.full_demod()
+        o, n = g.fetch_all()
+        assert list(n) == [10, 10]
+
+
+def test_caller_stream_orders_the_audio_tail(oracle_lib):
+    """rtlfm_gpu_set_stream: on a caller-owned stream everything is ordered on that stream, the audio
+    tail included - a consumer enqueued on it behind run_device sees the finished output without
+    release_to / sync."""
+    from rtlsdr_amd.demod import GpuDemod
+    ov, sig = [(o, s) for n, o, s in CASES if n == "wbfm_preset"][0]
+    L, ns, nb = 65536, 64, 4
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=1717, **sig)
+    want, want_len, _ = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    d = torch.from_numpy(iq).cuda()
+    st = torch.cuda.Stream()
+    with GpuDemod(cfg, ns, 0) as g:
+        g.set_stream(st.cuda_stream)
+        assert g.get_option("tail_serial") == 1
+        cap = g.result_cap(nb)
+        out = torch.zeros((ns, cap), dtype=torch.int16, device="cuda")
+        n = torch.zeros(ns, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            g.run_device(d.data_ptr(), d.stride(0), nb, out.data_ptr(), out.stride(0), n.data_ptr())
+            snap, nsnap = out.clone(), n.clone()   # consumer on the caller's stream, no other ordering
+        st.synchronize()
+        g.set_stream(0)
+        assert g.get_option("tail_serial") == 0
+    snap, nsnap = snap.cpu().numpy(), nsnap.cpu().numpy()
+    assert np.array_equal(nsnap, want_len)
+    for s in range(ns):
+        assert np.array_equal(snap[s, :nsnap[s]], want[s, :want_len[s]]), s
+
+
 def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
     """The staging ring has two halves: callbacks keep pushing (from several threads) while the
     previous run's transfer and kernels are in flight, results are fetched one run late, nothing is
@@ -842,7 +1060,7 @@ def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
 
 @pytest.mark.parametrize("a,rates,scalar", [(13, (170000, 32000), 0), (2, (48000, 11025), 0), (30, (240000, 96000), 0),
                                             (9, (170000, 169999), 0), (13, (170000, 32000), 1)])
-def test_deemph_replay_feeds_low_pass_real(oracle_lib, monkeypatch, a, rates, scalar):
+def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates, scalar):
     """deemph_filter followed directly by low_pass_real on long runs (-M wbfm's tail): the time-parallel
     filter's replay pass feeds the resampler's accumulator itself; outputs that straddle chunk
     boundaries are put together afterwards.  Carried / injected accumulator, phase and filter state
@@ -851,8 +1069,6 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, monkeypatch, a, rates, sc
     four passes), runs split over launches.  The resampler's outputs leave in 16-byte groups
     (LprSink); `scalar`: one by one, as for output rows that are not 16-byte aligned."""
     from rtlsdr_amd.demod import GpuDemod
-    if scalar:
-        monkeypatch.setenv("RTLFM_LPR_SCALAR_STORES", "1")
     L, nb, ns = 32768, 6, 6
     ov = dict(downsample=6, custom_atan=1, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],
               resampler=capi.RESAMPLE_LOW_PASS_REAL)
@@ -870,7 +1086,7 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, monkeypatch, a, rates, sc
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
     for splits in (None, [(0, 2), (2, 3), (3, 6)]):
         outs = [[] for _ in range(ns)]
-        with GpuDemod(cfg, ns, 0) as g:
+        with GpuDemod(cfg, ns, 0, options=dict(lpr_scalar_stores=scalar)) as g:
             for s in range(ns):
                 g.state_set(s, st_copy[s])
             d = torch.from_numpy(iq).cuda()

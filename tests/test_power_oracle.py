@@ -65,6 +65,51 @@ def test_power_functions_against_live_reference(oracle_lib):
         ref.close()
 
 
+def _random_power_cfg(rng):
+    kw = dict(bin_e=int(rng.integers(0, 15)), window=int(rng.integers(0, 8)), peak_hold=int(rng.random() < 0.25))
+    kw["buf_len"] = int(rng.choice([16384, 16384, 32768, 65536]))
+    r = rng.random()
+    if r < 0.3:
+        kw.update(downsample=int(rng.choice([2, 3, 5, 7, 16])), boxcar=1)
+    elif r < 0.6:
+        p_ = int(rng.integers(1, 5))
+        kw.update(downsample=1 << p_, downsample_passes=p_, boxcar=0, comp_fir_size=int(rng.choice([0, 9])))
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_SCANNER", "64"))))
+def test_oracle_scan_against_live_scanner(oracle_lib, seed):
+    """The committed pin of the rtl_power oracle at the level of scanner() itself
+    (src/rtl_power.c:642-720, compiled in place, reading through the file-backed device layer): seeded
+    random configurations - the same generator as the GPU sweep, tests/test_power_gpu.py - FM signal and
+    full-scale random bytes, 2..4 reads, avg[] (int64) and samples identical.  Configurations outside
+    scanner()'s own domain (rtlpower_cfg_validate: a trailing frame past the read, where the reference
+    transforms what its static buffer still holds) are skipped and counted."""
+    if not oracle_lib.have_power_reference():
+        pytest.skip("oracle/_ref not built here")
+    from rtlsdr_amd import build as hipbuild
+    from rtlsdr_amd import capi, synth
+    hipbuild.build()
+    lib = capi.load()
+    rng = np.random.default_rng(5000 + seed)
+    kw = _random_power_cfg(rng)
+    cfg = RtlpowerCfg.default(**kw)
+    if lib.rtlpower_cfg_validate(C.byref(cfg)) < 0:
+        pytest.skip(f"outside scanner()'s domain: {kw}")
+    L, nr = int(cfg.buf_len), int(rng.integers(2, 5))
+    iq = np.concatenate([synth.fm_iq_u8(1, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=100 + seed),
+                         synth.random_u8(1, L * nr, seed=200 + seed)])
+    avg, n = oracle_lib.power_scan_batch(cfg, iq)
+    ref = oracle_lib.PowerReference()
+    try:
+        for s in range(2):
+            ravg, rn = ref.scan_stream(cfg, iq[s])
+            assert rn == n[s], (kw, s)
+            assert np.array_equal(ravg, avg[s]), (kw, s)
+    finally:
+        ref.close()
+
+
 def test_remove_dc_removes_only_half(oracle_lib):
     """p2 quirk: the sum over N/2 samples is divided by N."""
     lib = oracle_lib._power_lib()

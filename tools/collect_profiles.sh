@@ -2,12 +2,13 @@
 # tools/collect_profiles.sh — on the GPU box: for every measured workload the bench line, right
 # behind it the rocprofv3 kernel-trace stats of the same workload (the box drifts by a few per cent
 # over minutes at its power cap, so the two that have to agree are taken back to back), and PMC
-# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/r02/ (copy
+# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r03) (copy
 # what should be judged into profiles/ afterwards; the raw traces are deleted, they are large).
 # One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r02
+ROUND=${ROUND:-r03}
+OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 top() { # csv title
 python3 - "$1" "$2" <<'PY'
@@ -23,7 +24,7 @@ for r in rows[:10]:
 PY
 }
 # long enough that the clock ramp of the first launches after idle does not weigh on the averages
-COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0"
+COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0 --ceiling 0 --also 0"
 for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
   tag=${spec%%:*}; args=${spec#*:}
   if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $tag "; then continue; fi
@@ -40,11 +41,18 @@ for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--box
   rm -rf $OUT/trace_$tag $OUT/trace_$tag.log
 done
 cd $ROOT
-if [ -n "${ONLY:-}" ]; then du -sh $ROOT/gpurun_out; exit 0; fi  # ONLY="wbfm c3": those workloads again, no PMC passes
-bash tools/prof_pmc.sh r02_c2 > /dev/null 2>&1
-PMC_KERNEL=k_boxcar_scan bash tools/prof_pmc.sh r02_box10 --boxcar 10 > /dev/null 2>&1
-PMC_KERNEL=k_boxcar_scan bash tools/prof_pmc.sh r02_box6 --boxcar 6 > /dev/null 2>&1
-PMC_KERNEL=k_power_scan bash tools/prof_pmc.sh r02_c4 --workload c4 > /dev/null 2>&1
-for t in c2 box10 box6 c4; do cp $ROOT/gpurun_out/pmc_r02_$t/summary.txt $OUT/pmc_$t.txt; rm -rf $ROOT/gpurun_out/pmc_r02_$t; done
+if [ -n "${ONLY:-}" ] && [ -z "${PMC_ONLY:-}" ]; then du -sh $ROOT/gpurun_out; exit 0; fi  # ONLY="wbfm c3": those workloads again, no PMC passes; PMC_ONLY="c3 wbfm": those PMC sets
+pmc() { # tag kernels bench-args...
+  local tag=$1 kernels=$2; shift 2
+  PMC_KERNELS="$kernels" bash tools/prof_pmc.sh ${ROUND}_$tag "$@" > /dev/null 2>&1
+  for k in $kernels; do cp $ROOT/gpurun_out/pmc_${ROUND}_$tag/summary_$k.txt $OUT/pmc_${tag}_$k.txt; done
+  rm -rf $ROOT/gpurun_out/pmc_${ROUND}_$tag
+}
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " c2 "; then pmc c2 "k_fused"; fi
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " c3 "; then pmc c3 "k_fused k_deemph_spec_arb" --workload c3; fi
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " wbfm "; then pmc wbfm "k_boxcar_scan k_deemph_spec_lpr" --workload wbfm; fi
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " box10 "; then pmc box10 "k_boxcar_scan" --boxcar 10; fi
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " box6 "; then pmc box6 "k_boxcar_scan" --boxcar 6; fi
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " c4 "; then pmc c4 "k_power_scan" --workload c4; fi
 du -sh $ROOT/gpurun_out
 head -3 $OUT/kernel_stats_*.txt

@@ -1,7 +1,9 @@
 #!/bin/bash
-# tools/prof_pmc.sh <tag> [bench args...] — PMC passes for the fused kernel on the GPU box.
-# Counters are collected in their own runs (no tracing domains mixed in), one
-# hardware pass per rocprofv3 invocation, as MI355X_MICROARCH.md prescribes.
+# tools/prof_pmc.sh <tag> [bench args...] — PMC passes on the GPU box for the kernels named in
+# PMC_KERNELS (space-separated substrings of kernel names, default "k_fused"): one summary per kernel
+# from the same runs.  Counters are collected in their own runs (no tracing domains mixed in), one
+# hardware pass per rocprofv3 invocation, as MI355X_MICROARCH.md prescribes.  bench.py notices the
+# profiler and neither builds nor starts the PCIe leg's child process (nothing execs under the preload).
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0 --ceiling 0 --also 0 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
 }
 BENCH_ARGS=("$@")
 run sqA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
@@ -18,4 +20,6 @@ run sqB SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU 
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE GRBM_GUI_ACTIVE
 cd $ROOT
-python3 tools/pmc_summary.py $OUT | tee $OUT/summary.txt
+for k in ${PMC_KERNELS:-${PMC_KERNEL:-k_fused}}; do
+  { echo "# rocprofv3 --pmc passes of: python3 bench.py --steps 3 --warmup 1 ${BENCH_ARGS[*]} ; kernel *$k*"; python3 tools/pmc_summary.py $OUT "$k"; } | tee $OUT/summary_$k.txt
+done
