@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--pmc", type=int, default=-1, help="rocprofv3 PMC passes for roofline.traffic: 1 on, 0 off, -1 on for N = 1 when rocprofv3 exists")
     ap.add_argument("--e2e", type=int, default=1, help="1: also time the PCIe-inclusive push / run / fetch path (N = 1)")
     ap.add_argument("--ceiling", type=int, default=1, help="1: measure this box's streaming ceilings (roofline.ceiling)")
+    ap.add_argument("--colocate", type=int, default=0, help="1: leave the output wherever the allocator puts it (normally the input's HBM quarter)")
     ap.add_argument("--also", type=int, default=1, help="1: default workload also times north_star's 4096-stream shapes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scatter", action="store_true",
@@ -160,7 +161,7 @@ def pmc_traffic(a):
     base = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--pmc", "0", "--gpus", "1", "--steps", "3",
             "--warmup", "2", "--sustain", "0", "--no-cpu-baseline", "--check", "0", "--workload", a.workload,
             "--streams", str(a.streams), "--blocks", str(a.blocks), "--block-len", str(a.block_len),
-            "--path", str(a.path), "--atan", a.atan]
+            "--path", str(a.path), "--atan", a.atan, "--colocate", "1", "--ceiling", "0", "--also", "0", "--e2e", "0"]
     base += ["--boxcar", str(a.boxcar)] if a.boxcar else ["--passes", str(a.passes), "--fir9", str(a.fir9)]
     out = {}
     tmp = tempfile.mkdtemp(prefix="rtlfm_pmc_", dir="/tmp")
@@ -415,6 +416,33 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
                     f"bounded by the host memcpy into the ring and PCIe, not by the kernels"}
 
 
+class ApartRows:
+    """int16 [rows, cols] device memory for a kernel's OUTPUT, a quarter of the HBM away from the input it is
+    computed from (rtlfm_gpu_malloc_apart: the read and the write stream of a launch get in each other's way when
+    they share a 72 GB quarter of the MI355X's memory - DESIGN.md section 3).  Quacks like the torch tensor it replaces."""
+
+    def __init__(self, rows, cols, other_ptr, other_bytes, device):
+        import ctypes as C
+        from rtlsdr_amd.capi import check, load
+        self.lib = load()
+        self.rows, self.cols = rows, cols
+        p, apart = C.c_void_p(), C.c_int()
+        check(self.lib.rtlfm_gpu_malloc_apart(device, rows * cols * 2, other_ptr, other_bytes, C.byref(p), C.byref(apart)),
+              "rtlfm_gpu_malloc_apart")
+        self.ptr, self.apart = p.value, bool(apart.value)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def stride(self, dim):
+        return self.cols if dim == 0 else 1
+
+    def free(self):
+        if self.ptr:
+            self.lib.rtlfm_gpu_free(self.ptr)
+            self.ptr = None
+
+
 def ceiling_leg(job, local_rank):
     """This box's own HBM ceilings (nominal 8 TB/s AND a measured ceiling), same invocation:
     the front end's access pattern without its arithmetic (rtlfm_gpu_bw_probe, bw_probe_kernel.h) over
@@ -424,14 +452,17 @@ def ceiling_leg(job, local_rank):
     from rtlsdr_amd.capi import load
     lib = load()
     wd = max(1, int(round(2.0 / max(job.alg_bytes_per_sample - 2.0, 2.0 / 64))))
-    rd, rw, wf = C.c_double(), C.c_double(), C.c_double()
-    r = lib.rtlfm_gpu_bw_probe(local_rank, 4 << 30, wd, 20, C.byref(rd), C.byref(rw), C.byref(wf))
+    rd, rw, rwc, wf = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    r = lib.rtlfm_gpu_bw_probe(local_rank, 4 << 30, wd, 20, C.byref(rd), C.byref(rw), C.byref(rwc), C.byref(wf))
     if r < 0:
         return None
-    return {"read_only": round(rd.value, 1), "read_write": round(rw.value, 1), "unit": "GB/s",
+    return {"read_only": round(rd.value, 1), "read_write": round(rw.value, 1), "read_write_colocated": round(rwc.value, 1),
+            "apart_found": bool(r), "unit": "GB/s",
             "write_fraction": round(wf.value, 5), "workload_write_fraction": round((job.alg_bytes_per_sample - 2.0) / 2.0, 5),
             "how": "rtlfm_gpu_bw_probe: 8192 waves x 8 KiB tiles, non-temporal coalesced dwordx4 loads with the next "
-                   "tile in flight, 4 waves/SIMD, 4 GiB, 20 launches each, HIP events; read_write = (read + written bytes) / time"}
+                   "tile in flight, 4 waves/SIMD, 4 GiB, 20 launches each, HIP events; read_write = (read + written bytes) / time "
+                   "with the written bytes in another 72 GB quarter of the HBM than the read ones (as bench.py places its own "
+                   "output: config.output_apart), read_write_colocated = both inside one allocation"}
 
 
 def also_leg(a, job, local_rank, ceiling):
@@ -453,7 +484,7 @@ def also_leg(a, job, local_rank, ceiling):
         cfg.max_blocks = nb
         with GpuDemod(cfg, S, local_rank) as g:
             cap = g.result_cap(nb)
-            o = torch.empty((S, cap), dtype=torch.int16, device=job.iq.device)
+            o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
             n = torch.zeros(S, dtype=torch.int32, device=job.iq.device)
 
             def step():
@@ -476,6 +507,8 @@ def also_leg(a, job, local_rank, ceiling):
             g.clock_probe(False)
             if st is not None:
                 segs = len(st) // S
+            g.sync()
+        o.free()
         samples = S * nb * L // 2
         alg = job.alg_bytes_per_sample * samples
         launch_ms = ms / max(cnt, 1)
@@ -568,7 +601,10 @@ class FmJob:
         self.g = GpuDemod(self.cfg, S, local_rank)
         self.g.set_path(a.path)
         cap = self.g.result_cap(NB) + int(os.environ.get("RTLFM_BENCH_ROW_PAD", "0"))  # experiments: rows off the 128-byte lines
-        self.out = torch.empty((S, cap), dtype=torch.int16, device=dev)
+        # the output a quarter of the HBM away from the input (data layout); --colocate 1 = wherever torch puts it
+        self.out = (torch.empty((S, cap), dtype=torch.int16, device=dev) if a.colocate
+                    else ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank))
+        self.output_apart = bool(getattr(self.out, "apart", False))
         self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
         self.local_rank = local_rank
         # u8 I + u8 Q in, int16 PCM out at 1/D (x the resampling ratio)
@@ -613,6 +649,8 @@ class FmJob:
 
     def close(self):
         self.g.close()
+        if hasattr(self.out, "free"):
+            self.out.free()
 
 
 class PowerJob:
@@ -869,6 +907,7 @@ def main():
                 "ranks": world,
                 "requested_gpus": int(os.environ.get("RTLFM_BENCH_REQUESTED_GPUS", a.gpus)),
                 "prewarm_steps": prewarm,
+                "output_apart": getattr(job, "output_apart", None),
                 "device": torch.cuda.get_device_name(local_rank),
             },
             "roofline": roof,

@@ -293,15 +293,18 @@ int rtlfm_gpu_clock_stamps(rtlfm_gpu *h, uint64_t *out, int cap_waves, int *wave
  * The box's own HBM streaming ceilings (SURVEY.md §8d asks for a measured ceiling next to the
  * nominal 8 TB/s): the front-end kernels' skeleton - one wave per contiguous segment, 8 KiB tiles,
  * non-temporal coalesced 16-byte loads with the next tile in flight, the same LDS footprint - and
- * none of their arithmetic, over `bytes` (>= 64 MiB) of device memory, `reps` launches each:
- *   *read_gbs        read only
- *   *rw_gbs          the same with one byte stored per ~write_div bytes read (16 = the /16 chain's PCM);
- *                    (bytes read + bytes written) / time
- *   *write_fraction  the share actually stored (2, 4, 8 or 16 bytes per lane and tile: 1/64 ... 1/8)
- * Allocates and frees its own buffers; no handle needed.
+ * none of their arithmetic, over `bytes` (>= 256 MiB) of device memory, `reps` launches each:
+ *   *read_gbs          read only
+ *   *rw_gbs            the same with one byte stored per ~write_div bytes read (16 = the /16 chain's PCM),
+ *                      the written bytes a quarter of the HBM away from the read ones (rtlfm_gpu_malloc_apart);
+ *                      (bytes read + bytes written) / time
+ *   *rw_colocated_gbs  the same with input and output inside one allocation (the same quarter)
+ *   *write_fraction    the share actually stored (2, 4, 8 or 16 bytes per lane and tile: 1/64 ... 1/8)
+ * Allocates and frees its own buffers; no handle needed.  Returns 1 when the "apart" placement was found,
+ * 0 when it was not (then *rw_gbs is another co-located figure), negative on error.
  */
 int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int reps, double *read_gbs, double *rw_gbs,
-                       double *write_fraction);
+                       double *rw_colocated_gbs, double *write_fraction);
 
 /*
  * Diagnostic: evaluates the kernels' atan2 -> Q14 routine (the arithmetic of
@@ -324,6 +327,28 @@ int rtlfm_gpu_selftest_const_div(int device, const int32_t *nd, int n, int32_t *
  * decimating kernels fold into their taps); it is offered as a standalone operator.
  */
 int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream);
+
+/*
+ * Where the output lives relative to the input matters on MI355X: its HBM behaves as four quarters of
+ * 72 GB, and a kernel that reads from one quarter and writes into the SAME quarter - the PCM is 1/16 of
+ * the bytes at /16 - streams 5.6 TB/s where it streams 6.5 TB/s with the writes in another quarter
+ * (read only: 6.9).  Buffers allocated one after the other normally share a quarter.
+ *
+ * rtlfm_gpu_malloc_apart: `bytes` of device memory for a write stream that runs beside the read stream
+ * of `other` (other_bytes long; only read): candidates are timed against `other` with the bandwidth
+ * probe until one lies in another quarter (a few ms each; up to 80 GB of temporary allocations are
+ * walked over and freed again).  *apart (may be NULL) = 1 when found; otherwise - buffers too small to
+ * matter (< 256 MiB streamed), no budget, probe failure - ordinary memory is returned with *apart = 0.
+ * The library's own result buffers behind rtlfm_gpu_push() / _run() are placed this way.
+ * rtlfm_gpu_placement_probe: 1 if existing buffers `in` / `out` are a quarter apart, 0 if not (or too
+ * small to tell); OVERWRITES the first in_bytes / 16 bytes of `out`.
+ * rtlfm_gpu_malloc / _free: plain device memory through the library.
+ */
+int rtlfm_gpu_malloc(int device, size_t bytes, void **out);
+int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart);
+int rtlfm_gpu_placement_probe(int device, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                              double *read_ms, double *rw_ms);
+int rtlfm_gpu_free(void *p);
 
 const char *rtlfm_gpu_strerror(int err);
 /* (major<<16)|(minor<<8)|patch */

@@ -18,7 +18,8 @@ The edit sites (reference old-dab/rtlsdr, src/rtl_fm.c):
   :1325-1342   rtlsdr_callback: u8->int16 convert, dc_block_raw, rotate, memcpy into demod.lowpassed
                -> rtlfm_gpu_push(gpu, 0, buf, len)
   :1361        demod_thread_fn: full_demod(d) -> rtlfm_gpu_run + rtlfm_gpu_fetch into d->result
-  :1387        (test determinism only, RTLFM_HIPREF_LOSSLESS=1) wait until the output thread has written
+  :1387, :1398, :1402   (replay determinism only, RTLFM_HIPREF_LOSSLESS=1) the demod -> output hand-off with a
+               predicate: the output thread writes every buffer exactly once
   :1471        controller thread, after optimal_settings(): rtlfm_gpu_create from the demod_state fields
 src/rtl_power.c:
   :641         glue inserted in front of scanner()
@@ -48,6 +49,7 @@ FM_GLUE = r'''
 static rtlfm_gpu *volatile hip_gpu;
 static int hip_lossless = -1;     /* RTLFM_HIPREF_LOSSLESS=1: wait instead of dropping (replay from a file) */
 static int hip_hits_seen;
+static volatile unsigned hip_pushed, hip_taken;   /* replay only: buffers queued by the callback / taken by the demod thread */
 
 static int hip_is_lossless(void)
 {
@@ -106,6 +108,15 @@ static int hip_push(struct demod_state *d, unsigned char *buf, uint32_t len)
 		safe_cond_signal(&d->ready, &d->ready_m);
 		usleep(100);
 	}
+	if (r == 0 && hip_is_lossless()) {
+		/* replay: the wake-up of :1343 is lost when the demod thread is not waiting yet, and after the
+		 * file's last buffer nobody would signal again: keep signalling until THIS buffer has been taken */
+		const unsigned mine = ++hip_pushed;
+		while (!do_exit && hip_taken < mine) {
+			safe_cond_signal(&d->ready, &d->ready_m);
+			usleep(50);
+		}
+	}
 	if (r == -ENOSPC)
 		return 0;        /* live: the reference overwrites the pending buffer (src/rtl_fm.c:1339-1342); here the newer one is dropped */
 	if (r < 0) {
@@ -134,8 +145,10 @@ static void hip_full_demod(struct demod_state *d)
 	r = rtlfm_gpu_run(hip_gpu);
 	if (r == -EAGAIN)
 		return;          /* woken without a queued buffer */
-	if (r == 0)
+	if (r == 0) {
+		hip_taken++;
 		r = rtlfm_gpu_fetch(hip_gpu, 0, d->result, MAXIMUM_BUF_LENGTH, &n);
+	}
 	if (r < 0) {
 		fprintf(stderr, "rtlfm_gpu_run/fetch: %s\n", rtlfm_gpu_strerror(r));
 		d->exit_flag = 1;
@@ -146,19 +159,53 @@ static void hip_full_demod(struct demod_state *d)
 		hip_hits_seen = d->squelch_hits = st.squelch_hits;
 }
 
-/* replay only: the demod -> output hand-off overwrites o->result when the output thread is late
- * (src/rtl_fm.c:1382-1387); wait until this buffer's bytes have been written (output_thread_fn
- * counts them in waveDataSize) */
-static void hip_wait_output(struct output_state *o, uint32_t written_before)
+/* replay only: both hand-offs of the reference are lossy by design - the demod -> output one
+ * overwrites o->result when the output thread is late (src/rtl_fm.c:1382-1387), and safe_cond_wait
+ * has no predicate, so a wake-up can be lost or taken twice.  With RTLFM_HIPREF_LOSSLESS=1 the output
+ * thread waits on a flag under the condition's own mutex and the demod thread waits until the buffer
+ * has been written; without it both sites behave exactly as the reference. */
+static int hip_out_pending;
+
+static int hip_out_take(struct output_state *s)   /* in place of safe_cond_wait(&s->ready, ...) at :1398 */
 {
-	if (!hip_is_lossless() || o->result_len <= 0)
+	int took;
+	if (!hip_is_lossless()) {
+		safe_cond_wait(&s->ready, &s->ready_m);
+		return 1;
+	}
+	pthread_mutex_lock(&s->ready_m);
+	while (!hip_out_pending && !do_exit)
+		pthread_cond_wait(&s->ready, &s->ready_m);
+	took = hip_out_pending;
+	pthread_mutex_unlock(&s->ready_m);
+	return took;          /* 0: woken to exit, nothing new to write */
+}
+
+static void hip_out_done(struct output_state *s)   /* behind the fwrite, :1402 */
+{
+	pthread_mutex_lock(&s->ready_m);
+	hip_out_pending = 0;
+	pthread_mutex_unlock(&s->ready_m);
+}
+
+static void hip_out_post(struct output_state *o)   /* behind the demod thread's signal, :1387 */
+{
+	if (!hip_is_lossless())
 		return;
-	while (!do_exit && waveDataSize == written_before) {
-		safe_cond_signal(&o->ready, &o->ready_m);
-		usleep(100);
+	pthread_mutex_lock(&o->ready_m);
+	hip_out_pending = 1;
+	pthread_cond_signal(&o->ready);
+	pthread_mutex_unlock(&o->ready_m);
+	while (!do_exit) {
+		int p;
+		pthread_mutex_lock(&o->ready_m);
+		p = hip_out_pending;
+		pthread_mutex_unlock(&o->ready_m);
+		if (!p)
+			break;
+		usleep(50);
 	}
 }
-static uint32_t hip_written;
 /* ---- end of inserted glue ---- */
 '''
 
@@ -270,6 +317,9 @@ def patch_rtl_fm(src: str) -> str:
     expect(lines, 1361, "full_demod")
     expect(lines, 1382, "OutputToStdout")
     expect(lines, 1387, "safe_cond_signal")
+    expect(lines, 1398, "safe_cond_wait")
+    expect(lines, 1400, "fwrite")
+    expect(lines, 1402, "pthread_rwlock_unlock")
     expect(lines, 1471, "optimal_settings", "freqs")
     out = []
     for no, text in enumerate(lines, 1):
@@ -285,11 +335,16 @@ def patch_rtl_fm(src: str) -> str:
         if no == 1361:
             out.append(text.replace("full_demod(d)", "hip_full_demod(d)"))
             continue
-        if no == 1382:
-            out.append("\t\thip_written = waveDataSize;")
         if no == 1387:
             out.append(text)
-            out.append("\t\t\thip_wait_output(o, hip_written);")
+            out.append("\t\t\thip_out_post(o);")
+            continue
+        if no == 1398:
+            out.append("\t\tif (!hip_out_take(s))\n\t\t\tcontinue;")
+            continue
+        if no == 1402:
+            out.append(text)
+            out.append("\t\thip_out_done(s);")
             continue
         if no == 1471:
             out.append(text)

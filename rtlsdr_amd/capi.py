@@ -191,13 +191,18 @@ _SIGNATURES = [
     ("rtlfm_gpu_clock_probe", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlfm_gpu_clock_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double)]),
     ("rtlfm_gpu_clock_stamps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _P(C.c_int)]),
-    ("rtlfm_gpu_bw_probe", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    ("rtlfm_gpu_bw_probe", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_double),
+                                     _P(C.c_double)]),
     ("rtlfm_gpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     ("rtlfm_gpu_get_option", C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_long)]),
     ("rtlfm_gpu_selftest_atan2", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("rtlfm_gpu_selftest_fast_atan2", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("rtlfm_gpu_selftest_const_div", C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     ("rtlfm_gpu_rotate_90_u8", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rtlfm_gpu_malloc", C.c_int, [C.c_int, C.c_size_t, _P(C.c_void_p)]),
+    ("rtlfm_gpu_malloc_apart", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_void_p), _P(C.c_int)]),
+    ("rtlfm_gpu_placement_probe", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_double), _P(C.c_double)]),
+    ("rtlfm_gpu_free", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_strerror", C.c_char_p, [C.c_int]),
     ("rtlfm_gpu_version", C.c_int, []),
 ]

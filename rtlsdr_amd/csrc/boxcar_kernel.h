@@ -42,7 +42,8 @@ struct Params {
 	int mode, output_scale;
 	int D, q4096, r4096;  // 4096 = q4096 * D + r4096
 	int out_cap;          // 4096 / D + 2
-	int segs, tiles_per_seg;    // as in fused_kernel.h: runs of tiles, not of whole buffers
+	int segs, tiles_per_seg, nlist;  // as in fused_kernel.h: runs of tiles, long segments first
+	int seg_start[fused::kMaxSegList + 1];
 	const uint8_t *dummy_tile;  // what the reload reads after a segment's last tile (fused_kernel.h)
 	int has_first;              // k_boxcar_scan: the LDS copy of each dword's first sample exists (odd D)
 	int R;                      // k_boxcar_scan: outputs per lane and tile, ceil((4096 / D + 1) / 64)
@@ -149,14 +150,13 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const int lane = threadIdx.x;
 	const int wave = blockIdx.x;
-	const int seg = wave % p.segs;
-	const int s = wave / p.segs;
-	if (s >= p.nstreams) return;
+	const int seg = wave / p.nstreams;
+	const int s = wave - seg * p.nstreams;
+	if (seg >= p.segs) return;
 	const int tpb = (int)(p.block_len / kTileBytes);
 	const int total_tiles = p.nblocks * tpb;
-	const int t0 = seg * p.tiles_per_seg;
-	int t1 = t0 + p.tiles_per_seg;
-	if (t1 > total_tiles) t1 = total_tiles;
+	int t0, t1;
+	fused::segment_bounds(p, seg, total_tiles, t0, t1);
 	if (t0 >= t1) return;
 	const bool from_state = (t0 == 0);
 	const bool writes_state = (t1 == total_tiles);
@@ -419,7 +419,8 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.D = c.downsample; p.q4096 = kTileSamples / p.D; p.r4096 = kTileSamples % p.D;
 	p.out_cap = kTileSamples / p.D + 2;
 	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, nblocks * (int)(c.block_len / kTileBytes));
-	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg;
+	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
+	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;
 	const bool std_fm = c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM;
 	p.has_first = (p.D & 1) ? 1 : 0;

@@ -54,6 +54,7 @@ constexpr int kTileSamples = 64 * kLaneSamples;  // 4096
 constexpr int kTileBytes = 2 * kTileSamples;     // 8192
 constexpr int kPre = 16;                         // prefix entries of a linear ring
 constexpr int kMaxP = 6;
+constexpr int kMaxSegList = 128;
 
 #ifdef RTLFM_FUSED_MARKS  // analysis builds only: section markers in the .s
 #define RTLFM_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -221,13 +222,32 @@ struct Params {
 	uint32_t *emit_iq;
 	size_t emit_iq_stride;  // dwords between streams
 	const uint8_t *dummy_tile;  // 8 KiB, what the reload reads after a segment's last tile
-	int segs, tiles_per_seg;    // a segment is a run of tiles of one stream; it may begin and end inside a buffer
+	// A segment is a run of tiles of one stream (it may begin and end inside a buffer); wave w takes
+	// segment w / nstreams of stream w % nstreams.  Uniform: segment j = tiles [j tiles_per_seg, ...);
+	// nlist > 0: segment j = [seg_start[j], seg_start[j + 1]) - long segments first, short ones last
+	// (plan_segments).
+	int segs, tiles_per_seg, nlist;
+	int seg_start[kMaxSegList + 1];
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps (printed per launch; +16 = 18:
 	            // only on timing_read, i.e. for the last launch of an uninterrupted run), 4 = reload one (cached) tile
 	unsigned long long *stamps;  // [waves][4] when debug & 2
 	Pass0Taps taps;
 };
+
+// tiles [t0, t1) of segment `seg` (wave-uniform: scalar loads from the kernel arguments)
+template <typename ParamsT>
+__device__ __forceinline__ void segment_bounds(const ParamsT &p, int seg, int total_tiles, int &t0, int &t1)
+{
+	if (p.nlist > 0) {
+		t0 = p.seg_start[seg];
+		t1 = p.seg_start[seg + 1];
+	} else {
+		t0 = seg * p.tiles_per_seg;
+		t1 = t0 + p.tiles_per_seg;
+	}
+	if (t1 > total_tiles) t1 = total_tiles;
+}
 
 // ---- LDS layout of one wave (dword offsets) -----------------------------------
 template <int P, bool FIR9, bool MFMA0 = false>
@@ -416,14 +436,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	__shared__ __attribute__((aligned(128))) uint32_t lds[L::total];
 	const int lane = threadIdx.x;
 	const int wave = blockIdx.x;
-	const int seg = wave % p.segs;
-	const int s = wave / p.segs;
-	if (s >= p.nstreams) return;
+	const int seg = wave / p.nstreams;
+	const int s = wave - seg * p.nstreams;
+	if (seg >= p.segs) return;
 	const int tpb = (int)(p.block_len / kTileBytes);
 	const int total_tiles = p.nblocks * tpb;
-	const int t0 = seg * p.tiles_per_seg;
-	int t1 = t0 + p.tiles_per_seg;
-	if (t1 > total_tiles) t1 = total_tiles;
+	int t0, t1;
+	segment_bounds(p, seg, total_tiles, t0, t1);
 	if (t0 >= t1) return;
 	const bool from_state = (t0 == 0);
 	const bool writes_state = (t1 == total_tiles);
@@ -943,6 +962,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	flush_held();
 	if ((p.debug & 2) && lane == 0) {
 		unsigned long long e_clk = __builtin_amdgcn_s_memtime(), e_rt = __builtin_amdgcn_s_memrealtime();
+		if (p.debug & 32) {
+			// where the wave ran, in place of its clock stamps: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID
+			const unsigned long long hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID[31:0]
+			const unsigned long long xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
+			st_clk = hw | (xcc << 32);
+			e_clk = st_clk;
+		}
 		p.stamps[(size_t)wave * 4 + 0] = st_clk; p.stamps[(size_t)wave * 4 + 1] = e_clk;
 		p.stamps[(size_t)wave * 4 + 2] = st_rt; p.stamps[(size_t)wave * 4 + 3] = e_rt;
 	}
@@ -960,7 +986,8 @@ struct Workspace {
 	int target_waves = 8192;                      // enough waves to fill the 4096 wave slots of 256 CUs twice
 	int min_tiles = 8;                            // a segment pays one warm-up tile: at most 1/8 on top
 	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
-	int debug = 0;                                // fused_debug: 2 = clock stamps per launch (+16: only on timing_read), 4 = reload a cached tile
+	int gss_x10 = 0;                              // guided segment lengths: remaining / (gss R) per round, x10 (0 = equal segments)
+	int debug = 0;                                // fused_debug: 2 = clock stamps per launch (+16: only on timing_read), 4 = reload a cached tile, 32 = stamp HW_ID / XCC_ID instead of the shader clock
 	void release()
 	{
 		if (stamps) hipFree(stamps);
@@ -976,26 +1003,60 @@ struct Workspace {
 // min_tiles or more - unless the launch cannot fill the GPU's wave slots anyway: then the extra
 // waves run where nothing else would, and shorter segments only shorten the launch (one callback
 // buffer of one stream, the reference's own shape, gets a wave per tile).
+//
+// Segment lengths DEcrease along the stream ("guided" scheduling, option fused_gss): the SIMD's
+// instruction arbiter favours its oldest wave, so four equal waves that start together finish one
+// after the other (measured: 563 / 631 / 735 / 839 us for the four slots of a SIMD, tools/
+// wave_placement.py) and with equal segments the launch ends in a long tail of half-empty SIMDs.
+// The dispatcher hands out workgroups in index order as slots free up, and wave w is segment
+// w / nstreams: the long segments of every stream go first, ever shorter ones fill the freed slots,
+// and the tail is as long as the SHORTEST segment.  Round r gives each stream R segments (R = the
+// stream's share of the wave slots) of remaining / (gss R) tiles.
 constexpr int kWaveSlots = 256 * 4 * 4;  // CUs x SIMDs x resident waves of these kernels
-struct SegPlan { int segs, tiles_per_seg; };
+struct SegPlan {
+	int segs = 1, tiles_per_seg = 0, nlist = 0;
+	int start[kMaxSegList + 1];
+};
 inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
 {
-	SegPlan sp{1, total_tiles};
+	SegPlan sp;
+	sp.tiles_per_seg = total_tiles;
 	if (ws.tiles_per_seg > 0) {
 		sp.tiles_per_seg = ws.tiles_per_seg < total_tiles ? ws.tiles_per_seg : total_tiles;
-	} else {
-		int segs = (ws.target_waves + nstreams - 1) / nstreams;
-		int cap = total_tiles / (ws.min_tiles > 0 ? ws.min_tiles : 1);
-		if (cap < 1) cap = 1;
-		if ((long long)nstreams * cap < kWaveSlots) {
-			cap = (kWaveSlots + nstreams - 1) / nstreams;
-			if (cap > total_tiles) cap = total_tiles;
-		}
-		if (segs > cap) segs = cap;
-		if (segs < 1) segs = 1;
-		sp.tiles_per_seg = (total_tiles + segs - 1) / segs;
+		sp.segs = (total_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
+		return sp;
 	}
+	const int min_tiles = ws.min_tiles > 0 ? ws.min_tiles : 1;
+	int segs = (ws.target_waves + nstreams - 1) / nstreams;
+	int cap = total_tiles / min_tiles;
+	if (cap < 1) cap = 1;
+	const bool underfilled = (long long)nstreams * cap < kWaveSlots;
+	if (underfilled) {
+		cap = (kWaveSlots + nstreams - 1) / nstreams;
+		if (cap > total_tiles) cap = total_tiles;
+	}
+	if (segs > cap) segs = cap;
+	if (segs < 1) segs = 1;
+	sp.tiles_per_seg = (total_tiles + segs - 1) / segs;
 	sp.segs = (total_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
+	if (ws.gss_x10 <= 0 || underfilled || sp.segs < 2) return sp;
+	// guided: R segments per stream and round
+	const int R = (kWaveSlots + nstreams - 1) / nstreams;
+	int n = 0, at = 0;
+	sp.start[0] = 0;
+	while (at < total_tiles) {
+		int len = (int)((long long)(total_tiles - at) * 10 / ((long long)ws.gss_x10 * R));
+		if (len < min_tiles) len = min_tiles;
+		for (int k = 0; k < R && at < total_tiles; k++) {
+			if (n == kMaxSegList) return sp;  // too many pieces for the argument block: stay uniform
+			int l = len;
+			if (total_tiles - at - l < min_tiles) l = total_tiles - at;  // no crumbs at the end
+			at += l;
+			sp.start[++n] = at;
+		}
+	}
+	sp.nlist = n;
+	sp.segs = n;
 	return sp;
 }
 
@@ -1080,7 +1141,8 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.debug = ws.debug;
 	if (ws.want_stamps) p.debug |= 2;
 	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)(c.block_len / kTileBytes));
-	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg;
+	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
+	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;
 	if (p.debug & 2) {
 		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; ws.stamp_waves = 0; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }

@@ -352,12 +352,25 @@ static int ensure_deep_buffers(rtlfm_gpu *h)
 	HIP_TRY(hipMalloc(&h->deepB, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
 	return 0;
 }
-static int ensure_res_buffers(rtlfm_gpu *h)
+extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart);
+
+// d_iq / iq_bytes: the input the first run streams from - the buffers the front end writes the demodulated
+// samples into ([parity][0]) go a quarter of the HBM away from it where they are large enough to matter
+static int ensure_res_buffers(rtlfm_gpu *h, const uint8_t *d_iq = nullptr, size_t iq_bytes = 0)
 {
 	const size_t S = (size_t)h->nstreams;
 	if (!h->res[0][0]) {
 		for (int p = 0; p < 2; p++)
-			for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc(&h->res[p][k], S * h->tstride * sizeof(int16_t)));
+			for (int k = 0; k < 2; k++) {
+				void *q = nullptr;
+				if (k == 0 && d_iq) {
+					int r = rtlfm_gpu_malloc_apart(h->device, S * h->tstride * sizeof(int16_t), d_iq, iq_bytes, &q, nullptr);
+					if (r < 0) return r;
+				} else {
+					HIP_TRY(hipMalloc(&q, S * h->tstride * sizeof(int16_t)));
+				}
+				h->res[p][k] = (int16_t *)q;
+			}
 	}
 	return 0;
 }
@@ -477,7 +490,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 {
 	struct { const char *n; int *p; } tab[] = {
 		{"fused_waves", &h->fws.target_waves}, {"fused_min_tiles", &h->fws.min_tiles},
-		{"fused_tiles_per_seg", &h->fws.tiles_per_seg}, {"fused_debug", &h->fws.debug},
+		{"fused_tiles_per_seg", &h->fws.tiles_per_seg}, {"fused_debug", &h->fws.debug}, {"fused_gss", &h->fws.gss_x10},
 		{"pass0_engine", &h->fws.pass0_engine},
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores},
@@ -958,7 +971,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	// --- mode_demod (src/rtl_fm.c:1256-1259)
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		r = ensure_res_buffers(h);
+		r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
 		if (r < 0) return r;
 	}
 	int16_t *dd; size_t dds;
@@ -1038,7 +1051,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		int r = ensure_res_buffers(h);
+		int r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
 		if (r < 0) return r;
 	}
 	int16_t *dd; size_t dds;
@@ -1083,7 +1096,7 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	}
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		int r = ensure_res_buffers(h);
+		int r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
 		if (r < 0) return r;
 	}
 	std::pair<hipEvent_t, hipEvent_t> ev;
@@ -1142,7 +1155,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		int r = ensure_res_buffers(h);
+		int r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
 		if (r < 0) return r;
 	}
 	int16_t *dd; size_t dds;
@@ -1299,7 +1312,14 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 	for (int k = 0; k < 2; k++) {
 		HIP_TRY(hipHostMalloc(&in->h_stage[k], bytes, hipHostMallocDefault));
 		HIP_TRY(hipMalloc(&in->d_in[k], bytes));
-		HIP_TRY(hipMalloc(&in->d_result[k], S * in->ostride * sizeof(int16_t)));
+		{
+			// the results a quarter of the HBM away from the input they are demodulated from (see
+			// rtlfm_gpu_malloc_apart; plain memory when the ring is too small for it to matter)
+			void *p = nullptr;
+			int r = rtlfm_gpu_malloc_apart(h->device, S * in->ostride * sizeof(int16_t), in->d_in[k], bytes, &p, nullptr);
+			if (r < 0) return r;
+			in->d_result[k] = (int16_t *)p;
+		}
 		HIP_TRY(hipMalloc(&in->d_result_len[k], S * sizeof(int32_t)));
 		HIP_TRY(hipEventCreateWithFlags(&in->ev_h2d[k], hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&in->ev_run[k], hipEventDisableTiming));
@@ -1679,60 +1699,222 @@ extern "C" int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void 
 	return 0;
 }
 
-// The box's own streaming ceilings, measured with the front end's access pattern and none of its
-// arithmetic (bw_probe_kernel.h).  bench.py puts them next to the nominal 8 TB/s.
-extern "C" int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int reps, double *read_gbs, double *rw_gbs,
-                                  double *write_fraction)
+// ---------------------------------------------- placement: read stream vs write stream ----
+//
+// MI355X's 288 GB of HBM3E behave as four quarters of 72 GB for this purpose: a kernel that streams
+// reads from one quarter and writes (even 1/16 of the bytes) into the SAME quarter moves 5.6 TB/s,
+// the same kernel writing into another quarter 6.5 TB/s (read only: 6.9) - tools/bank_probe2.hip walks
+// the allocator across a boundary: 0.813 -> 0.697 ms for 4 GiB in + 256 MiB out, at the 72 GB mark, for
+// any offsets inside an allocation (tools/bank_probe.hip) and stable over time (tools/mode_probe*.py).
+// The driver hands out physical memory in order, so two buffers allocated one after the other share a
+// quarter unless a boundary happens to fall between them: that was the "box-to-box" spread of rounds 1
+// and 2 (0.78-0.80 vs 0.85-0.87 ms for the headline launch).  Nothing in HIP names the quarter, so it
+// is found by measurement: the bandwidth-probe skeleton (bw_probe_kernel.h), read only and read + write.
+
+namespace {
+
+struct ProbeRig {
+	uint32_t *sink = nullptr;
+	hipEvent_t a = nullptr, b = nullptr;
+	int init()
+	{
+		if (hipMalloc(&sink, (size_t)8192 * 256) != hipSuccess) return -ENOMEM;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -EIO;
+		return 0;
+	}
+	~ProbeRig()
+	{
+		if (a) hipEventDestroy(a);
+		if (b) hipEventDestroy(b);
+		if (sink) hipFree(sink);
+	}
+	// ms per launch: `region` bytes of `in` streamed by 8192 waves, W bytes stored per lane and tile into `out`
+	// (region / 8192 * 64 * W / 8192 ... = region * W / 128 bytes in all)
+	int run(const uint8_t *in, size_t region, uint8_t *out, int W, int reps, float *ms)
+	{
+		const int waves = 8192;
+		const size_t seg = (region / waves) & ~(size_t)8191;
+		if (seg < 8192) return -EINVAL;
+		auto go = [&]() {
+			switch (W) {
+			case 0: hipLaunchKernelGGL((bwprobe::k_stream<0>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, in, seg, sink, out); break;
+			case 2: hipLaunchKernelGGL((bwprobe::k_stream<2>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, in, seg, sink, out); break;
+			case 4: hipLaunchKernelGGL((bwprobe::k_stream<4>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, in, seg, sink, out); break;
+			case 8: hipLaunchKernelGGL((bwprobe::k_stream<8>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, in, seg, sink, out); break;
+			default: hipLaunchKernelGGL((bwprobe::k_stream<16>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, in, seg, sink, out); break;
+			}
+		};
+		for (int i = 0; i < 3; i++) go();  // clocks, TLBs
+		if (hipEventRecord(a, 0) != hipSuccess) return -EIO;
+		for (int i = 0; i < reps; i++) go();
+		if (hipEventRecord(b, 0) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return -EIO;
+		if (hipEventElapsedTime(ms, a, b) != hipSuccess) return -EIO;
+		*ms /= (float)reps;
+		return hipGetLastError() == hipSuccess ? 0 : -EIO;
+	}
+};
+
+// how much of `in` a placement test streams when the write stream has out_bytes to land in
+size_t probe_region(size_t in_bytes, size_t out_bytes)
 {
-	if (bytes < ((size_t)64 << 20) || reps < 1 || write_div < 1) return -EINVAL;
+	size_t r = in_bytes;
+	if (r > 16 * out_bytes) r = 16 * out_bytes;   // W = 8: one byte written per 16 read
+	if (r > ((size_t)2 << 30)) r = (size_t)2 << 30;
+	return r & ~(((size_t)8192 * 8192) - 1);      // whole tiles for 8192 waves
+}
+
+constexpr float kApartRatio = 1.21f;  // read+write over read-only time: 1.12 apart, 1.31 in the same quarter
+
+}  // namespace
+
+// Device memory for a WRITE stream that is to run next to the read stream of `other` (the output of
+// rtlfm_gpu_run_device next to its input): `bytes` in another quarter of the HBM than `other`.
+// Candidates are allocated and timed against `other` with the bandwidth probe; those that share its
+// quarter are kept (with 4 GiB of filler each) so that the allocator moves on, and everything but the
+// winner is freed at the end.  *apart = 1 when a quarter away was found, 0 when the buffers are too
+// small for it to matter (< 256 MiB streamed), the search ran out of memory budget, or the probe
+// failed - the memory returned is good device memory in every case.  `other` is only read.
+extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart)
+{
+	if (!out || !bytes) return -EINVAL;
+	if (apart) *apart = 0;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
 	HIP_TRY(hipSetDevice(device));
-	const int waves = 8192;
-	const size_t seg = (bytes / waves) & ~(size_t)8191;
-	if (seg < 8192) return -EINVAL;
-	const size_t total = seg * waves;
+	const size_t region = other ? probe_region(other_bytes, bytes) : 0;
+	if (region < ((size_t)256 << 20)) {
+		void *p = nullptr;
+		HIP_TRY(hipMalloc(&p, bytes));
+		*out = p;
+		return 0;
+	}
+	ProbeRig rig;
+	int r = rig.init();
+	if (r < 0) return r;
+	HIP_TRY(hipDeviceSynchronize());
+	float rd = 0;
+	if ((r = rig.run((const uint8_t *)other, region, nullptr, 0, 6, &rd)) < 0) return r;
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	const size_t step = (size_t)4 << 30;
+	// a quarter is 72 GB: at most that much is walked over, and never more than what is free minus a reserve
+	size_t budget = (size_t)80 << 30;
+	if (free_b < budget + ((size_t)8 << 30)) budget = free_b > ((size_t)8 << 30) ? free_b - ((size_t)8 << 30) : 0;
+	std::vector<void *> keep;
+	void *win = nullptr, *last = nullptr;
+	size_t walked = 0;
+	for (;;) {
+		void *p = nullptr;
+		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+		float rw = 0;
+		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 6, &rw) < 0) { last = p; break; }
+		if (rw < kApartRatio * rd) { win = p; break; }
+		last = p;
+		if (walked + step + bytes > budget) break;
+		keep.push_back(p);
+		last = nullptr;
+		void *f = nullptr;
+		if (hipMalloc(&f, step) != hipSuccess) { (void)hipGetLastError(); break; }
+		keep.push_back(f);
+		walked += step + bytes;
+	}
+	for (void *k : keep) hipFree(k);
+	if (win) {
+		if (last) hipFree(last);
+		*out = win;
+		if (apart) *apart = 1;
+		return 0;
+	}
+	if (!last) HIP_TRY(hipMalloc(&last, bytes));
+	*out = last;
+	return 0;
+}
+
+// Are two existing buffers a quarter apart?  1 = yes, 0 = no / too small to tell; `in` is read,
+// the first in_bytes / 16 bytes of `out` are OVERWRITTEN.
+extern "C" int rtlfm_gpu_placement_probe(int device, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                                         double *read_ms, double *rw_ms)
+{
+	if (!in || !out) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	const size_t region = probe_region(in_bytes, out_bytes);
+	if (region < ((size_t)256 << 20)) return 0;
+	ProbeRig rig;
+	int r = rig.init();
+	if (r < 0) return r;
+	HIP_TRY(hipDeviceSynchronize());
+	float rd = 0, rw = 0;
+	if ((r = rig.run((const uint8_t *)in, region, nullptr, 0, 6, &rd)) < 0) return r;
+	if ((r = rig.run((const uint8_t *)in, region, (uint8_t *)out, 8, 6, &rw)) < 0) return r;
+	if (read_ms) *read_ms = rd;
+	if (rw_ms) *rw_ms = rw;
+	return rw < kApartRatio * rd ? 1 : 0;
+}
+
+// The box's own streaming ceilings, measured with the front end's access pattern and none of its
+// arithmetic (bw_probe_kernel.h): read only; read + write with the written bytes a quarter of the HBM
+// away from the read ones (what rtlfm_gpu_malloc_apart arranges); read + write inside one allocation.
+extern "C" int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int reps, double *read_gbs, double *rw_gbs,
+                                  double *rw_colocated_gbs, double *write_fraction)
+{
+	if (bytes < ((size_t)256 << 20) || reps < 1 || write_div < 1) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	const size_t total = bytes & ~(((size_t)8192 * 8192) - 1);
 	// bytes stored per lane and tile: the power of two nearest to 128 / write_div
 	int W = 2;
 	for (int w : {2, 4, 8, 16})
 		if (fabs(128.0 / write_div - w) < fabs(128.0 / write_div - W)) W = w;
-	uint8_t *d_in = nullptr, *d_wr = nullptr;
-	uint32_t *d_sink = nullptr;
-	hipEvent_t a = nullptr, b = nullptr;
-	int rc = 0;
-	auto fail = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = e == hipErrorOutOfMemory ? -ENOMEM : -EIO; return e != hipSuccess; };
+	const size_t wbytes = total / 128 * W + 4096;
+	uint8_t *d_in = nullptr, *d_near = nullptr;
+	void *d_far = nullptr;
+	ProbeRig rig;
+	int rc = rig.init();
+	if (rc < 0) return rc;
 	do {
-		if (fail(hipMalloc(&d_in, total)) || fail(hipMalloc(&d_wr, total / 8192 * 64 * 16 + 4096)) || fail(hipMalloc(&d_sink, (size_t)waves * 256))) break;
-		if (fail(hipMemset(d_in, 0x5a, total))) break;
-		if (fail(hipEventCreate(&a)) || fail(hipEventCreate(&b))) break;
-		double out[2] = {0, 0};
-		for (int leg = 0; leg < 2 && !rc; leg++) {
-			auto go = [&]() {
-				if (leg == 0) hipLaunchKernelGGL((bwprobe::k_stream<0>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
-				else if (W == 2) hipLaunchKernelGGL((bwprobe::k_stream<2>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
-				else if (W == 4) hipLaunchKernelGGL((bwprobe::k_stream<4>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
-				else if (W == 8) hipLaunchKernelGGL((bwprobe::k_stream<8>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
-				else hipLaunchKernelGGL((bwprobe::k_stream<16>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, d_in, seg, d_sink, d_wr);
-			};
-			for (int i = 0; i < 3; i++) go();  // clocks, TLBs
-			if (fail(hipEventRecord(a, 0))) break;
-			for (int i = 0; i < reps; i++) go();
-			if (fail(hipEventRecord(b, 0)) || fail(hipEventSynchronize(b))) break;
-			float ms = 0;
-			if (fail(hipEventElapsedTime(&ms, a, b))) break;
-			const double moved = (double)total * (leg ? 1.0 + W / 128.0 : 1.0);
-			out[leg] = moved * reps / (ms * 1e-3) / 1e9;
-		}
-		if (read_gbs) *read_gbs = out[0];
-		if (rw_gbs) *rw_gbs = out[1];
+		// input and the co-located output in ONE allocation: the same quarter by construction
+		if (hipMalloc(&d_in, total + wbytes) != hipSuccess) { rc = -ENOMEM; break; }
+		d_near = d_in + total;
+		if (hipMemset(d_in, 0x5a, total) != hipSuccess) { rc = -EIO; break; }
+		int apart = 0;
+		if ((rc = rtlfm_gpu_malloc_apart(device, wbytes, d_in, total, &d_far, &apart)) < 0) break;
+		float ms[3] = {0, 0, 0};
+		if ((rc = rig.run(d_in, total, nullptr, 0, reps, &ms[0])) < 0) break;
+		if ((rc = rig.run(d_in, total, (uint8_t *)d_far, W, reps, &ms[1])) < 0) break;
+		if ((rc = rig.run(d_in, total, d_near, W, reps, &ms[2])) < 0) break;
+		const double moved = (double)total * (1.0 + W / 128.0);
+		if (read_gbs) *read_gbs = (double)total / (ms[0] * 1e-3) / 1e9;
+		if (rw_gbs) *rw_gbs = moved / (ms[1] * 1e-3) / 1e9;
+		if (rw_colocated_gbs) *rw_colocated_gbs = moved / (ms[2] * 1e-3) / 1e9;
 		if (write_fraction) *write_fraction = W / 128.0;
+		rc = apart;  // 1: the "apart" figure really is a quarter away
 	} while (0);
-	if (a) hipEventDestroy(a);
-	if (b) hipEventDestroy(b);
 	if (d_in) hipFree(d_in);
-	if (d_wr) hipFree(d_wr);
-	if (d_sink) hipFree(d_sink);
+	if (d_far) hipFree(d_far);
 	return rc;
+}
+
+// Plain device memory (hipMalloc) through the library, for callers that have no HIP runtime of their own at hand.
+extern "C" int rtlfm_gpu_malloc(int device, size_t bytes, void **out)
+{
+	if (!out || !bytes) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	void *p = nullptr;
+	HIP_TRY(hipMalloc(&p, bytes));
+	*out = p;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_free(void *p)
+{
+	if (!p) return 0;
+	HIP_TRY(hipFree(p));
+	return 0;
 }
 
 // the raw stamps of the last stamped launch: per wave {shader clock at start, at end, 100 MHz

@@ -33,7 +33,8 @@ POWER = os.path.join(ROOT, "oracle", "_ref", "rtl_power_hipref")
 def _run_rtl_fm(args, src, out, want_bytes, env_extra=None):
     """The tool never exits on end of input (its main() polls do_exit, src/rtl_fm.c:2010-2012):
     SIGINT once everything expected is on disk or the output has stopped growing."""
-    env = dict(os.environ, RTLSDR_FILE=str(src), RTLFM_HIPREF_LOSSLESS="1", **(env_extra or {}))
+    env = dict(os.environ, RTLSDR_FILE=str(src), RTLFM_HIPREF_LOSSLESS="1")
+    env.update(env_extra or {})
     p = subprocess.Popen([FM] + args + [str(out)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     try:
         last, still = -1, 0

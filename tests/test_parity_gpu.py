@@ -262,7 +262,7 @@ def test_fullscale_random_bytes_std_and_fast_end_to_end(oracle_lib, front, atan)
 
 
 SEGMENTATIONS = [dict(fused_waves=1), dict(fused_tiles_per_seg=1), dict(fused_tiles_per_seg=3), dict(fused_tiles_per_seg=5),
-                 dict(fused_min_tiles=2, fused_waves=100000)]
+                 dict(fused_min_tiles=2, fused_waves=100000), dict(fused_gss=0)]
 
 
 @pytest.mark.parametrize("seg", SEGMENTATIONS, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))

@@ -26,21 +26,26 @@ def main():
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--nb", type=int, nargs="+", default=[1, 4])
     ap.add_argument("--waves", type=int, nargs="+", default=[4096, 8192, 16384])
-    ap.add_argument("--min-tiles", type=int, default=4)
+    ap.add_argument("--min-tiles", type=int, nargs="+", default=[4])
+    ap.add_argument("--gss", type=int, nargs="+", default=[0], help="fused_gss values (x10; 0 = equal segments)")
+    ap.add_argument("--streams-c2", action="store_true", help="the c2 shape: 256 streams x 16*nb buffers")
     ap.add_argument("--passes", type=int, default=4)
     ap.add_argument("--boxcar", type=int, default=0)
     ap.add_argument("--steps", type=int, default=400)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     S, L = a.streams, 262144
+    if a.streams_c2:
+        S, a.nb = 256, [16 * x for x in a.nb]
     D = a.boxcar or (1 << a.passes)
     nbmax = max(a.nb)
     iq = synth.fm_iq_u8_torch(S, nbmax * L // 2, dev, fs=2.4e6, dev_hz=75e3)
+    import itertools
     for nb in a.nb:
-        for w in a.waves:
+        for w, gss, mt in itertools.product(a.waves, a.gss, a.min_tiles):
             cfg = RtlfmCfg.default(downsample=D, downsample_passes=0 if a.boxcar else a.passes, rate_out=int(2.4e6 / D),
                                    block_len=L, max_blocks=nb)
-            with GpuDemod(cfg, S, 0, options=dict(fused_waves=w, fused_min_tiles=a.min_tiles)) as g:
+            with GpuDemod(cfg, S, 0, options=dict(fused_waves=w, fused_min_tiles=mt, fused_gss=gss)) as g:
                 cap = g.result_cap(nb)
                 out = torch.empty((S, cap), dtype=torch.int16, device=dev)
                 n = torch.zeros(S, dtype=torch.int32, device=dev)
@@ -62,7 +67,7 @@ def main():
                 g.clock_probe(False)
             launch = ms / cnt
             gbs = (2.0 + 2.0 / D) * S * nb * (L // 2) / (launch * 1e-3) / 1e9
-            line = f"nb={nb} fused_waves={w:6d}: {launch:.4f} ms/launch = {gbs:7.1f} GB/s ({gbs / 8000:.3f})"
+            line = f"S={S} nb={nb} fused_waves={w:6d} gss={gss:3d} min_tiles={mt:2d}: {launch:.4f} ms/launch = {gbs:7.1f} GB/s ({gbs / 8000:.3f})"
             if st is not None and len(st):
                 rt0, rt1 = st[:, 2].astype(np.int64), st[:, 3].astype(np.int64)
                 base = rt0.min()
