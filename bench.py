@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--boxcar", type=int, default=None,
                     help="D > 0: the reference's default low_pass boxcar /D instead of fifth_order passes")
     ap.add_argument("--fir9", type=int, default=None)
+    ap.add_argument("--rdc", type=int, default=0, help="1: -E rdc (dc_block_raw_filter) in front of the chain")
     ap.add_argument("--atan", choices=["std", "fast", "lut"], default=None)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 staged, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,7 +163,7 @@ def pmc_traffic(a):
             "--warmup", "2", "--sustain", "0", "--no-cpu-baseline", "--check", "0", "--workload", a.workload,
             "--streams", str(a.streams), "--blocks", str(a.blocks), "--block-len", str(a.block_len),
             "--path", str(a.path), "--atan", a.atan, "--colocate", "1", "--ceiling", "0", "--also", "0", "--e2e", "0"]
-    base += ["--boxcar", str(a.boxcar)] if a.boxcar else ["--passes", str(a.passes), "--fir9", str(a.fir9)]
+    base += ["--boxcar", str(a.boxcar)] if a.boxcar else ["--passes", str(a.passes), "--fir9", str(a.fir9), "--rdc", str(a.rdc)]
     out = {}
     tmp = tempfile.mkdtemp(prefix="rtlfm_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -367,20 +368,45 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
         import subprocess
         import tempfile
         nthreads = int(os.environ.get("RTLFM_E2E_THREADS", "8"))  # 8: 46 GB/s, 16-128: 37-43 on the box it was tried on
-        with tempfile.NamedTemporaryFile(suffix=".cfg") as tf:
-            tf.write(bytes(cfg)); tf.flush()
-            try:
-                p = subprocess.run([native, tf.name, str(S), str(nthreads), str(seconds), str(local_rank)], capture_output=True,
-                                   text=True, timeout=120)
-                res = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else None
-            except Exception:  # noqa: BLE001 - fall back to the Python threads
-                res = None
+
+        def run_native(c, streams, mode, secs):
+            with tempfile.NamedTemporaryFile(suffix=".cfg") as tf:
+                tf.write(bytes(c)); tf.flush()
+                try:
+                    p = subprocess.run([native, tf.name, str(streams), str(nthreads), str(secs), "--devices", str(local_rank),
+                                        "--mode", mode], capture_output=True, text=True, timeout=180)
+                    return json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else None
+                except Exception:  # noqa: BLE001 - fall back to the Python threads
+                    return None
+        res = run_native(cfg, S, "push", seconds)
         if res:
-            return {"value": res["Msamples/s"], "unit": "Msamples/s", "GB/s_in": res["GB/s_in"],
-                    "pinned_h2d_GB/s": round(h2d_ceiling(), 1), "harness": "native",
-                    "what": f"{S} streams x 1 buffer x {L} B per run, {res['runs']} pipelined runs in {res['seconds']:.2f} s: {nthreads} "
-                            f"native threads rtlfm_gpu_push (pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | "
-                            f"rtlfm_gpu_fetch_all; bounded by the host memcpy into the ring and PCIe, not by the kernels"}
+            h2d = round(h2d_ceiling(), 1)
+            out = {"value": res["Msamples/s"], "unit": "Msamples/s", "GB/s_in": res["GB/s_in"],
+                   "pinned_h2d_GB/s": h2d, "frac_of_pinned_h2d": round(res["GB/s_in"] / h2d, 3), "harness": "native",
+                   "what": f"{S} streams x 1 buffer x {L} B per run, {res['runs']} pipelined runs in {res['seconds']:.2f} s: {nthreads} "
+                           f"native threads rtlfm_gpu_push (pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | "
+                           f"rtlfm_gpu_fetch_all; bounded by the host memcpy into the ring and PCIe, not by the kernels"}
+            za = run_native(cfg, S, "acquire", seconds)
+            if za:
+                out["zero_copy"] = {"GB/s_in": za["GB/s_in"], "value": za["Msamples/s"], "frac_of_pinned_h2d": round(za["GB/s_in"] / h2d, 3),
+                                    "what": "the same loop with rtlfm_gpu_acquire / _commit: the producer writes the pinned ring slot itself "
+                                            "(here a repeating 64 KiB pattern per buffer: what a receiving socket or a DMA-capable device layer "
+                                            "leaves behind), no memcpy between producer and H2D"}
+            if a.workload == "c2":
+                # BASELINE configs[4]'s per-GPU share end to end: 4096 NBFM streams, /64 + FIR9 + deemph + arbitrary_resample
+                from rtlsdr_amd.capi import RESAMPLE_ARBITRARY, load
+                c3 = RtlfmCfg.default(downsample=64, downsample_passes=6, comp_fir_size=9, rate_out=16000, deemph=1,
+                                      deemph_a=load().rtlfm_deemph_a(16000, 75), rate_out2=22050, resampler=RESAMPLE_ARBITRARY,
+                                      block_len=L, max_blocks=1)
+                for mode in ("push", "acquire"):
+                    r3 = run_native(c3, 4096, mode, 2.0)
+                    if r3:
+                        out.setdefault("c3_4096_streams", {})[mode] = {
+                            "GB/s_in": r3["GB/s_in"], "value": r3["Msamples/s"], "frac_of_pinned_h2d": round(r3["GB/s_in"] / h2d, 3)}
+                if "c3_4096_streams" in out:
+                    out["c3_4096_streams"]["what"] = (f"configs[4]'s share of one GPU end to end: 4096 streams x 1 buffer x {L} B per run, "
+                                                      "u8 IQ in host memory -> int16 audio at 22.05 kHz in host memory")
+            return out
     host = job.iq[:S, :L].contiguous().cpu().numpy()  # pageable, as a driver's transfer buffers are
     nthreads = int(os.environ.get("RTLFM_E2E_THREADS", "16"))
     with GpuDemod(cfg, S, local_rank) as g, ThreadPoolExecutor(max_workers=nthreads) as pool:
@@ -575,7 +601,7 @@ class FmJob:
         self.D = D
         rate_out = int(a.fs / D)
         kw = dict(downsample=D, downsample_passes=a.passes, comp_fir_size=9 if a.fir9 else 0, custom_atan=atan,
-                  rate_out=rate_out, block_len=a.block_len, max_blocks=a.blocks)
+                  rate_out=rate_out, block_len=a.block_len, max_blocks=a.blocks, dc_block_raw=1 if a.rdc else 0)
         self.out_ratio = 1.0
         if a.tail == "c3":
             kw.update(rate_out=16000, deemph=1, deemph_a=lib.rtlfm_deemph_a(16000, 75), rate_out2=22050,
@@ -640,6 +666,7 @@ class FmJob:
         a, D = self.a, self.D
         front = f"low_pass boxcar /{D}" if a.boxcar else f"{a.passes}x fifth_order (/{D})" + (" + FIR9" if a.fir9 else "")
         tail = {"c3": " + deemph + arbitrary_resample 16k -> 22050", "wbfm": " + deemph + low_pass_real 170k -> 32k"}.get(a.tail, "")
+        front = ("dc_block_raw_filter + " if a.rdc else "") + front
         return (f"rtl_fm -A {a.atan}: {a.streams} streams/GPU x {a.blocks} buffers x {a.block_len} B u8 IQ @{a.fs / 1e6:g} MS/s, "
                 f"{front} + polar discriminant{tail} -> int16 PCM")
 

@@ -168,6 +168,22 @@ int rtlfm_gpu_destroy(rtlfm_gpu *h);
 int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint32_t len);
 
 /*
+ * The same boundary without the copy: the reference's zero-copy mode hands the callback the kernel's own
+ * transfer buffers (use_zerocopy, src/librtlsdr.c:2744-2810); here the producer - a file reader, an rtl_tcp
+ * receiver, any device layer that can write to a pointer - writes the samples of `stream`'s next buffer
+ * straight into the pinned staging ring:
+ *   rtlfm_gpu_acquire   *buf = where to write, *cap = cfg.block_len bytes of room; -ENOSPC when max_blocks
+ *                       buffers are queued, -EBUSY while this stream's previous slot is still open
+ *   rtlfm_gpu_commit    the first len bytes are a buffer (whole 512-byte packets, at most block_len;
+ *                       len == 0 gives the slot back unused)
+ * One open slot per stream; different streams concurrently, also while a run is in flight.
+ * rtlfm_gpu_run() returns -EAGAIN while a slot is open (it sees every buffer whole or not at all).
+ * rtlfm_gpu_push() stays for buffers that belong to someone else (librtlsdr's callback argument).
+ */
+int rtlfm_gpu_acquire(rtlfm_gpu *h, int stream, uint8_t **buf, uint32_t *cap);
+int rtlfm_gpu_commit(rtlfm_gpu *h, int stream, uint32_t len);
+
+/*
  * full_demod() for every queued buffer of every stream (all streams must have the same number
  * queued, else -EAGAIN and nothing changes).  Asynchronous: hands the filled half of the ring to
  * the GPU (async H2D on a copy stream, kernels behind it) and returns; callbacks go on filling the
@@ -349,6 +365,9 @@ int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t o
 int rtlfm_gpu_placement_probe(int device, const void *in, size_t in_bytes, void *out, size_t out_bytes,
                               double *read_ms, double *rw_ms);
 int rtlfm_gpu_free(void *p);
+/* NUMA node of the host the device hangs on (sysfs), or -1 if unknown: where the threads that fill the
+ * device's staging ring should run. */
+int rtlfm_gpu_device_numa_node(int device);
 
 const char *rtlfm_gpu_strerror(int err);
 /* (major<<16)|(minor<<8)|patch */

@@ -58,6 +58,17 @@ int rtlsdr_reset_buffer(rtlsdr_dev_t *dev);
 int rtlsdr_read_sync(rtlsdr_dev_t *dev, void *buf, int len, int *n_read);
 int rtlsdr_read_async(rtlsdr_dev_t *dev, rtlsdr_read_async_cb_t cb, void *ctx, uint32_t buf_num, uint32_t buf_len);
 int rtlsdr_cancel_async(rtlsdr_dev_t *dev);
+
+/*
+ * Extension (not one of the 26): zero-copy reads.  The reference's USB layer can hand the callback the
+ * kernel's own transfer buffers (use_zerocopy, src/librtlsdr.c:2744-2810); the counterpart here lets the
+ * consumer say where the next buffer is to be read TO - e.g. rtlfm_gpu_acquire()'s slot of the pinned
+ * staging ring.  `source(ctx, &buf, &cap)` is called before every read of rtlsdr_read_async(): 0 = read
+ * up to buf_len bytes into buf (cap >= buf_len), anything else = use the library's own buffer for this one.
+ * The callback then receives that pointer.  NULL switches it off.
+ */
+typedef int (*rtlamd_file_buffer_source_t)(void *ctx, unsigned char **buf, uint32_t *cap);
+int rtlamd_file_set_buffer_source(rtlsdr_dev_t *dev, rtlamd_file_buffer_source_t source, void *ctx);
 int rtlsdr_set_bias_tee(rtlsdr_dev_t *dev, int on);
 int rtlsdr_set_opt_string(rtlsdr_dev_t *dev, const char *opts, int verbose);
 const char *rtlsdr_get_ver_id(void);

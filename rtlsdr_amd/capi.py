@@ -171,6 +171,8 @@ _SIGNATURES = [
     ("rtlfm_gpu_create", C.c_int, [_P(RtlfmCfg), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("rtlfm_gpu_destroy", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_push", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]),
+    ("rtlfm_gpu_acquire", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_uint32)]),
+    ("rtlfm_gpu_commit", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("rtlfm_gpu_run", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_run_device", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -203,6 +205,7 @@ _SIGNATURES = [
     ("rtlfm_gpu_malloc_apart", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_void_p), _P(C.c_int)]),
     ("rtlfm_gpu_placement_probe", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_double), _P(C.c_double)]),
     ("rtlfm_gpu_free", C.c_int, [C.c_void_p]),
+    ("rtlfm_gpu_device_numa_node", C.c_int, [C.c_int]),
     ("rtlfm_gpu_strerror", C.c_char_p, [C.c_int]),
     ("rtlfm_gpu_version", C.c_int, []),
 ]

@@ -229,6 +229,7 @@ struct Params {
 	int segs, tiles_per_seg, nlist;
 	int seg_start[kMaxSegList + 1];
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
+	const int2 *rdc_avg;        // RDC kernels: [stream][nblocks] (avgI, avgQ) of dc_block_raw_filter, from k_rdc_sums / k_rdc_smooth
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps (printed per launch; +16 = 18:
 	            // only on timing_read, i.e. for the last launch of an uninterrupted run), 4 = reload one (cached) tile
 	unsigned long long *stamps;  // [waves][4] when debug & 2
@@ -369,10 +370,11 @@ __device__ __forceinline__ void ring_exchange(uint32_t *ring, const uint32_t (&m
 
 // unpack one raw dword (samples 2j, 2j+1 of a buffer) into two rotated packed
 // (I,Q) int16 pairs: reference convert (:1326-1328) + rotate16_neg90 (:424-434)
-__device__ __forceinline__ void unpack_rot(uint32_t raw, int j_odd, int rotate, uint32_t &s0, uint32_t &s1)
+// dcI / dcQ: what dc_block_raw_filter (:1043-1065) subtracts from this buffer's I / Q samples before the rotation
+__device__ __forceinline__ void unpack_rot(uint32_t raw, int j_odd, int rotate, uint32_t &s0, uint32_t &s1, int dcI = 0, int dcQ = 0)
 {
-	int a0 = (int)(raw & 0xff) - 127, b0 = (int)((raw >> 8) & 0xff) - 127;
-	int a1 = (int)((raw >> 16) & 0xff) - 127, b1 = (int)(raw >> 24) - 127;
+	int a0 = (int)(raw & 0xff) - 127 - dcI, b0 = (int)((raw >> 8) & 0xff) - 127 - dcQ;
+	int a1 = (int)((raw >> 16) & 0xff) - 127 - dcI, b1 = (int)(raw >> 24) - 127 - dcQ;
 	if (!rotate) {
 		s0 = pack_iq(a0, b0); s1 = pack_iq(a1, b1);
 	} else if (!j_odd) {
@@ -428,9 +430,17 @@ struct AtanNodesLds {
 // common case and the one the roofline is quoted on); otherwise p.variant picks
 // fast / lut at run time.
 // MFMA0: pass 0 on the int8 matrix pipe instead of v_dot4 (see make_mfma_taps).
-template <int P, bool FIR9, bool STD, bool MFMA0>
+// RDC: dc_block_raw_filter (-E rdc, src/rtl_fm.c:1043-1065, 1330-1332) in front of the chain.  The
+// filter subtracts one (avgI, avgQ) per buffer - the block mean smoothed over the blocks, which a
+// pre-pass has to know before the first sample (k_rdc_sums / k_rdc_smooth: one more read of the
+// input) - and everything up to pass 0's ">> 4" is linear: the six-tap sum of the rotated constant is
+// C_I = -/+ 4 (aI - aQ), C_Q = -/+ 4 (aI + aQ) for even / odd outputs (32 aI, 32 aQ without the
+// rotation), and -16 C is what the MFMA accumulators start from instead of zero.  No instruction is
+// added to the tile; samples now span +-255, so pass 3 takes the 32-bit form as it does without rotation.
+template <int P, bool FIR9, bool STD, bool MFMA0, bool RDC = false>
 __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
 {
+	static_assert(!RDC || MFMA0, "the raw DC block rides on the MFMA accumulators");
 	using L = Lds<P, FIR9, MFMA0>;
 	constexpr int CZ = L::cz;
 	__shared__ __attribute__((aligned(128))) uint32_t lds[L::total];
@@ -530,6 +540,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		const uint4 a = reinterpret_cast<const uint4 *>(p.mfma_taps)[lane];
 		mfma_a = v4i_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
 	}
+	int dcI = 0, dcQ = 0;             // RDC: this buffer's (avgI, avgQ)
+	v4i_t dc_acc = {0, 0, 0, 0};      // -16 x the six-tap sum of the rotated constant: rows (I', Q') of an even and an odd output
 
 	// The PCM of tile t is stored just before tile t+2's loads are issued, never
 	// after them: loads and stores share the in-order vmcnt counter on gfx9-family
@@ -571,6 +583,17 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		const bool archive = last && writes_state && lane == 63;
 
 		RTLFM_MARK("tile_begin");
+		if constexpr (RDC) {
+			if (bs || gt == gt_begin) {
+				// a scalar load (the index is wave-uniform; readfirstlane says so to the compiler): a vector load
+				// would share the in-order vmcnt with the tile prefetch and force it to land (tools/check_prefetch.py)
+				const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + gt / tpb);
+				const int2 a = p.rdc_avg[idx];
+				dcI = __builtin_amdgcn_readfirstlane(a.x); dcQ = __builtin_amdgcn_readfirstlane(a.y);
+				if (rotate) dc_acc = v4i_t{64 * (dcI - dcQ), 64 * (dcI + dcQ), -64 * (dcI - dcQ), -64 * (dcI + dcQ)};
+				else dc_acc = v4i_t{-512 * dcI, -512 * dcQ, -512 * dcI, -512 * dcQ};
+			}
+		}
 		// ---------------------------------------------------------------- pass 0 ----
 		uint32_t Y0[32];
 		if constexpr (MFMA0) {
@@ -581,9 +604,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				uint32_t e[11];
 #pragma unroll
 				for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
-				unpack_rot(cur[0].x, 0, rotate, e[5], e[6]);
-				unpack_rot(cur[0].y, 1, rotate, e[7], e[8]);
-				unpack_rot(cur[0].z, 0, rotate, e[9], e[10]);
+				unpack_rot(cur[0].x, 0, rotate, e[5], e[6], dcI, dcQ);
+				unpack_rot(cur[0].y, 1, rotate, e[7], e[8], dcI, dcQ);
+				unpack_rot(cur[0].z, 0, rotate, e[9], e[10], dcI, dcQ);
 				fix0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
 				fix1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
 				fix2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
@@ -591,10 +614,10 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			__builtin_amdgcn_wave_barrier();
 			if (next_bs) {
 				uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
-				unpack_rot(cur[7].x, 0, rotate, a0, a1);
-				unpack_rot(cur[7].y, 1, rotate, a2, a3);
-				unpack_rot(cur[7].z, 0, rotate, a4, a5);
-				unpack_rot(cur[7].w, 1, rotate, a6, a7);
+				unpack_rot(cur[7].x, 0, rotate, a0, a1, dcI, dcQ);
+				unpack_rot(cur[7].y, 1, rotate, a2, a3, dcI, dcQ);
+				unpack_rot(cur[7].z, 0, rotate, a4, a5, dcI, dcQ);
+				unpack_rot(cur[7].w, 1, rotate, a6, a7, dcI, dcQ);
 				if (lane == 63) {
 					lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
 					lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
@@ -659,7 +682,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					for (int k = 0; k < 4; k++) {
 						const uint4 o = bop[g + k];
 						acc[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mfma_a, v4i_t{(int)o.x, (int)o.y, (int)o.z, (int)o.w},
-						                                                v4i_t{0, 0, 0, 0}, 0, 0, 0);
+						                                                RDC ? dc_acc : v4i_t{0, 0, 0, 0}, 0, 0, 0);
 					}
 #pragma unroll
 					for (int k = 0; k < 4; k++) {
@@ -826,7 +849,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lane, next_bs);
 					// with rotation |x| <= 1023 here, so the 16-bit form cannot overflow;
 					// without it an all-255 input reaches exactly 2^15
-					if (rotate) fifth_lane<8, true>(Y2, h5, Y3);
+					if (rotate && !RDC) fifth_lane<8, true>(Y2, h5, Y3);
 					else fifth_lane<8, false>(Y2, h5, Y3);
 					archive_regs(Y2, std::integral_constant<int, 8>(), 3);
 					if constexpr (P == 4) {
@@ -960,6 +983,10 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 	}
 	flush_held();
+	if constexpr (RDC) {
+		// dc_block_raw_filter keeps its smoothed averages (src/rtl_fm.c:1062-1063): those of the run's last buffer
+		if (writes_state && lane == 0) { sout->dc_avgI = dcI; sout->dc_avgQ = dcQ; }
+	}
 	if ((p.debug & 2) && lane == 0) {
 		unsigned long long e_clk = __builtin_amdgcn_s_memtime(), e_rt = __builtin_amdgcn_s_memrealtime();
 		if (p.debug & 32) {
@@ -1084,14 +1111,20 @@ inline bool supported(const rtlfm_cfg &c, int nblocks)
 		return false;
 	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
 	if (c.block_len % kTileBytes) return false;
-	if (c.dc_block_raw || c.squelch_level || c.report_levels) return false;
+	if (c.squelch_level || c.report_levels) return false;
 	(void)nblocks;
-	return true;
+	return true;  // -E rdc: the RDC instantiations (MFMA pass 0 only; rtlfm_hip.hip checks the engine)
 }
 
 template <int P, bool FIR9>
 static int launch_one(const Params &p, int waves, hipStream_t q)
 {
+	if (p.rdc_avg) {
+		if (!p.mfma_taps) return -ENOTSUP;
+		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true, true>), dim3(waves), dim3(64), 0, q, p);
+		else hipLaunchKernelGGL((k_fused<P, FIR9, false, true, true>), dim3(waves), dim3(64), 0, q, p);
+		return hipGetLastError() == hipSuccess ? 0 : -EIO;
+	}
 	if (p.mfma_taps) {
 		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true>), dim3(waves), dim3(64), 0, q, p);
 		else hipLaunchKernelGGL((k_fused<P, FIR9, false, true>), dim3(waves), dim3(64), 0, q, p);
@@ -1106,11 +1139,13 @@ static int launch_one(const Params &p, int waves, hipStream_t q)
 // passes configured, the first six run here (without the FIR)
 inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, const state_t *sin, state_t *sout,
-                  const int32_t *lut, hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0)
+                  const int32_t *lut, hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0,
+                  const int2 *rdc_avg = nullptr)
 {
 	if (!emit_iq && (((uintptr_t)d_out & 15) || (out_stride & 7))) return -EINVAL;
 	Params p{};
 	p.emit_iq = emit_iq; p.emit_iq_stride = emit_iq_stride;
+	p.rdc_avg = rdc_avg;
 	if (int r = ensure_dummy_tile(ws)) return r;
 	p.dummy_tile = ws.dummy_tile;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
@@ -1128,6 +1163,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	// passes, 11 % at 5).  The v_dot4 form needs no matrix pipe and no LDS staging.
 	int engine = ws.pass0_engine;
 	if (engine < 0) engine = RTLFM_PASS0_DEFAULT ? 1 : 0;
+	if (rdc_avg && engine != 1) return -ENOTSUP;
 	if (engine == 1) {
 		uint32_t *&t = ws.mfma_taps[p.rotate];
 		if (!t) {

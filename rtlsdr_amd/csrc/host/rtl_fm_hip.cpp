@@ -75,13 +75,47 @@ struct App {
 	double level_sum = 0.0;
 	uint32_t user_freq = 0;
 	uint64_t blocks_in = 0, samples_out = 0, blocks_squelched = 0;
+	bool zero_copy = false;            // -Z: the device layer reads straight into the pinned staging ring
+	unsigned char *open_slot = nullptr;  // the slot the device layer is filling (rtlfm_gpu_acquire)
 };
+
+// -Z: where the device layer reads its next buffer to (rtlamd_file_set_buffer_source): a slot of the GPU
+// layer's pinned ring, the counterpart of the reference's zero-copy USB buffers (src/librtlsdr.c:2744-2810)
+int next_slot(void *ctx, unsigned char **buf, uint32_t *cap)
+{
+	App *a = static_cast<App *>(ctx);
+	for (;;) {
+		uint8_t *p = nullptr;
+		int r = rtlfm_gpu_acquire(a->gpu, 0, &p, cap);
+		if (r == 0) { a->open_slot = p; *buf = p; return 0; }
+		if (r != -ENOSPC) return r;  // not fatal: the device layer falls back to its own buffer and the callback pushes
+		std::unique_lock<std::mutex> g(a->p.m);
+		a->p.cv_room.wait(g, [&] { return a->p.queued < a->cfg.max_blocks || a->p.failed; });
+		if (a->p.failed) return -1;
+	}
+}
 
 // the rtlsdr_read_async callback (reference rtlsdr_callback, src/rtl_fm.c:1274)
 void on_buffer(unsigned char *buf, uint32_t len, void *ctx)
 {
 	App *a = static_cast<App *>(ctx);
 	len -= len % 512;  // actual_length comes in whole USB packets; a file's last bytes may not
+	if (a->open_slot && buf == a->open_slot) {
+		// the samples are already where they belong: say how many (0 gives the slot back)
+		a->open_slot = nullptr;
+		int r = rtlfm_gpu_commit(a->gpu, 0, len);
+		std::lock_guard<std::mutex> g(a->p.m);
+		if (r < 0) {
+			fprintf(stderr, "rtlfm_gpu_commit: %s\n", rtlfm_gpu_strerror(r));
+			a->p.failed = true;
+			rtlsdr_cancel_async(a->dev);
+		} else if (len) {
+			a->p.queued++;
+			a->blocks_in++;
+		}
+		a->p.cv_work.notify_one();
+		return;
+	}
 	if (len == 0) return;
 	for (;;) {
 		int r = rtlfm_gpu_push(a->gpu, 0, buf, len);
@@ -106,6 +140,7 @@ void on_buffer(unsigned char *buf, uint32_t len, void *ctx)
 
 void dongle_thread(App *a)
 {
+	if (a->zero_copy) rtlamd_file_set_buffer_source(a->dev, next_slot, a);
 	rtlsdr_read_async(a->dev, on_buffer, a, 0, a->cfg.block_len);
 	std::lock_guard<std::mutex> g(a->p.m);
 	a->p.eof = true;
@@ -218,6 +253,7 @@ void usage()
 	        "\t[-L N  prints levels every N calculations]\n"
 	        "\t[-W length of one buffer in units of 512 bytes (default: 32 = 16384 B)]\n"
 	        "\t[-H write a wave header with the auxi chunk SDR programs read the frequency from]\n"
+	        "\t[-Z zero-copy: the device layer reads straight into the GPU layer's pinned staging ring]\n"
 	        "\t[-d device_index] [-g gain] [-p ppm]  accepted and passed to the device layer\n"
 	        "\tfilename ('-' means stdout)\n");
 	exit(1);
@@ -238,7 +274,7 @@ int main(int argc, char **argv)
 	c.rate_out = 24000;
 	c.max_blocks = 8;
 	int opt;
-	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:t:r:p:E:F:A:M:hm:L:q:c:W:Hv")) != -1) {
+	while ((opt = getopt(argc, argv, "d:f:g:s:l:o:t:r:p:E:F:A:M:hm:L:q:c:W:HvZ")) != -1) {
 		switch (opt) {
 		case 'd': dev_index = atoi(optarg); break;
 		case 'f': freq = (uint32_t)atofs(optarg); have_freq = true; break;
@@ -296,6 +332,7 @@ int main(int argc, char **argv)
 			break;
 		}
 		case 'H': write_wav = true; break;
+		case 'Z': a.zero_copy = true; break;
 		case 'v': a.verbosity++; break;
 		default: usage();
 		}

@@ -36,6 +36,8 @@ struct rtlsdr_dev {
 	int gain, ppb, agc, direct, offset, bias, gain_mode;
 	volatile int async_running, cancel;
 	int loop;
+	rtlamd_file_buffer_source_t source;  /* zero-copy extension: where the next async buffer is read to */
+	void *source_ctx;
 };
 
 static const char *env_path(void)
@@ -231,15 +233,32 @@ int rtlsdr_read_async(rtlsdr_dev_t *d, rtlsdr_read_async_cb_t cb, void *ctx, uin
 	d->async_running = 1;
 	uint32_t k = 0;
 	while (!d->cancel) {
-		size_t got = read_some(d, bufs[k], buf_len);
-		if (got == 0) break;                   /* end of file */
-		if (cb) cb(bufs[k], (uint32_t)got, ctx);  /* may be short at the very end, as actual_length can be */
+		unsigned char *dst = bufs[k];
+		uint32_t cap = 0;
+		if (d->source) {
+			/* the consumer's own memory (e.g. a slot of the GPU layer's pinned ring): read straight into it */
+			unsigned char *p = NULL;
+			if (d->source(d->source_ctx, &p, &cap) == 0 && p && cap >= buf_len) dst = p;
+		}
+		size_t got = read_some(d, dst, buf_len);
+		if (got == 0 && dst == bufs[k]) break;  /* end of file */
+		if (cb) cb(dst, (uint32_t)got, ctx);    /* may be short at the very end, as actual_length can be; 0 bytes
+		                                         * only for a consumer-owned buffer, which has to be given back */
 		if (got < buf_len) break;
 		k = (k + 1) % buf_num;
 	}
 	d->async_running = 0;
 	for (uint32_t i = 0; i < buf_num; i++) free(bufs[i]);
 	free(bufs);
+	return 0;
+}
+
+int rtlamd_file_set_buffer_source(rtlsdr_dev_t *d, rtlamd_file_buffer_source_t source, void *ctx)
+{
+	if (!d) return -1;
+	if (d->async_running) return -2;
+	d->source = source;
+	d->source_ctx = ctx;
 	return 0;
 }
 

@@ -1059,7 +1059,16 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
-	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q);
+	const int2 *rdc = nullptr;
+	if (c.dc_block_raw) {
+		// dc_block_raw_filter needs every buffer's mean before its first sample: one more pass over the
+		// input (the per-buffer sums), the smoothing recurrence over a stream's buffers, and then the
+		// averages ride on the front end's MFMA accumulators (fused_kernel.h, RDC)
+		k_rdc_sums_wide<<<dim3((unsigned)nblocks, (unsigned)S), 256, 0, q>>>(d_iq, stream_stride, c.block_len, h->d_sums);
+		k_rdc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, sin, sout, h->d_rdc_avg);
+		rdc = h->d_rdc_avg;
+	}
+	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q, nullptr, 0, rdc);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -1184,6 +1193,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	HIP_TRY(hipSetDevice(h->device));
 	const size_t S = (size_t)h->nstreams;
 	bool can_fuse = fused::supported(h->cfg, nblocks);
+	if (h->cfg.dc_block_raw && h->fws.pass0_engine == 0) can_fuse = false;  // the raw DC block rides on the MFMA pass 0
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
@@ -1266,6 +1276,7 @@ struct Ingest {
 	uint8_t *d_in[2] = {nullptr, nullptr};
 	std::vector<uint32_t> h_len[2];             // bytes in each slot
 	std::unique_ptr<std::atomic<int>[]> pushed[2];
+	std::unique_ptr<std::atomic<int>[]> open_slot;  // [stream] 1 + half while a slot is out between acquire and commit
 	int fill = 0;                               // guarded by mu (shared: read, exclusive: flip)
 	std::shared_mutex mu;
 	hipStream_t copy_stream = nullptr;
@@ -1327,6 +1338,8 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 		in->pushed[k].reset(new std::atomic<int>[S]);
 		for (size_t s = 0; s < S; s++) in->pushed[k][s].store(0);
 	}
+	in->open_slot.reset(new std::atomic<int>[S]);
+	for (size_t s = 0; s < S; s++) in->open_slot[s].store(0);
 	return 0;
 }
 
@@ -1360,6 +1373,7 @@ static void ingest_reset(rtlfm_gpu *h)
 	std::unique_lock<std::shared_mutex> g(in->mu);
 	for (int k = 0; k < 2; k++)
 		for (int s = 0; s < h->nstreams; s++) in->pushed[k][s].store(0);
+	for (int s = 0; s < h->nstreams; s++) in->open_slot[s].store(0);
 	in->last = -1;
 	in->mirror_valid = false;
 }
@@ -1393,6 +1407,56 @@ extern "C" int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint3
 	const size_t at = (size_t)stream * h->cap_blocks + slot;
 	memcpy(in->h_stage[f] + at * h->cfg.block_len, iq, len);
 	in->h_len[f][at] = len;
+	return 0;
+}
+
+// Zero-copy ingest: the producer fills the pinned ring slot itself.  The reference has this at the
+// USB side (use_zerocopy, src/librtlsdr.c:2744-2810: the kernel's transfer buffers are mapped into
+// the process and handed to the callback as they are); here the device layer - a file reader, an
+// rtl_tcp receiver, anything that can write to a pointer - asks for the next slot of its stream,
+// writes the samples there, and commits the length.  No memcpy between the producer and the H2D copy.
+extern "C" int rtlfm_gpu_acquire(rtlfm_gpu *h, int stream, uint8_t **buf, uint32_t *cap)
+{
+	if (!h || !buf || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	int r = ingest_ensure(h);
+	if (r < 0) return r;
+	Ingest *in = h->ing;
+	std::shared_lock<std::shared_mutex> g(in->mu);
+	const int f = in->fill;
+	if (in->open_slot[stream].load(std::memory_order_acquire)) return -EBUSY;  // one open slot per stream
+	const int slot = in->pushed[f][stream].load(std::memory_order_acquire);
+	if (slot >= h->cap_blocks) return -ENOSPC;
+	in->open_slot[stream].store(1 + f, std::memory_order_release);
+	*buf = in->h_stage[f] + ((size_t)stream * h->cap_blocks + slot) * h->cfg.block_len;
+	if (cap) *cap = h->cfg.block_len;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_commit(rtlfm_gpu *h, int stream, uint32_t len)
+{
+	if (!h || stream < 0 || stream >= h->nstreams) return -EINVAL;
+	Ingest *in = h->ing;
+	if (!in) return -EINVAL;
+	std::shared_lock<std::shared_mutex> g(in->mu);
+	const int o = in->open_slot[stream].load(std::memory_order_acquire);
+	if (!o) return -EINVAL;
+	const int f = o - 1;  // rtlfm_gpu_run() does not flip the halves while a slot is open: f is still the filling half
+	if (len == 0) {       // nothing arrived: give the slot back
+		in->open_slot[stream].store(0, std::memory_order_release);
+		return 0;
+	}
+	if (len > h->cfg.block_len || len % 512) return -EINVAL;
+	if (len != h->cfg.block_len) {
+		rtlfm_cfg c = h->cfg;
+		c.block_len = len;
+		c.max_blocks = 1;
+		const int v = validate_cfg(&c);
+		if (v < 0) return v;
+	}
+	const int slot = in->pushed[f][stream].load(std::memory_order_acquire);
+	in->h_len[f][(size_t)stream * h->cap_blocks + slot] = len;
+	in->pushed[f][stream].store(slot + 1, std::memory_order_release);
+	in->open_slot[stream].store(0, std::memory_order_release);
 	return 0;
 }
 
@@ -1517,6 +1581,8 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 		for (int s = 1; s < S; s++)
 			if (in->pushed[f][s].load() != nb) return -EAGAIN;
 		if (nb == 0) return -EAGAIN;
+		for (int s = 0; s < S; s++)
+			if (in->open_slot[s].load(std::memory_order_acquire)) return -EAGAIN;  // a producer is still writing its slot
 		for (int s = 0; s < S && !ragged; s++)
 			for (int j = 0; j < nb; j++)
 				if (in->h_len[f][(size_t)s * h->cap_blocks + j] != L) { ragged = true; break; }
@@ -1897,6 +1963,26 @@ extern "C" int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int r
 	return rc;
 }
 
+// NUMA node of the host the device hangs on (/sys/bus/pci/devices/<bdf>/numa_node), or -1: where the
+// threads that feed the device's staging ring should run (host/ingest_bench.cpp pins them there)
+extern "C" int rtlfm_gpu_device_numa_node(int device)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -1;
+	char bdf[64] = {0};
+	if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return -1;
+	for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+	char path[256];
+	snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+	FILE *f = fopen(path, "r");
+	int node = -1;
+	if (f) {
+		if (fscanf(f, "%d", &node) != 1) node = -1;
+		fclose(f);
+	}
+	return node;
+}
+
 // Plain device memory (hipMalloc) through the library, for callers that have no HIP runtime of their own at hand.
 extern "C" int rtlfm_gpu_malloc(int device, size_t bytes, void **out)
 {
@@ -1940,7 +2026,8 @@ extern "C" const char *rtlfm_gpu_strerror(int err)
 	case -ENODEV: return "no usable HIP device (there is no CPU fallback)";
 	case -ENOMEM: return "out of device memory";
 	case -ENOSPC: return "max_blocks already queued for this stream";
-	case -EAGAIN: return "streams have unequal / zero queued blocks";
+	case -EAGAIN: return "streams have unequal / zero queued blocks, or a producer still holds an acquired slot";
+	case -EBUSY: return "the stream's previous slot is still open (rtlfm_gpu_acquire without rtlfm_gpu_commit)";
 	case -ENOTSUP: return "configuration not supported on this path";
 	case -EDOM: return "rate_out2 > rate_out with low_pass_real: the reference divides by zero here";
 	case -E2BIG: return "more blocks than cfg.max_blocks";

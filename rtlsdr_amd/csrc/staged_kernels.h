@@ -104,6 +104,40 @@ k_rdc_sums(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, int
 	}
 }
 
+// The same sums at streaming speed, for the fused front end's -E rdc path: one workgroup per
+// (buffer, stream), 16-byte loads, v_dot4 against (1, 0, 1, 0) / (0, 1, 0, 1) byte masks (u8 sums;
+// the -127 per sample is taken off once at the end), wave reduction by DPP.
+__global__ void __launch_bounds__(256)
+k_rdc_sums_wide(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, long long *__restrict__ sums /* [s][b][2] */)
+{
+	const int b = blockIdx.x, nblocks = gridDim.x;
+	const size_t s = blockIdx.y;
+	const uint8_t *src = iq + s * stream_stride + (size_t)b * L;
+	unsigned si = 0, sq = 0;  // <= 262144 * 255 / 2: fits
+	const uint32_t n16 = L / 16;
+	for (uint32_t k = threadIdx.x; k < n16; k += 256) {
+		const uint4 v = reinterpret_cast<const uint4 *>(src)[k];
+		si = __builtin_amdgcn_udot4(v.x, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.x, 0x01000100u, sq, false);
+		si = __builtin_amdgcn_udot4(v.y, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.y, 0x01000100u, sq, false);
+		si = __builtin_amdgcn_udot4(v.z, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.z, 0x01000100u, sq, false);
+		si = __builtin_amdgcn_udot4(v.w, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.w, 0x01000100u, sq, false);
+	}
+	for (uint32_t k = n16 * 16 + threadIdx.x * 2; k < L; k += 512) { si += src[k]; sq += src[k + 1]; }
+	for (int off = 32; off > 0; off >>= 1) {
+		si += __shfl_down(si, off, 64);
+		sq += __shfl_down(sq, off, 64);
+	}
+	__shared__ unsigned red[2][4];
+	const int w = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) { red[0][w] = si; red[1][w] = sq; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const long long pairs = L / 2;
+		sums[(s * nblocks + b) * 2] = (long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]) - 127 * pairs;
+		sums[(s * nblocks + b) * 2 + 1] = (long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]) - 127 * pairs;
+	}
+}
+
 // The smoothing recurrence of dc_block_raw_filter (src/rtl_fm.c:1054-1057,
 // :1062-1063), sequential over a stream's blocks.  One thread per stream.
 __global__ void k_rdc_smooth(const long long *__restrict__ sums, uint32_t L, int nblocks, int nstreams,

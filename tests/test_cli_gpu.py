@@ -26,6 +26,11 @@ CASES = [
     (["-M", "am", "-s", "12k", "-E", "dc"], (12000, 1000000, 0, dict(mode=MODE_AM, rate_out=12000, dc_block_audio=1)), 1.008e6),
     (["-M", "wbfm", "-E", "dc"], (170000, 1000000, 0, dict(rate_out=170000, rate_out2=32000, custom_atan=ATAN_FAST, deemph=1, resampler=RESAMPLE_LOW_PASS_REAL, dc_block_audio=1)), 1.02e6),
     (["-M", "usb", "-s", "3k"], (3000, 1000000, 0, dict(mode=MODE_USB, rate_out=3000)), 1.002e6),
+    # -Z: the device layer reads straight into the pinned staging ring (rtlfm_gpu_acquire / _commit)
+    (["-M", "fm", "-s", "150k", "-m", "1.3M", "-F", "0", "-Z"], (150000, 1300000, 1, dict(rate_out=150000)), 2.4e6),
+    (["-M", "wbfm", "-Z"], (170000, 1000000, 0, dict(rate_out=170000, rate_out2=32000, custom_atan=ATAN_FAST, deemph=1, resampler=RESAMPLE_LOW_PASS_REAL)), 1.02e6),
+    # -E rdc: dc_block_raw_filter in front of the chain, on the one-launch front end
+    (["-M", "fm", "-s", "150k", "-m", "1.3M", "-F", "0", "-E", "rdc"], (150000, 1300000, 1, dict(rate_out=150000, dc_block_raw=1)), 2.4e6),
 ]
 
 

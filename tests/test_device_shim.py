@@ -46,6 +46,49 @@ def test_exports_exactly_the_26_symbols(shim):
     assert have == sorted(SYMS) and len(have) == 26
 
 
+def test_async_reads_into_consumer_memory(shim, tmp_path, monkeypatch):
+    """The zero-copy extension (rtlamd_file_set_buffer_source): rtlsdr_read_async reads every buffer
+    straight into memory the consumer names and hands the callback that pointer - what rtl_fm_hip -Z does
+    with the GPU layer's pinned ring slots (the reference's counterpart: use_zerocopy,
+    src/librtlsdr.c:2744-2810)."""
+    lib, _ = shim
+    data = np.random.default_rng(2).integers(0, 256, size=16384 * 4 + 700, dtype=np.uint8)
+    f = tmp_path / "iq.bin"
+    data.tofile(f)
+    monkeypatch.setenv("RTLSDR_FILE", str(f))
+    h = C.c_void_p()
+    assert lib.rtlsdr_open(C.byref(h), 0) == 0
+    mine = np.zeros((6, 16384), dtype=np.uint8)
+    handed, seen = [], []
+    SRC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
+
+    def source(ctx, buf, cap):
+        k = len(handed)
+        if k == 2:          # "no slot this time": the library falls back to its own buffer
+            handed.append(None)
+            return -1
+        handed.append(mine[k].ctypes.data)
+        buf[0] = mine[k].ctypes.data
+        cap[0] = 16384
+        return 0
+
+    def cb(buf, n, ctx):
+        seen.append((C.cast(buf, C.c_void_p).value, n, bytes(C.string_at(buf, n))))
+    src_fn, cb_fn = SRC(source), CB(cb)
+    lib.rtlamd_file_set_buffer_source.argtypes = [C.c_void_p, SRC, C.c_void_p]
+    assert lib.rtlamd_file_set_buffer_source(h, src_fn, None) == 0
+    assert lib.rtlsdr_read_async(h, cb_fn, None, 0, 16384) == 0
+    assert [n for _, n, _ in seen] == [16384] * 4 + [700]
+    assert b"".join(b for _, _, b in seen) == data.tobytes()
+    for k, (ptr, n, _) in enumerate(seen):
+        if handed[k] is None:
+            assert ptr not in [x for x in handed if x]        # its own buffer
+        else:
+            assert ptr == handed[k]                            # read in place, no copy
+            assert bytes(mine[k][:n]) == data[k * 16384:k * 16384 + n].tobytes()
+    lib.rtlsdr_close(h)
+
+
 def test_no_file_means_no_device(shim, monkeypatch):
     lib, _ = shim
     monkeypatch.delenv("RTLSDR_FILE", raising=False)

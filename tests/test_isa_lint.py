@@ -20,6 +20,7 @@ def test_fused_kernels_keep_their_prefetch_in_flight():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
-    # every instantiation (6 pass counts x FIR on/off x std / run-time discriminator x two engines)
-    assert r.stdout.count(": ok") == 48, r.stdout[-3000:]
+    # every instantiation: 6 pass counts x FIR on/off x std / run-time discriminator x two engines,
+    # and the MFMA engine once more with the raw DC block (-E rdc) on its accumulators
+    assert r.stdout.count(": ok") == 72, r.stdout[-3000:]
     assert "STALL" not in r.stdout

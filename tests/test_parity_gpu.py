@@ -296,6 +296,41 @@ def test_segments_inside_buffers(oracle_lib, front, seg):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False)
 
 
+@pytest.mark.parametrize("passes,fir9,atan,offs", [(1, 0, 0, 0), (2, 1, 2, 0), (3, 0, 0, 0), (4, 0, 0, 0), (4, 1, 1, 0), (4, 0, 2, 1),
+                                                   (5, 1, 0, 0), (6, 1, 0, 0), (6, 0, 2, 1)])
+def test_raw_dc_block_on_the_fused_path(oracle_lib, passes, fir9, atan, offs):
+    """-E rdc (dc_block_raw_filter, src/rtl_fm.c:1043-1065, called at :1330-1332 between the u8 -> int16
+    conversion and the rotation) through the ONE-launch front end: per-buffer sums in a pre-pass, the
+    smoothed averages on the MFMA accumulators of pass 0.  Signals with a strong, drifting DC offset and
+    full-scale random bytes; carried dc_avgI / dc_avgQ; runs split over launches; segments inside buffers."""
+    ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if fir9 else 0, custom_atan=atan,
+              offset_tuning=offs, dc_block_raw=1)
+    L, nb, ns = 32768, 5, 7
+    cfg = make_cfg(ov, L, nb)
+    amp = 25.0 if atan == 1 else 50.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=7000 + passes, fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    rng = np.random.default_rng(passes)
+    for s_ in range(ns - 1):  # a DC offset per stream that changes from buffer to buffer
+        for b in range(nb):
+            off = rng.integers(-40, 41, size=2)
+            blk = iq[s_, b * L:(b + 1) * L].astype(np.int32)
+            blk[0::2] += off[0]; blk[1::2] += off[1]
+            iq[s_, b * L:(b + 1) * L] = np.clip(blk, 0, 255).astype(np.uint8)
+    if atan != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=passes)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits, opts in ((None, None), ([(0, 1), (1, 3), (3, 5)], None), (None, dict(fused_waves=1)), (None, dict(fused_tiles_per_seg=3))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        assert used == 2, "the raw DC block must not fall back to the staged kernels"
+        for s_ in range(ns):
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"rdc P={passes} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
+    so, ss, used1 = gpu_run(cfg, iq, path=1)
+    assert used1 == 1
+    for s_ in range(ns):
+        assert np.array_equal(so[s_], outs[s_])
+
+
 def test_options_by_name():
     """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
     from rtlsdr_amd.demod import GpuDemod

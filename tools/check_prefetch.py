@@ -83,8 +83,8 @@ def main():
         asm = open(out).read()
     bad = 0
     for name, body in kernels(asm):
-        m = re.match(r"_ZN5rtlfm5fused7k_fusedILi(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
-        tag = "P=%s fir9=%s std=%s mfma=%s" % m.groups() if m else name
+        m = re.match(r"_ZN5rtlfm5fused7k_fusedILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+        tag = "P=%s fir9=%s std=%s mfma=%s rdc=%s" % m.groups() if m else name
         pr = check(name, body)
         if pr:
             bad += 1
