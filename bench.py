@@ -856,9 +856,15 @@ def main():
     if a.e2e and rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child:
         e2e = e2e_leg(a, job, local_rank)
 
-    n_devices, scatter = 1, None
+    n_devices, scatter, per_rank = 1, None, None
     if dist:
         cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        # every rank's own clock and front-end launch time, so that host-side contention shows
+        mine = torch.tensor([elapsed / a.steps * 1e3, front_ms / max(launches, 1)], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(x[0]), 4) for x in allr], "launch_ms": [round(float(x[1]), 4) for x in allr],
+                    "backend": dist.get_backend(), "world_size": dist.get_world_size()}
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -948,6 +954,9 @@ def main():
             res["cpu_baseline"]["parity_checked"] = gate is not None
         else:
             res["cpu_baseline"] = None
+        if per_rank:
+            per_rank["ms_per_step_min"] = min(per_rank["ms_per_step"]); per_rank["ms_per_step_max"] = max(per_rank["ms_per_step"])
+            res["per_rank"] = per_rank
         if scatter:
             res["scatter"] = scatter
         print(json.dumps(res))

@@ -212,9 +212,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	const int al = (int)(((uintptr_t)out_base >> 1) & 7);
 	int flush_n = 0, flush_kb = 0;
 	auto flush = [&]() {
-		if (flush_n <= 0 || (RTLFM_ABLATE & 2)) return;
+		if (flush_n <= 0) return;
 		const int a = (al + flush_kb) & 7, last = a + flush_n;
-		int16_t *g16 = out_base + ((ptrdiff_t)((RTLFM_ABLATE & 8) ? (flush_kb & 7) : flush_kb) - a);  // & 8: analysis build, every tile to the same lines
+		int16_t *g16 = out_base + ((ptrdiff_t)flush_kb - a);
 		typedef uint4 __attribute__((may_alias)) u128_alias;  // the PCM is written as uint16
 		const u128_alias *pcm128 = reinterpret_cast<const u128_alias *>(lds + pcm_at);
 		const int j0 = (a + 7) >> 3, j1 = last >> 3;
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			return Pv;
 		};
-		const int R = (RTLFM_ABLATE & 4) ? 0 : p.R;
+		const int R = p.R;
 		const int e0 = lane * R;
 		uint32_t prevP, b;
 		{
@@ -324,8 +324,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				const int cr = fused::dot2_first(z, b);
 				const int cj = fused::dot2_first(z, bx);
 				int v;
-				if (RTLFM_ABLATE & 1) v = cj ^ cr;  // analysis builds only (tools/ablate.sh)
-				else if (V == 0 && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
+				if (V == 0 && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
 				else if (V == 1 || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
 				else if (V == 2) v = fast_atan2_q14(cj, cr);
 				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);

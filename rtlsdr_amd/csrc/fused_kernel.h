@@ -76,15 +76,22 @@ __device__ __forceinline__ uint32_t tap_pk16(uint32_t a, uint32_t b, uint32_t c,
 	return as_u32(s);
 }
 
-// the same with 32-bit lanes and the int16 store wrap
+// The same for inputs beyond the 16-bit form's range (32 |x| >= 2^15), up to |x| <= 8192 - every
+// pass this kernel runs, with or without the raw DC block (|x| <= 256 * 2^p, p <= 5): the three pair
+// sums a + f, b + e, c + d still fit 16-bit lanes (one v_pk_add_i16 each), and
+// sum = (a + f) + 5 (b + e) + 10 (c + d) is one v_dot2_i32_i16 per component with the taps (5, 10) and
+// the sign-extended a + f as the accumulator: 12 instructions instead of 26 (12 sign extensions, two
+// multiply-add chains).  ">> 4" in 32 bits, the store keeps the low 16 bits as the reference's int16 does.
 __device__ __forceinline__ uint32_t tap_i32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e,
                                             uint32_t f)
 {
-	iq16 A = unpack_iq(a), B = unpack_iq(b), C = unpack_iq(c), D = unpack_iq(d), E = unpack_iq(e),
-	     F = unpack_iq(f);
-	int yi = fifth_tap(A.i, B.i, C.i, D.i, E.i, F.i);
-	int yq = fifth_tap(A.q, B.q, C.q, D.q, E.q, F.q);
-	return pack_iq((int16_t)yi, (int16_t)yq);
+	const uint32_t s1 = as_u32(as_s2(a) + as_s2(f)), s5 = as_u32(as_s2(b) + as_s2(e)), s10 = as_u32(as_s2(c) + as_s2(d));
+	const short2_t taps = {(short)5, (short)10};
+	const uint32_t pi = __builtin_amdgcn_perm(s10, s5, 0x05040100u);  // (s5.I, s10.I)
+	const uint32_t pq = __builtin_amdgcn_perm(s10, s5, 0x07060302u);  // (s5.Q, s10.Q)
+	const int yi = __builtin_amdgcn_sdot2(as_s2(pi), taps, (int)(int16_t)(s1 & 0xffffu), false) >> 4;
+	const int yq = __builtin_amdgcn_sdot2(as_s2(pq), taps, (int)s1 >> 16, false) >> 4;
+	return __builtin_amdgcn_perm((uint32_t)yq, (uint32_t)yi, 0x05040100u);
 }
 
 // Pass 0 constants.  S_j = raw dword j (I_2j, Q_2j, I_2j+1, Q_2j+1) XOR 0x7f7f7f7f:
@@ -179,15 +186,24 @@ __device__ __forceinline__ uint4 load_stream16(const uint8_t *p)
 // Inline assembly, so the compiler's vmcnt bookkeeping does not see these stores: they are always
 // issued BEFORE the next tile's loads, and an older operation only makes an in-order vmcnt wait
 // wait for more, never for less.
+#ifndef RTLFM_PCM_STORE_POLICY
+#define RTLFM_PCM_STORE_POLICY 1  // 1 = sc1 (inline assembly), 0 = plain compiler-tracked stores, 2 = nt, 3 = sc1 without the memory clobber
+#endif
 __device__ __forceinline__ void store_out8(void *p, uint32_t a, uint32_t b)
 {
 	typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 	const u32x2_t v = {a, b};
-	asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+	if (RTLFM_PCM_STORE_POLICY == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+	else if (RTLFM_PCM_STORE_POLICY == 3) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v));
+	else if (RTLFM_PCM_STORE_POLICY == 2) __builtin_nontemporal_store(v, reinterpret_cast<u32x2_t *>(p));
+	else *reinterpret_cast<u32x2_t *>(p) = v;
 }
 __device__ __forceinline__ void store_out4(void *p, uint32_t a)
 {
-	asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(a) : "memory");
+	if (RTLFM_PCM_STORE_POLICY == 1) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(a) : "memory");
+	else if (RTLFM_PCM_STORE_POLICY == 3) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(a));
+	else if (RTLFM_PCM_STORE_POLICY == 2) __builtin_nontemporal_store(a, reinterpret_cast<uint32_t *>(p));
+	else *reinterpret_cast<uint32_t *>(p) = a;
 }
 
 // dot4 / dot2 with a zero accumulator in the VOP3 form (inline constant 0):
@@ -271,13 +287,21 @@ struct Lds {
 	// With the MFMA engine they live inside the chunk area, which is idle between pass 0's
 	// read-back and the next tile's staging (one wave's LDS queue is in order).
 	static constexpr int tr = MFMA0 ? 32 + 64 : 32;
-	static constexpr int after = MFMA0 ? 32 + 4 * 513 : 32 + 65 * tr_w;
+	// The body of a linear ring (ring_exchange: 64 * C values of one tile, C <= 4) is transient as well and
+	// shares one region behind the hand-off slots; only a ring's 16-entry prefix - the previous tile's tail -
+	// lives from tile to tile.  (With the bodies persistent the 6-pass kernel needed 10.5 KB per wave: 15
+	// waves per CU instead of 16.)
+	static constexpr int ring_body = ((tr + 65 * tr_w + 3) & ~3) + kPre;  // kPre entries in front of it: the prefix's transient copy
+	static constexpr int fz_c = (FIR9 && !fz_slots) ? cz : 0;     // values per lane in the FIR input ring
+	static constexpr int ring_c = (P >= 5 ? 4 : 0) > fz_c ? (P >= 5 ? 4 : 0) : fz_c;  // the widest ring of this instantiation
+	static constexpr int after = MFMA0 ? 32 + 4 * 513 : ring_body + 64 * ring_c;
+	static_assert(!MFMA0 || ring_body + 64 * ring_c <= 32 + 4 * 513, "the ring body must fit the chunk area");
 	static constexpr int atan = (after + 1) & ~1;                 // 17 doubles
 	static constexpr int c_fz = atan + 34;                        // [9]
-	static constexpr int y3 = c_fz + ((FIR9 && fz_slots) ? 9 : 0);  // Y3 ring, c=4 (P >= 5)
-	static constexpr int y4 = y3 + (P >= 5 ? kPre + 64 * 4 : 0);  // Y4 ring, c=2 (P >= 6)
-	static constexpr int fz = y4 + (P >= 6 ? kPre + 64 * 2 : 0);  // FIR input ring (!fz_slots)
-	static constexpr int fz_size = (FIR9 && !fz_slots) ? kPre + 64 * cz : 0;
+	static constexpr int y3 = c_fz + ((FIR9 && fz_slots) ? 9 : 0);  // prefix of the Y3 ring, c=4 (P >= 5)
+	static constexpr int y4 = y3 + (P >= 5 ? kPre : 0);           // prefix of the Y4 ring, c=2 (P >= 6)
+	static constexpr int fz = y4 + (P >= 6 ? kPre : 0);           // prefix of the FIR input ring (!fz_slots)
+	static constexpr int fz_size = (FIR9 && !fz_slots) ? kPre : 0;
 	static constexpr int total = fz + fz_size;
 };
 
@@ -297,21 +321,9 @@ __device__ __forceinline__ void hand_off(uint32_t *slots, const uint32_t *cr, co
 	for (int k = 0; k < W; k++) prev[k] = rp[k];
 	__builtin_amdgcn_wave_barrier();
 }
-#if RTLFM_ABLATE & 8
-#define hand_off hand_off_ablated
-template <int W>
-__device__ __forceinline__ void hand_off_ablated(uint32_t *, const uint32_t *, const uint32_t (&mine)[W], uint32_t (&prev)[W], int)
-{
-#pragma unroll
-	for (int k = 0; k < W; k++) prev[k] = mine[k] ^ 1u;
-}
-#endif
 template <int W>
 __device__ __forceinline__ void leave_carry(uint32_t *cr, const uint32_t (&carry)[W], int lane)
 {
-#if RTLFM_ABLATE & 8
-	return;
-#endif
 	if (lane == 63) {
 #pragma unroll
 		for (int k = 0; k < W; k++) cr[k] = carry[k];
@@ -337,22 +349,27 @@ __device__ __forceinline__ void fifth_history(uint32_t *slots, uint32_t *cr, con
 	}
 }
 
-// linear ring: write this tile's C values per lane, read H entries before the
-// lane's first, then move the tile's tail into the prefix for the next tile.
+// linear ring: this tile's C values per lane go into the transient body, every lane reads the H entries
+// before its first - from the body, or, for positions before the tile, from the ring's prefix (the last
+// kPre entries of the previous tile) - and then the lanes that hold the tile's last kPre entries leave
+// them in the prefix, straight from their registers.  Two barriers.
 // QUIRK: at a buffer start the entries that lie before the buffer are read one
 // position further back (see fifth_history); with fewer than five values per
 // lane that reaches lanes 1 and 2 as well, so it is applied per position.
 template <int C, int H, bool QUIRK>
-__device__ __forceinline__ void ring_exchange(uint32_t *ring, const uint32_t (&mine)[C], uint32_t (&hist)[H],
+__device__ __forceinline__ void ring_exchange(uint32_t *lds, int prefix, int body, const uint32_t (&mine)[C], uint32_t (&hist)[H],
                                               int lane, bool buffer_start)
 {
-#if RTLFM_ABLATE & 8
-#pragma unroll
-	for (int k = 0; k < H; k++) hist[k] = mine[k % C] ^ (uint32_t)k;
-	return;
-#endif
+	static_assert(kPre % C == 0 && H + 1 <= kPre, "the prefix holds whole lanes and reaches back far enough");
+	// the kept prefix goes in front of the transient body, so that every lane reads its history at
+	// one base address + constants (a per-position choice between two places cost a register per
+	// position and pushed the 6-pass kernels into spilling)
+	uint32_t *ring = lds + body - kPre;
+	uint32_t carried = 0;
+	if (lane < kPre) carried = lds[prefix + lane];
 #pragma unroll
 	for (int k = 0; k < C; k++) ring[kPre + lane * C + k] = mine[k];
+	if (lane < kPre) ring[lane] = carried;
 	__builtin_amdgcn_wave_barrier();
 #pragma unroll
 	for (int k = 0; k < H; k++) {
@@ -361,10 +378,10 @@ __device__ __forceinline__ void ring_exchange(uint32_t *ring, const uint32_t (&m
 		hist[k] = ring[kPre + pos];
 	}
 	__builtin_amdgcn_wave_barrier();
-	uint32_t t = 0;
-	if (lane < kPre) t = ring[64 * C + lane];
-	__builtin_amdgcn_wave_barrier();
-	if (lane < kPre) ring[lane] = t;
+	if (lane >= 64 - kPre / C) {
+#pragma unroll
+		for (int k = 0; k < C; k++) lds[prefix + (lane - (64 - kPre / C)) * C + k] = mine[k];
+	}
 	__builtin_amdgcn_wave_barrier();
 }
 
@@ -411,12 +428,6 @@ struct AtanNodesLds {
 #endif
 #ifndef RTLFM_PASS0_DEFAULT
 #define RTLFM_PASS0_DEFAULT 1  // 0: always v_dot4 on the VALU, 1: int8 MFMA where it is faster (RTLFM_PASS0=valu|mfma overrides)
-#endif
-// Analysis builds only (tools/ablate.sh): leave parts of the tile out to see what they cost
-// under the real power/clock conditions.  1 = no atan2, 2 = no passes 1.., 4 = no MFMA
-// phase (MFMA engine), 8 = hand-offs return zeros.  Results are wrong by construction.
-#ifndef RTLFM_ABLATE
-#define RTLFM_ABLATE 0
 #endif
 // Where the MFMA variant issues the next tile's loads: 0 = after the MFMA phase, 1 = after
 // pass 0's read-back and the deferred PCM store, 2 = after pass 1 (P >= 2 only).
@@ -550,8 +561,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	int16_t held[CZ];
 	int16_t *held_dst = nullptr;
 	auto flush_held = [&]() {
-		if (held_dst && !(RTLFM_ABLATE & 16)) {
-			int16_t *dst = (RTLFM_ABLATE & 32) ? out_base + lane * CZ : held_dst;  // analysis builds (tools/ablate.sh): no stores / every tile to the same lines
+		if (held_dst) {
+			int16_t *dst = held_dst;
 			if constexpr (CZ >= 8) {
 				// 1-3 passes: the PCM is 12-50 % of the bytes, and written through it costs (P = 2: +16 %)
 				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
@@ -628,14 +639,6 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				}
 			}
 			__builtin_amdgcn_wave_barrier();
-#if RTLFM_ABLATE & 4
-#pragma unroll
-			for (int k = 0; k < 8; k++) {
-				Y0[4 * k] = cur[k].x ^ 0x7f7f7f7fu; Y0[4 * k + 1] = cur[k].y ^ 0x7f7f7f7fu;
-				Y0[4 * k + 2] = cur[k].z ^ 0x7f7f7f7fu; Y0[4 * k + 3] = cur[k].w ^ 0x7f7f7f7fu;
-			}
-			reload(gt, more);
-#else
 			// stage S = raw ^ 0x7f7f7f7f as chunks 0..511 (chunk -1 is still the previous tile's 511)
 			uint4 *chunks = reinterpret_cast<uint4 *>(lds + L::rawbuf + 4);
 			uint4 last;
@@ -715,7 +718,6 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				Y0[4 * k] = v.x; Y0[4 * k + 1] = v.y; Y0[4 * k + 2] = v.z; Y0[4 * k + 3] = v.w;
 			}
 			__builtin_amdgcn_wave_barrier();
-#endif
 			if (bs && lane == 0) { Y0[0] = fix0; Y0[1] = fix1; Y0[2] = fix2; }
 		} else
 		{
@@ -817,13 +819,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		RTLFM_MARK("pass0_special_done");
 		// ------------------------------------------------------------ passes 1.. ----
 		uint32_t Z[CZ];  // output of the last pass
-		if constexpr ((RTLFM_ABLATE & 2) != 0) {
-			uint32_t x = 0;
-#pragma unroll
-			for (int k = CZ; k < 32; k++) x ^= Y0[k];
-#pragma unroll
-			for (int k = 0; k < CZ; k++) Z[k] = Y0[k] ^ x;
-		} else if constexpr (P == 1) {
+		if constexpr (P == 1) {
 #pragma unroll
 			for (int k = 0; k < 32; k++) Z[k] = Y0[k];
 		} else {
@@ -857,14 +853,14 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 						for (int k = 0; k < 4; k++) Z[k] = Y3[k];
 					} else {
 						uint32_t Y4[2];
-						ring_exchange<4, 5, true>(lds + L::y3, Y3, h5, lane, bs);
+						ring_exchange<4, 5, true>(lds, L::y3, L::ring_body, Y3, h5, lane, bs);
 						fifth_lane<4, false>(Y3, h5, Y4);
 						archive_ring(L::y3, 4);
 						if constexpr (P == 5) {
 							Z[0] = Y4[0]; Z[1] = Y4[1];
 						} else {
 							uint32_t Y5[1];
-							ring_exchange<2, 5, true>(lds + L::y4, Y4, h5, lane, bs);
+							ring_exchange<2, 5, true>(lds, L::y4, L::ring_body, Y4, h5, lane, bs);
 							fifth_lane<2, false>(Y4, h5, Y5);
 							archive_ring(L::y4, 5);
 							Z[0] = Y5[0];
@@ -890,7 +886,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(mine[j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
 			} else {
-				ring_exchange<CZ, 9, false>(lds + L::fz, Z, h9, lane, false);
+				ring_exchange<CZ, 9, false>(lds, L::fz, L::ring_body, Z, h9, lane, false);
 				if (archive) {
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(lds[L::fz + kPre - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
@@ -958,9 +954,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			const int cr = dot2_first(c, b);
 			const int cj = dot2_first(c, bx);
 			int v;
-			if (RTLFM_ABLATE & 1) {
-				v = cj ^ cr;
-			} else if (STD) {
+			if (STD) {
 				v = atan2_q14(cj, cr, nodes);
 			} else {
 				if (p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, c, p.output_scale);

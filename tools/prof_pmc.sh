@@ -12,7 +12,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0 --ceiling 0 --also 0 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
+  # --pmc-child: the input is one random fill instead of the signal generator's thousands of small dispatches
+  # (rocprofv3's counter mode stalls on those at 4096 streams: 25 GPU-minutes were lost finding out), no build,
+  # no child processes; the outer timeout bounds a pass that stalls anyway
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --pmc-child --steps 3 --warmup 1 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0 --ceiling 0 --also 0 --colocate 1 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
 }
 BENCH_ARGS=("$@")
 run sqA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
