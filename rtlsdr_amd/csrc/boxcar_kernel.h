@@ -314,6 +314,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			b = e0 > 0 ? pk_sub16(a1, e0 > 1 ? a2 : edgeP) : last_out;
 		}
 		uint32_t curP = P_at(e0);
+		// (The per-lane `if`s below are cheaper than they look: a branch-free form - outputs past Et computed
+		// and dumped, the last output's boundary kept in registers - measured 8-13 % SLOWER.)
 		for (int r = 0; r < R; r++) {
 			const int e = e0 + r;
 			const uint32_t nxtP = P_at(e + 1);
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				const int cj = fused::dot2_first(z, bx);
 				int v;
 				if (V == 0 && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
-				else if (V == 1 || (bs && e == 0)) v = atan2_q14(cj, cr, nodes);
+				else if (V == 1) v = atan2_q14(cj, cr, nodes);
 				else if (V == 2) v = fast_atan2_q14(cj, cr);
 				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
@@ -336,6 +338,17 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				}
 			}
 			prevP = curP; b = z; curP = nxtP;
+		}
+		if (V != 1 && bs && (V != 0 || p.mode == RTLFM_MODE_FM) && Et > 0) {
+			// fm_demod's first sample of a buffer is always polar_discriminant, whatever -A says
+			// (src/rtl_fm.c:935-937): redone here, once per buffer, instead of as a second discriminator
+			// under a per-lane condition inside the output loop (where it cost every output of a -A fast
+			// run the std path's instructions as well)
+			const uint32_t z0 = pk_sub16(P_at(0), edgeP), b0 = last_out;
+			const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
+			const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
+			const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
+			if (lane == 0) pcm[(al + kb) & 7] = (uint16_t)(int16_t)v0;
 		}
 		__builtin_amdgcn_wave_barrier();
 		const uint32_t Plast = lds[ScanLds::scratch];

@@ -30,12 +30,12 @@ for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--box
   if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $tag "; then continue; fi
   cd $ROOT
   case $tag in
-    c2) python bench.py > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
-    box*) python bench.py $args --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
-    *) python bench.py $args --steps 100 --warmup 50 --cpu-seconds 6 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+    c2) timeout 400 python bench.py > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+    box*) timeout 300 python bench.py $args --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+    *) timeout 400 python bench.py $args --steps 100 --warmup 50 --cpu-seconds 6 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
   esac
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 $ROOT/bench.py $COMMON $args > $OUT/trace_$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python3 $ROOT/bench.py $COMMON $args > $OUT/trace_$tag.log 2>&1
   f=$(find $OUT/trace_$tag -name "*kernel_stats.csv" | head -1)
   top "$f" "rocprofv3 --kernel-trace --stats -- python3 bench.py $COMMON $args" > $OUT/kernel_stats_$tag.txt
   rm -rf $OUT/trace_$tag $OUT/trace_$tag.log
