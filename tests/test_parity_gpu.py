@@ -331,6 +331,31 @@ def test_raw_dc_block_on_the_fused_path(oracle_lib, passes, fir9, atan, offs):
         assert np.array_equal(so[s_], outs[s_])
 
 
+@pytest.mark.parametrize("L", [24576, 40960, 8192 * 7])
+@pytest.mark.parametrize("front", ["p4", "p4rdc", "p5fir", "box10"])
+def test_buffer_sizes_that_are_not_powers_of_two(oracle_lib, front, L):
+    """-W n gives buffers of 512 n bytes (src/rtl_fm.c:1869-1873): every multiple of 8192 - 24576, 40960, 57344
+    here: three, five, seven tiles per buffer - takes the one-launch front end (`last_path == 2`), with and
+    without the raw DC block, runs split over launches and segments that cut the buffers anywhere."""
+    if front.startswith("box"):
+        ov = dict(downsample=10, downsample_passes=0)
+    else:
+        passes = int(front[1])
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if "fir" in front else 0,
+                  dc_block_raw=1 if "rdc" in front else 0)
+    nb, ns = 4, 6
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=L + len(front), fs=2.4e6, dev_hz=75e3)
+    iq[ns - 1] = synth.random_u8(1, L * nb, seed=L)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits, opts in ((None, None), ([(0, 1), (1, 4)], dict(fused_tiles_per_seg=2)), (None, dict(fused_waves=1))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        assert used == 2
+        for s_ in range(ns):
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"{front} L={L} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
+
+
 def test_options_by_name():
     """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
     from rtlsdr_amd.demod import GpuDemod
