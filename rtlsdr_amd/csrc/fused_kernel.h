@@ -426,6 +426,14 @@ struct AtanNodesLds {
 #ifndef RTLFM_FUSED_WAVES_PER_SIMD
 #define RTLFM_FUSED_WAVES_PER_SIMD 4
 #endif
+// The 4- and 5-pass polar_discriminant kernels with the MFMA pass 0 fit 96 VGPRs without a spill (see the
+// note on the lane index in the MFMA phase), i.e. five waves per SIMD by registers and 19 per CU by LDS.
+// Measured with the wave count matched to the 4864 slots (tools/ab_engines.py --waves): no faster than four
+// (0.823-0.835 vs 0.822 ms at /16, 0.803-0.820 vs 0.796 at /32), so four it stays; -DRTLFM_FUSED_WAVES_STD45=5
+// builds the other.
+#ifndef RTLFM_FUSED_WAVES_STD45
+#define RTLFM_FUSED_WAVES_STD45 4
+#endif
 #ifndef RTLFM_PASS0_DEFAULT
 #define RTLFM_PASS0_DEFAULT 1  // 0: always v_dot4 on the VALU, 1: int8 MFMA where it is faster (RTLFM_PASS0=valu|mfma overrides)
 #endif
@@ -449,7 +457,7 @@ struct AtanNodesLds {
 // rotation), and -16 C is what the MFMA accumulators start from instead of zero.  No instruction is
 // added to the tile; samples now span +-255, so pass 3 takes the 32-bit form as it does without rotation.
 template <int P, bool FIR9, bool STD, bool MFMA0, bool RDC = false>
-__global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
+__global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : (STD && MFMA0 && !RDC && (P == 4 || P == 5)) ? RTLFM_FUSED_WAVES_STD45 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
 {
 	static_assert(!RDC || MFMA0, "the raw DC block rides on the MFMA accumulators");
 	using L = Lds<P, FIR9, MFMA0>;
@@ -652,7 +660,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			__builtin_amdgcn_wave_barrier();
 			// 16 segments of 128 outputs: lane (n = l&15, q = l>>4) feeds window n's bytes
 			// 16q..16q+15 = chunk 32s + 2n + q - 1 and receives outputs 128s + 8n + 2q + {0,1}
-			const int n = lane & 15, q = lane >> 4;
+			// (the lane index goes through an empty asm here and once more below: the half-dozen LDS addresses
+			// derived from it are loop-invariant, the compiler keeps each in a register across the whole tile,
+			// and recomputing them - a few VALU operations per tile - brings the kernel from 113 to 97 VGPRs
+			// (96 and no spill under a five-waves bound; see RTLFM_FUSED_WAVES_STD45))
+			int ln = lane;
+			asm volatile("" : "+v"(ln));
+			const int n = ln & 15, q = ln >> 4;
 			const uint4 *rd = chunks + (2 * n + q - 1);
 			// Outputs go back in place, but the eight 16-byte slots of each lane's later
 			// 128-byte run (run L = m >> 5) are stored XOR-swizzled, slot k at k ^ ((L >> 1) & 7):
@@ -711,7 +725,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			// the MFMA phase no longer needs the register file for operands and accumulators
 			if (RTLFM_MFMA_RELOAD_AT == 0) reload(gt, more);
 			// back to the lane-contiguous form the later passes use
-			const uint32_t yl0 = 4u * (uint32_t)(L::rawbuf + 4) + 128u * lane + 16u * ((lane >> 1) & 7);
+			const uint32_t yl0 = 4u * (uint32_t)(L::rawbuf + 4) + 128u * ln + 16u * ((ln >> 1) & 7);
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
 				const uint4 v = *reinterpret_cast<const uint4 *>(lds_b + (yl0 ^ (16u * k)));
@@ -816,6 +830,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			}
 		};
 
+		int lz = lane;
+		asm volatile("" : "+v"(lz));  // see the MFMA phase: hand-off addresses recomputed, not carried
 		RTLFM_MARK("pass0_special_done");
 		// ------------------------------------------------------------ passes 1.. ----
 		uint32_t Z[CZ];  // output of the last pass
@@ -825,7 +841,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		} else {
 			uint32_t h5[5];
 			uint32_t Y1[16];
-			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lane, next_bs);
+			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lz, next_bs);
 			fifth_lane<32, true>(Y0, h5, Y1);
 			archive_regs(Y0, std::integral_constant<int, 32>(), 1);
 			if (MFMA0 && RTLFM_MFMA_RELOAD_AT == 2) reload(gt, more);
@@ -834,7 +850,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
 			} else {
 				uint32_t Y2[8];
-				fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lane, next_bs);
+				fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lz, next_bs);
 				fifth_lane<16, true>(Y1, h5, Y2);
 				archive_regs(Y1, std::integral_constant<int, 16>(), 2);
 				if constexpr (P == 3) {
@@ -842,7 +858,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					for (int k = 0; k < 8; k++) Z[k] = Y2[k];
 				} else {
 					uint32_t Y3[4];
-					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lane, next_bs);
+					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lz, next_bs);
 					// with rotation |x| <= 1023 here, so the 16-bit form cannot overflow;
 					// without it an all-255 input reaches exactly 2^15
 					if (rotate && !RDC) fifth_lane<8, true>(Y2, h5, Y3);
@@ -853,14 +869,14 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 						for (int k = 0; k < 4; k++) Z[k] = Y3[k];
 					} else {
 						uint32_t Y4[2];
-						ring_exchange<4, 5, true>(lds, L::y3, L::ring_body, Y3, h5, lane, bs);
+						ring_exchange<4, 5, true>(lds, L::y3, L::ring_body, Y3, h5, lz, bs);
 						fifth_lane<4, false>(Y3, h5, Y4);
 						archive_ring(L::y3, 4);
 						if constexpr (P == 5) {
 							Z[0] = Y4[0]; Z[1] = Y4[1];
 						} else {
 							uint32_t Y5[1];
-							ring_exchange<2, 5, true>(lds, L::y4, L::ring_body, Y4, h5, lane, bs);
+							ring_exchange<2, 5, true>(lds, L::y4, L::ring_body, Y4, h5, lz, bs);
 							fifth_lane<2, false>(Y4, h5, Y5);
 							archive_ring(L::y4, 5);
 							Z[0] = Y5[0];
@@ -879,14 +895,14 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				uint32_t mine[9];
 #pragma unroll
 				for (int k = 0; k < 9; k++) mine[k] = Z[CZ - 9 + k];
-				hand_off<9>(lds + L::tr, lds + L::c_fz, mine, h9, lane);
+				hand_off<9>(lds + L::tr, lds + L::c_fz, mine, h9, lz);
 				leave_carry<9>(lds + L::c_fz, mine, lane);
 				if (archive) {
 #pragma unroll
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(mine[j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
 			} else {
-				ring_exchange<CZ, 9, false>(lds, L::fz, L::ring_body, Z, h9, lane, false);
+				ring_exchange<CZ, 9, false>(lds, L::fz, L::ring_body, Z, h9, lz, false);
 				if (archive) {
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(lds[L::fz + kPre - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
@@ -934,7 +950,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		uint32_t pv;
 		{
 			uint32_t mine[1] = {V[CZ - 1]}, prev[1];
-			hand_off<1>(lds + L::tr, lds + L::c_zd, mine, prev, lane);
+			hand_off<1>(lds + L::tr, lds + L::c_zd, mine, prev, lz);
 			leave_carry<1>(lds + L::c_zd, mine, lane);
 			pv = prev[0];
 			if (archive) {

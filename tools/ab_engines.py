@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=60)
     ap.add_argument("--burst", type=int, default=5, help="launches per engine per round")
     ap.add_argument("--paths", type=int, nargs="+", default=[3, 4])
+    ap.add_argument("--waves", type=int, nargs="+", default=None, help="fused_waves per entry of --paths")
     ap.add_argument("--libs", nargs="+", default=None,
                     help="one library build per entry of --paths (default: the in-tree build for all)")
     a = ap.parse_args()
@@ -52,6 +53,8 @@ def main():
     for path, lib in zip(a.paths, libs):
         g = GpuDemod(cfg, S, 0, lib_path=lib and os.path.abspath(lib))
         g.set_path(path)
+        if a.waves:
+            g.set_option("fused_waves", a.waves[len(hs)])
         hs.append(g)
     cap = hs[0].result_cap(NB)
     # the output a quarter of the HBM away from the input, as bench.py places it (rtlfm_gpu_malloc_apart)
