@@ -385,7 +385,8 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
                    "pinned_h2d_GB/s": h2d, "frac_of_pinned_h2d": round(res["GB/s_in"] / h2d, 3), "harness": "native",
                    "what": f"{S} streams x 1 buffer x {L} B per run, {res['runs']} pipelined runs in {res['seconds']:.2f} s: {nthreads} "
                            f"native threads rtlfm_gpu_push (pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | "
-                           f"rtlfm_gpu_fetch_all; bounded by the host memcpy into the ring and PCIe, not by the kernels"}
+                           f"rtlfm_gpu_fetch_all_prev (two runs in flight: run k + 1 is started before the audio of run k is "
+                           f"collected, so the H2D copies follow each other on the link); bounded by PCIe, not by the kernels"}
             za = run_native(cfg, S, "acquire", seconds)
             if za:
                 out["zero_copy"] = {"GB/s_in": za["GB/s_in"], "value": za["Msamples/s"], "frac_of_pinned_h2d": round(za["GB/s_in"] / h2d, 3),

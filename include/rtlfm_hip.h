@@ -217,6 +217,10 @@ int rtlfm_gpu_fetch(rtlfm_gpu *h, int stream, int16_t *out, int cap, int *n);
 /* The same for all streams at once: stream s gets lens[s] samples at out + s * out_stride (int16
  * elements; rtlfm_result_cap() * max_blocks is always enough).  One device-to-host transfer. */
 int rtlfm_gpu_fetch_all(rtlfm_gpu *h, int16_t *out, size_t out_stride, int32_t *lens);
+/* The same for the run BEFORE the last one (-EAGAIN until there have been two).  Waits for that run only,
+ * not for the one started since: run(k + 1) as soon as its buffers are in, then fetch_all_prev() for run k,
+ * keeps consecutive runs' H2D copies back to back on the link. */
+int rtlfm_gpu_fetch_all_prev(rtlfm_gpu *h, int16_t *out, size_t out_stride, int32_t *lens);
 
 /*
  * rms() of the decimated IQ (`sr` in full_demod(), src/rtl_fm.c:1204-1237) of every buffer of the

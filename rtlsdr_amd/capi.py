@@ -178,6 +178,7 @@ _SIGNATURES = [
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rtlfm_gpu_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, _P(C.c_int)]),
     ("rtlfm_gpu_fetch_all", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rtlfm_gpu_fetch_all_prev", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rtlfm_gpu_levels", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, _P(C.c_int)]),
     ("rtlfm_gpu_state_get", C.c_int, [C.c_void_p, C.c_int, _P(RtlfmStreamState)]),
     ("rtlfm_gpu_state_set", C.c_int, [C.c_void_p, C.c_int, _P(RtlfmStreamState)]),

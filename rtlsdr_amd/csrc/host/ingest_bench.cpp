@@ -15,7 +15,7 @@
 // bench.py's `e2e` leg starts this program.  Prints one JSON line: aggregate and per-device rates.
 //
 //   ingest_bench <cfg file: the bytes of a rtlfm_cfg> <streams per device> <threads per device> <seconds>
-//                [--devices 0,1,...] [--mode push|acquire] [--pin 0|1]
+//                [--devices 0,1,...] [--mode push|acquire] [--pin 0|1] [--depth 1|2]
 //   (a bare fifth argument is still taken as the one device to use)
 #include <pthread.h>
 #include <sched.h>
@@ -94,6 +94,7 @@ int main(int argc, char **argv)
 	const double seconds = atof(argv[4]);
 	std::vector<int> ids;
 	bool acquire = false, pin = true;
+	int depth = 2;  // 1: run / fetch / run; 2: run(k + 1) before the results of run k are collected (rtlfm_gpu_fetch_all_prev)
 	for (int i = 5; i < argc; i++) {
 		const std::string a = argv[i];
 		if (a == "--devices" && i + 1 < argc) {
@@ -103,6 +104,8 @@ int main(int argc, char **argv)
 			acquire = !strcmp(argv[++i], "acquire");
 		} else if (a == "--pin" && i + 1 < argc) {
 			pin = atoi(argv[++i]) != 0;
+		} else if (a == "--depth" && i + 1 < argc) {
+			depth = atoi(argv[++i]) >= 2 ? 2 : 1;
 		} else if (i == 5 && a[0] != '-') {
 			ids.push_back(atoi(argv[i]));
 		}
@@ -173,10 +176,16 @@ int main(int argc, char **argv)
 			rtlfm_gpu_fetch_all(h, out.data(), (size_t)cap, lens.data());  // warm: ring, mirrors, clocks
 			start.arrive_and_wait();                                        // all devices begin together
 			const auto t0 = std::chrono::steady_clock::now();
+			if (depth == 2) {
+				// two runs in flight: one more run so that there is a "run before the last"
+				if ((r = rtlfm_gpu_run(h)) < 0) d->err = r;
+				push_all(); pushed();
+			}
 			while (!d->err) {
-				if ((r = rtlfm_gpu_run(h)) < 0) { d->err = r; break; }        // run k in flight ...
+				if ((r = rtlfm_gpu_run(h)) < 0) { d->err = r; break; }        // run k (depth 2: k + 1) in flight ...
 				push_all();                                                    // ... the producers fill the other half ...
-				r = rtlfm_gpu_fetch_all(h, out.data(), (size_t)cap, lens.data());  // ... and run k's audio comes back
+				r = depth == 2 ? rtlfm_gpu_fetch_all_prev(h, out.data(), (size_t)cap, lens.data())   // ... and the audio of run k
+				               : rtlfm_gpu_fetch_all(h, out.data(), (size_t)cap, lens.data());       //     comes back meanwhile
 				pushed();
 				if (r < 0 || err.load() < 0) { d->err = r < 0 ? r : err.load(); break; }
 				d->runs++;
@@ -209,8 +218,8 @@ int main(int argc, char **argv)
 	}
 	per += "]";
 	printf("{\"runs\": %ld, \"seconds\": %.3f, \"streams\": %d, \"threads\": %d, \"block_len\": %u, \"devices\": %zu, \"mode\": \"%s\", "
-	       "\"GB/s_in\": %.2f, \"Msamples/s\": %.1f, \"pcm_per_run\": %ld, \"per_device\": %s}\n",
-	       runs, tmax, S, T, L, devs.size(), acquire ? "acquire" : "push", agg_gbs, agg_ms, devs.empty() ? 0 : pcm / (long)devs.size(), per.c_str());
+	       "\"depth\": %d, \"GB/s_in\": %.2f, \"Msamples/s\": %.1f, \"pcm_per_run\": %ld, \"per_device\": %s}\n",
+	       runs, tmax, S, T, L, devs.size(), acquire ? "acquire" : "push", depth, agg_gbs, agg_ms, devs.empty() ? 0 : pcm / (long)devs.size(), per.c_str());
 	for (auto &d : devs) rtlfm_gpu_destroy(d->h);
 	return 0;
 }

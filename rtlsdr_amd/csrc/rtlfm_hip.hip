@@ -1286,6 +1286,9 @@ struct Ingest {
 	int32_t *d_result_len[2] = {nullptr, nullptr};
 	size_t ostride = 0;
 	int last = -1;                              // half of the last run
+	int prev = -1;                              // ... and of the run before it (rtlfm_gpu_fetch_all_prev)
+	int tail_par[2] = {0, 0};                   // per half: step parity of its run, and whether that run left an audio tail
+	bool tail_any[2] = {false, false};          // on the tail stream (ev_tail[parity])
 	int16_t *h_result = nullptr;                // pinned mirror of the last run's results (per-stream fetch)
 	int32_t *h_result_len = nullptr;
 	bool mirror_valid = false;
@@ -1375,6 +1378,7 @@ static void ingest_reset(rtlfm_gpu *h)
 		for (int s = 0; s < h->nstreams; s++) in->pushed[k][s].store(0);
 	for (int s = 0; s < h->nstreams; s++) in->open_slot[s].store(0);
 	in->last = -1;
+	in->prev = -1;
 	in->mirror_valid = false;
 }
 
@@ -1607,8 +1611,36 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 	if (r < 0) return r;
 	HIP_TRY(hipEventRecord(in->ev_run[f], h->stream));
 	in->run_pending[f] = true;
+	in->tail_par[f] = (int)((h->step - 1) & 1);
+	in->tail_any[f] = !ragged && h->tail_pending[in->tail_par[f]];
+	in->prev = in->last;
 	in->last = f;
 	in->mirror_valid = false;
+	return 0;
+}
+
+// Results of the run BEFORE the last one (they stay valid until the second run after theirs).  Waits for
+// that run only - its front end's event and, if it left one, its audio tail's - not for the run that has
+// been started since: a server that calls run(k + 1) as soon as the buffers of k + 1 are in and only then
+// collects run k keeps the H2D copies of consecutive runs back to back on the link (host/ingest_bench.cpp
+// --depth 2), where run / fetch / run leaves it idle for a kernel and a D2H copy per run.
+extern "C" int rtlfm_gpu_fetch_all_prev(rtlfm_gpu *h, int16_t *out, size_t out_stride, int32_t *lens)
+{
+	if (!h || !out || !lens) return -EINVAL;
+	Ingest *in = h->ing;
+	if (!in || in->prev < 0 || in->prev == in->last) return -EAGAIN;
+	HIP_TRY(hipSetDevice(h->device));
+	const int f = in->prev;
+	HIP_TRY(hipEventSynchronize(in->ev_run[f]));
+	if (in->tail_any[f]) HIP_TRY(hipEventSynchronize(h->ev_tail[in->tail_par[f]]));
+	const int S = h->nstreams;
+	HIP_TRY(hipMemcpy(lens, in->d_result_len[f], (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost));
+	int mx = 0;
+	for (int s = 0; s < S; s++) mx = lens[s] > mx ? lens[s] : mx;
+	if ((size_t)mx > out_stride) return -ENOBUFS;
+	if (mx > 0)
+		HIP_TRY(hipMemcpy2D(out, out_stride * sizeof(int16_t), in->d_result[f], in->ostride * sizeof(int16_t),
+		                    (size_t)mx * sizeof(int16_t), S, hipMemcpyDeviceToHost));
 	return 0;
 }
 

@@ -77,6 +77,14 @@ class GpuDemod:
         check(self.lib.rtlfm_gpu_fetch_all(self._h, out.ctypes.data, cap, lens.ctypes.data), "rtlfm_gpu_fetch_all")
         return out, lens
 
+    def fetch_all_prev(self):
+        """The same for the run BEFORE the last one (rtlfm_gpu_fetch_all_prev): does not wait for the run started since."""
+        cap = capi.load().rtlfm_result_cap(C.byref(self.cfg)) * max(1, self.cfg.max_blocks) + 16
+        out = np.empty((self.nstreams, cap), dtype=np.int16)
+        lens = np.zeros(self.nstreams, dtype=np.int32)
+        check(self.lib.rtlfm_gpu_fetch_all_prev(self._h, out.ctypes.data, cap, lens.ctypes.data), "rtlfm_gpu_fetch_all_prev")
+        return out, lens
+
     # -- device-resident form ------------------------------------------------
     def result_cap(self, nblocks: int) -> int:
         c = self.lib.rtlfm_result_cap(C.byref(self.cfg)) * nblocks + 16

@@ -1032,6 +1032,42 @@ def test_tail_overlap_is_deterministic_over_many_steps(oracle_lib, name):
             assert gu.state_dict(res[serial][1][s], False) == gu.state_dict(wst[s], False), (name, s, serial)
 
 
+@pytest.mark.parametrize("name", ["c2_p4_std", "wbfm_preset", "c3_p6_fir9_deemph_up22050"])
+def test_two_runs_in_flight_fetch_the_one_before(oracle_lib, name):
+    """rtlfm_gpu_fetch_all_prev: run(k + 1) is started as soon as its buffers are in, and only then the
+    results of run k are collected - they must be run k's (not disturbed by the run in flight, which
+    reuses the other half of every buffer pair), with and without an audio tail on the tail stream."""
+    from rtlsdr_amd.demod import GpuDemod
+    ov, sig = [(o, s) for n, o, s in CASES if n == name][0]
+    L, ns, depth, rounds = 16384, 32, 2, 7
+    cfg = make_cfg(ov, L, depth)
+    nb = rounds * depth
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=6161, **sig)
+    want, want_len, _ = oracle_lib.run_batch(make_cfg(ov, L, nb), iq, nthreads=4)
+    got = [[] for _ in range(ns)]
+    with GpuDemod(cfg, ns, 0) as g:
+        def push_round(r):
+            for b in range(r * depth, (r + 1) * depth):
+                for s in range(ns):
+                    g.rtlsdr_callback(iq[s, b * L:(b + 1) * L], s)
+        with pytest.raises(capi.RtlfmError):
+            g.fetch_all_prev()            # nothing has run yet
+        push_round(0); g.full_demod()
+        with pytest.raises(capi.RtlfmError):
+            g.fetch_all_prev()            # one run: there is no run before it
+        for r in range(1, rounds):
+            push_round(r)
+            g.full_demod()                # run r in flight ...
+            o, n = g.fetch_all_prev()     # ... the audio of run r - 1
+            for s in range(ns):
+                got[s].append(o[s, :n[s]].copy())
+        o, n = g.fetch_all()              # the last run
+        for s in range(ns):
+            got[s].append(o[s, :n[s]].copy())
+    for s in range(ns):
+        assert_parity(np.concatenate(got[s]), want[s, :want_len[s]], cfg, f"{name} stream {s}")
+
+
 def test_push_rejects_lengths_the_chain_cannot_take():
     """A short buffer is demodulated as a buffer of that length; a length the configured chain cannot
     take (here: 512 bytes through 10 fifth_order passes need a multiple of 2048) is refused by push()
