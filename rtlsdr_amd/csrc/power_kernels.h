@@ -71,13 +71,16 @@ __device__ __forceinline__ int element_at(const ScanParams &p, const uint8_t *ra
 typedef short pk16_t __attribute__((ext_vector_type(2)));
 
 // One butterfly of fix_fft (src/rtl_power.c:309-321) on packed (re, im) int16 pairs.
-//   FIX_MPY(a, b) = ((a*b >> 14) >> 1) + ((a*b >> 14) & 1) = (a*b + 2^14) >> 15   (exact identity)
+//   FIX_MPY(a, b) = ((a*b >> 14) >> 1) + ((a*b >> 14) & 1) = (a*b + 2^14) >> 15 = (a*2b + 2^15) >> 16  (exact)
 //   tr = FIX_MPY(wr, b.re) - FIX_MPY(wi, b.im), ti = FIX_MPY(wr, b.im) + FIX_MPY(wi, b.re)
 //   q  = a >> 1 (per component);  b' = q - t,  a' = q + t
 // Every int16 store of the reference wraps mod 2^16; so do the packed 16-bit adds here.
-// The four products take their 16-bit halves straight out of the packed twiddle w = (wr, wi) and the
-// packed point b = (re, im) - v_mad_i32_i16 with op_sel, the rounding constant 2^14 as its addend -, so
-// neither is unpacked: 14 instructions per butterfly instead of 18.
+// The twiddle table holds (2 wr, 2 wi) (both fit int16: wr, wi are the halved sines, -16384 .. 16383), so
+// every FIX_MPY is the HIGH HALF of one v_mad_i32_i16 - op_sel takes the 16-bit halves straight out of the
+// packed twiddle and the packed point, the rounding constant is the addend - and two v_perm gather the
+// four high halves into the packed pairs (m1, m3) and (m2, m4) without a single shift.  The one
+// subtraction, m1 - m2 = m1 + 1 + ~m2: the + 1 rides on m1's addend (2^15 + 2^16), the complement is one
+// xor of the low half.  11 instructions per butterfly (rounds 1-2: 18, round 3 before this: 14).
 __device__ __forceinline__ int mad_i16(uint32_t x, uint32_t y, int c, int xhi, int yhi)
 {
 	int r;
@@ -87,15 +90,44 @@ __device__ __forceinline__ int mad_i16(uint32_t x, uint32_t y, int c, int xhi, i
 	else asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(x), "v"(y), "s"(c));
 	return r;
 }
-__device__ __forceinline__ void butterfly(uint32_t &a, uint32_t &b, uint32_t w)
+// KIND: 0 = any twiddle; 1 = the twiddle is real (wi == 0: FIX_MPY(0, x) == 0, two products drop out);
+// 2 = it is imaginary (wr == 0).  The first three stages know which at compile time: positions 0 and N/4.
+template <int KIND = 0>
+__device__ __forceinline__ void butterfly(uint32_t &a, uint32_t &b, uint32_t w2)
 {
-	const int tr = (mad_i16(w, b, 16384, 0, 0) >> 15) - (mad_i16(w, b, 16384, 1, 1) >> 15);  // FIX_MPY(wr, b.re) - FIX_MPY(wi, b.im)
-	const int ti = (mad_i16(w, b, 16384, 0, 1) >> 15) + (mad_i16(w, b, 16384, 1, 0) >> 15);  // FIX_MPY(wr, b.im) + FIX_MPY(wi, b.re)
-	const uint32_t tt = __builtin_amdgcn_perm((uint32_t)ti, (uint32_t)tr, 0x05040100u);
+	typedef unsigned short upk16_t __attribute__((ext_vector_type(2)));
+	pk16_t tv;
+	if (KIND == 1) {
+		const uint32_t p1 = (uint32_t)mad_i16(w2, b, 32768, 0, 0);  // high half: FIX_MPY(wr, b.re)
+		const uint32_t p3 = (uint32_t)mad_i16(w2, b, 32768, 0, 1);  //            FIX_MPY(wr, b.im)
+		tv = __builtin_bit_cast(pk16_t, __builtin_amdgcn_perm(p3, p1, 0x07060302u));
+	} else {
+		const uint32_t p2 = (uint32_t)mad_i16(w2, b, 32768, 1, 1);  // FIX_MPY(wi, b.im)
+		const uint32_t p4 = (uint32_t)mad_i16(w2, b, 32768, 1, 0);  // FIX_MPY(wi, b.re)
+		const uint32_t m24 = __builtin_amdgcn_perm(p4, p2, 0x07060302u) ^ 0x0000ffffu;
+		uint32_t m13 = 0x00000001u;                                  // (0 + 1, 0)
+		if (KIND == 0) {
+			const uint32_t p1 = (uint32_t)mad_i16(w2, b, 32768 + 65536, 0, 0);  // FIX_MPY(wr, b.re) + 1
+			const uint32_t p3 = (uint32_t)mad_i16(w2, b, 32768, 0, 1);          // FIX_MPY(wr, b.im)
+			m13 = __builtin_amdgcn_perm(p3, p1, 0x07060302u);
+		}
+		tv = __builtin_bit_cast(pk16_t, (upk16_t)(__builtin_bit_cast(upk16_t, m13) + __builtin_bit_cast(upk16_t, m24)));
+	}
 	const pk16_t q = __builtin_bit_cast(pk16_t, a) >> 1;
-	const pk16_t tv = __builtin_bit_cast(pk16_t, tt);
 	b = __builtin_bit_cast(uint32_t, (pk16_t)(q - tv));
 	a = __builtin_bit_cast(uint32_t, (pk16_t)(q + tv));
+}
+
+// sum over the wave, valid in lane 63 (inclusive DPP scan)
+__device__ __forceinline__ int wave_total(int x)
+{
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+	return x;
 }
 
 // real_conj (src/rtl_power.c:636-640): re^2 + im^2 of a packed int16 pair is at most 2 * 2^30 = 2^31, which
@@ -106,40 +138,64 @@ __device__ __forceinline__ long long power_of(uint32_t v)
 	return (long long)(uint32_t)__builtin_amdgcn_sdot2(x, x, 0, false);
 }
 
-// LDS holds the points skewed by 8 dwords per 64-dword block: with the natural
-// layout the stride-8 pass (stages 3-5) puts 32 lanes on 8 banks.
-__device__ __forceinline__ int skew(int a) { return a + ((a >> 6) << 3); }
-__host__ __device__ constexpr int skewed_size(int n) { return n + ((n >> 6) << 3) + 8; }
+// LDS holds the points skewed by 4 dwords per 32-dword block.  Every access pattern of the transform is
+// then bank-conflict free: the stride-8 pass (stages 3-5) puts 32 lanes on 32 banks instead of 8 (what
+// the skew was introduced for), and the first pass (stages 0-2), where every lane owns eight CONSECUTIVE
+// dwords - two 16-byte accesses at a lane stride of 32 bytes -, no longer folds lanes l and l + 4 onto the
+// same four banks (with the 8-per-64 skew of rounds 1-2 that pass ran two-way conflicted both ways:
+// a quarter of the LDS time of the whole kernel, SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int skew(int a) { return a + ((a >> 5) << 2); }
+__host__ __device__ constexpr int skewed_size(int n) { return n + ((n >> 5) << 2) + 8; }
+// skew(a + b) == skew(a) + skew(b) whenever (a mod 32) + (b mod 32) < 32 - true for a group's base index
+// and its k-th point at distance k h for every stage width the passes use (h = 1, 8, or a multiple of 64)
+__host__ __device__ constexpr int skew_c(int a) { return a + ((a >> 5) << 2); }
+__host__ __device__ constexpr unsigned brev_c(unsigned v)
+{
+	unsigned r = 0;
+	for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+	return r;
+}
 
 // stages st .. st+R-1 for every group of 2^R points at stride 2^st (st is a multiple
 // of 3).  tw[(1 << stage) - 1 + m] holds the stage's twiddle for butterfly position m
-// as packed int16 (wr, wi), already halved as fix_fft does (src/rtl_power.c:303-308):
+// as packed int16 (2 wr, 2 wi) of the halved values fix_fft uses (src/rtl_power.c:303-308), see butterfly():
 // consecutive lanes read consecutive dwords (or the same one), never a strided table.
-template <int R>
-__device__ __forceinline__ void fft_pass(uint32_t *pts, const uint32_t *tw, int M, int st, int t)
+// ST >= 0: the stage is known at compile time (k_power_scan_big) and every point offset is an immediate.
+template <int R, int ST = -1>
+__device__ __forceinline__ void fft_pass(uint32_t *pts, const uint32_t *tw, int M, int st_rt, int t)
 {
 	constexpr int G = 1 << R;
+	const int st = ST >= 0 ? ST : st_rt;
 	const int h = 1 << st;
-	const int hs = h + ((h >> 6) << 3);  // stride between a group's points in the skewed layout
-	for (int g = t; g < (M >> R); g += kThreads) {
+	auto group = [&](int g) {
 		const int glo = g & (h - 1), ghi = g >> st;
 		const int base = skew((ghi << (st + R)) | glo);
+		int off[G];
+#pragma unroll
+		for (int k = 0; k < G; k++) off[k] = ST >= 0 ? skew_c(k << (ST >= 0 ? ST : 0)) : skew(k << st);
 		uint32_t x[G];
 #pragma unroll
-		for (int k = 0; k < G; k++) x[k] = pts[base + k * hs];
+		for (int k = 0; k < G; k++) x[k] = pts[base + off[k]];
 #pragma unroll
 		for (int r = 0; r < R; r++) {
 			const uint32_t *tws = tw + ((1 << (st + r)) - 1) + glo;
 #pragma unroll
 			for (int k = 0; k < G; k++) {
 				if (k & (1 << r)) continue;
-				const uint32_t w = tws[(k & ((1 << r) - 1)) * h];  // position m = glo + (k mod 2^r) * h
-				butterfly(x[k], x[k + (1 << r)], w);
+				const int kk = k & ((1 << r) - 1);
+				const uint32_t w = tws[kk * h];  // position m = glo + (k mod 2^r) * h of the stage's 2^(st+r)
+				// stages 0-2: position 0 is the real twiddle (16383, 0), the middle one (0, -16384)
+				if (ST == 0 && kk == 0) butterfly<1>(x[k], x[k + (1 << r)], w);
+				else if (ST == 0 && r > 0 && kk == (1 << r) / 2) butterfly<2>(x[k], x[k + (1 << r)], w);
+				else butterfly<0>(x[k], x[k + (1 << r)], w);
 			}
 		}
 #pragma unroll
-		for (int k = 0; k < G; k++) pts[base + k * hs] = x[k];
-	}
+		for (int k = 0; k < G; k++) pts[base + off[k]] = x[k];
+	};
+	// (unrolling k_power_scan_big's two or four rounds so that one round's LDS reads travel under the other's
+	// butterflies costs 9 more registers and measured 2 % SLOWER: four waves per SIMD already overlap them)
+	for (int g = t; g < (M >> R); g += kThreads) group(g);
 }
 
 __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
@@ -257,7 +313,7 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
 	uint32_t *pts = sm;                       // [skewed_size(N)]
 	uint32_t *tw = sm + skewed_size(N);       // [N]
-	__shared__ long long red[2][kThreads / 64];
+	__shared__ int red[2][kThreads / 64];
 	__shared__ int ave[2];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const size_t s = blockIdx.x / p.groups;
@@ -265,10 +321,16 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
 	if (r_begin >= r_end) return;
 	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
-	const int j0 = (lane << (E - 6)) | (wave << (E - 10));
+	// the thread's points: the BIT-REVERSED lane index in the top bits of j, so that the bit-reversed LDS
+	// address of point j0 + k has the lane itself in its low bits - consecutive lanes, consecutive dwords
+	// (with the lane in the top bits the low address bits were its bit reversal: the first 32 lanes of a
+	// wave hit only the even banks)
+	const int lane_r = (int)(__brev((unsigned)lane) >> 26);
+	const int j0 = (lane_r << (E - 6)) | (wave << (E - 10));
 	// the thread's window coefficients are fetched again for every read (64 bytes from a table that
 	// lives in L2): held in registers across the transform they pushed the radix-8 pass into spilling
 	const int4 *wp = reinterpret_cast<const int4 *>(p.window + j0);
+	const int scatter0 = skew((int)(__brev((unsigned)j0) >> (32 - E)));
 	long long acc[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) acc[k] = 0;
@@ -279,30 +341,40 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 
 	for (int r = r_begin; r < r_end; r++) {
 		// ---- A: remove_dc sums (all 2N elements are below len_dec here) ------------
-		int si = 0, sq = 0;
+		// at most N * 128 = 2^21 in magnitude: 32-bit sums, one v_dot4 per dword and component, the wave's
+		// total by DPP (lane 63 holds it), and a division by a compile-time constant - rounds 1-2 did
+		// this in 64 bits, whose emulated division ran once per read on one lane while the other fifteen
+		// waves stood at the barrier
+		int si = -127 * P, sq = -127 * P;
 #pragma unroll
 		for (int v = 0; v < V; v++) {
 			const uint32_t d[4] = {cur[v].x, cur[v].y, cur[v].z, cur[v].w};
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
-				si += (int)(d[q] & 0xff) + (int)((d[q] >> 16) & 0xff) - 254;
-				sq += (int)((d[q] >> 8) & 0xff) + (int)(d[q] >> 24) - 254;
+				si = (int)__builtin_amdgcn_udot4(d[q], 0x00010001u, (uint32_t)si, false);
+				sq = (int)__builtin_amdgcn_udot4(d[q], 0x01000100u, (uint32_t)sq, false);
 			}
 		}
-		long long li = si, lq = sq;
-		for (int off = 32; off > 0; off >>= 1) { li += __shfl_down(li, off); lq += __shfl_down(lq, off); }
-		__syncthreads();  // previous read's phase D is done with pts / red
-		if (lane == 0) { red[0][wave] = li; red[1][wave] = lq; }
-		__syncthreads();
-		if (t == 0) {
-			long long a = 0, b = 0;
-			for (int k = 0; k < kThreads / 64; k++) { a += red[0][k]; b += red[1][k]; }
-			ave[0] = (int)(int16_t)(a / (long long)(2 * N));
-			ave[1] = (int)(int16_t)(b / (long long)(2 * N - 1));
-		}
-		__syncthreads();
-		const int ai = ave[0], aq = ave[1];
+		si = wave_total(si);
+		sq = wave_total(sq);
+		if (lane == 63) { red[0][wave] = si; red[1][wave] = sq; }
+		__syncthreads();  // the sums are out, and the previous read's phase D is done with pts
+		// every wave adds the sixteen partial sums itself (lanes 0-15: I, 16-31: Q; a DPP row is 16 lanes):
+		// no second barrier, no single lane working while fifteen waves wait
+		int part = lane < 2 * (kThreads / 64) ? (&red[0][0])[lane] : 0;
+		part += __builtin_amdgcn_update_dpp(0, part, 0x111, 0xf, 0xf, false);
+		part += __builtin_amdgcn_update_dpp(0, part, 0x112, 0xf, 0xf, false);
+		part += __builtin_amdgcn_update_dpp(0, part, 0x114, 0xf, 0xf, false);
+		part += __builtin_amdgcn_update_dpp(0, part, 0x118, 0xf, 0xf, false);
+		const int ai = (int)(int16_t)(__builtin_amdgcn_readlane(part, 15) / (2 * N));
+		const int aq = (int)(int16_t)(__builtin_amdgcn_readlane(part, 31) / (2 * N - 1));
 		// ---- B: convert, DC, window, bit-reversed placement (conflict-free) ---------
+		// on packed pairs: v_perm lifts (I, Q) out of the dword as two zero-extended 16-bit halves, one
+		// v_pk_sub takes 127 + average off both, one v_pk_mul_lo_u16 applies the window coefficient (only
+		// the low 16 bits of either product survive the reference's int16 stores) - three instructions per
+		// point where the scalar form took eight and two quarter-rate 32-bit multiplies
+		typedef unsigned short upk16_t __attribute__((ext_vector_type(2)));
+		const upk16_t dcw = {(unsigned short)(127 + ai), (unsigned short)(127 + aq)};
 		int w[P];
 		const int4 *wq = wp;
 		asm volatile("" : "+v"(wq));  // keeps the loads inside the loop (they are loop-invariant, and hoisted they spill)
@@ -311,12 +383,11 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 #pragma unroll
 		for (int k = 0; k < P; k++) {
 			const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
-			const uint32_t pair = (k & 1) ? (d >> 16) : (d & 0xffffu);
-			int vi = (int16_t)((int)(pair & 0xff) - 127 - ai);
-			int vq = (int16_t)((int)(pair >> 8) - 127 - aq);
-			vi = (int16_t)(vi * w[k]);
-			vq = (int16_t)(vq * w[k]);
-			pts[skew((int)(__brev((unsigned)(j0 + k)) >> (32 - E)))] = pack_iq(vi, vq);
+			const upk16_t iq = __builtin_bit_cast(upk16_t, __builtin_amdgcn_perm(0u, d, (k & 1) ? 0x0c030c02u : 0x0c010c00u));
+			const upk16_t ww = {(unsigned short)w[k], (unsigned short)w[k]};
+			// bit reversal of j0 + k: k's E - 10 bits land above bit 10 (a compile-time offset, additive
+			// under the skew), the wave's four bits at 6..9, the lane in the low six
+			pts[scatter0 + skew_c((int)(brev_c(k) >> (32 - (E - 10))) << 10)] = __builtin_bit_cast(uint32_t, (upk16_t)((upk16_t)(iq - dcw) * ww));
 		}
 		// the next read's bytes travel while this one is transformed
 		if (r + 1 < r_end) {
@@ -324,20 +395,24 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
 		}
 		__syncthreads();
-		// ---- C ------------------------------------------------------------------------
-		for (int st = 0; st < E;) {
-			const int R = E - st >= 3 ? 3 : E - st;
-			if (R == 3) fft_pass<3>(pts, tw, N, st, t);
-			else if (R == 2) fft_pass<2>(pts, tw, N, st, t);
-			else fft_pass<1>(pts, tw, N, st, t);
-			st += R;
-			__syncthreads();
-		}
+		// ---- C: E = 13: four radix-8 passes and a radix-2 one; E = 14: four and a radix-4 one ----------
+		fft_pass<3, 0>(pts, tw, N, 0, t); __syncthreads();
+		fft_pass<3, 3>(pts, tw, N, 3, t); __syncthreads();
+		fft_pass<3, 6>(pts, tw, N, 6, t); __syncthreads();
+		fft_pass<3, 9>(pts, tw, N, 9, t); __syncthreads();
+		fft_pass<E - 12, 12>(pts, tw, N, 12, t); __syncthreads();
 		// ---- D ------------------------------------------------------------------------
+		// one |X|^2 is at most 2^31: the peak-hold maximum lives in 32 bits, the sum takes one 64-bit add
+		if (p.peak_hold) {
 #pragma unroll
-		for (int a = 0; a < P; a++) {
-			const long long pw = power_of(pts[skew(t + kThreads * a)]);
-			acc[a] = p.peak_hold ? (pw > acc[a] ? pw : acc[a]) : acc[a] + pw;
+			for (int a = 0; a < P; a++) {
+				const uint32_t pw = (uint32_t)power_of(pts[skew(t + kThreads * a)]);
+				const uint32_t m = (uint32_t)acc[a];
+				acc[a] = (long long)(pw > m ? pw : m);
+			}
+		} else {
+#pragma unroll
+			for (int a = 0; a < P; a++) acc[a] += power_of(pts[skew(t + kThreads * a)]);
 		}
 #pragma unroll
 		for (int v = 0; v < V; v++) cur[v] = nxt[v];

@@ -271,7 +271,9 @@ static int power_create_body(rtlpower_gpu *h)
 		HIP_TRY(hipMemcpy(h->d_window, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 		// sine_table(), src/rtl_power.c:247-261, regrouped per FFT stage: stage s uses
 		// wr = Sinewave[j + N/4] >> 1, wi = -Sinewave[j] >> 1 at j = m << (log2N - 1 - s)
-		// for m < 2^s (:303-308); entry (1 << s) - 1 + m holds them packed (wr, wi).
+		// for m < 2^s (:303-308); entry (1 << s) - 1 + m holds them DOUBLED and packed, (2 wr, 2 wi) - the
+		// butterfly takes FIX_MPY as the high half of a 16 x 16 product (power_kernels.h); wr, wi lie in
+		// -16384 .. 16383, so the doubled values still fit int16.
 		std::vector<int16_t> sine((size_t)h->N * 3 / 4 + 1);
 		for (int i = 0; i < h->N * 3 / 4; i++)
 			sine[i] = (int16_t)(int)round(32767 * sin((double)i * 2.0 * M_PI / h->N));
@@ -282,7 +284,7 @@ static int power_create_body(rtlpower_gpu *h)
 				const int j = m << k;
 				int16_t wr = sine[j + h->N / 4], wi = (int16_t)(-sine[j]);
 				wr >>= 1; wi >>= 1;
-				tw[(size_t)(1 << st) - 1 + m] = (uint32_t)(uint16_t)wr | ((uint32_t)(uint16_t)wi << 16);
+				tw[(size_t)(1 << st) - 1 + m] = (uint32_t)(uint16_t)(wr * 2) | ((uint32_t)(uint16_t)(wi * 2) << 16);
 			}
 		}
 		HIP_TRY(hipMalloc(&h->d_tw, tw.size() * sizeof(uint32_t)));
