@@ -78,9 +78,9 @@ typedef short pk16_t __attribute__((ext_vector_type(2)));
 // The twiddle table holds (2 wr, 2 wi) (both fit int16: wr, wi are the halved sines, -16384 .. 16383), so
 // every FIX_MPY is the HIGH HALF of one v_mad_i32_i16 - op_sel takes the 16-bit halves straight out of the
 // packed twiddle and the packed point, the rounding constant is the addend - and two v_perm gather the
-// four high halves into the packed pairs (m1, m3) and (m2, m4) without a single shift.  The one
-// subtraction, m1 - m2 = m1 + 1 + ~m2: the + 1 rides on m1's addend (2^15 + 2^16), the complement is one
-// xor of the low half.  11 instructions per butterfly (rounds 1-2: 18, round 3 before this: 14).
+// four high halves into the packed pairs (m1, m3) and (m2, m4) without a single shift; the one subtraction
+// among tr, ti is a packed multiply-add by (-1, +1).  10 instructions per butterfly: 4 v_mad_i32_i16,
+// 2 v_perm, v_pk_mad_i16, v_pk_ashr, v_pk_sub, v_pk_add (rounds 1-2: 18, round 3 before this: 14).
 __device__ __forceinline__ int mad_i16(uint32_t x, uint32_t y, int c, int xhi, int yhi)
 {
 	int r;
@@ -95,7 +95,7 @@ __device__ __forceinline__ int mad_i16(uint32_t x, uint32_t y, int c, int xhi, i
 template <int KIND = 0>
 __device__ __forceinline__ void butterfly(uint32_t &a, uint32_t &b, uint32_t w2)
 {
-	typedef unsigned short upk16_t __attribute__((ext_vector_type(2)));
+	const pk16_t pm = {(short)-1, (short)1};  // t = (m1 - m2, m3 + m4) = (m2, m4) * (-1, +1) + (m1, m3): one v_pk_mad_i16
 	pk16_t tv;
 	if (KIND == 1) {
 		const uint32_t p1 = (uint32_t)mad_i16(w2, b, 32768, 0, 0);  // high half: FIX_MPY(wr, b.re)
@@ -104,14 +104,15 @@ __device__ __forceinline__ void butterfly(uint32_t &a, uint32_t &b, uint32_t w2)
 	} else {
 		const uint32_t p2 = (uint32_t)mad_i16(w2, b, 32768, 1, 1);  // FIX_MPY(wi, b.im)
 		const uint32_t p4 = (uint32_t)mad_i16(w2, b, 32768, 1, 0);  // FIX_MPY(wi, b.re)
-		const uint32_t m24 = __builtin_amdgcn_perm(p4, p2, 0x07060302u) ^ 0x0000ffffu;
-		uint32_t m13 = 0x00000001u;                                  // (0 + 1, 0)
+		const pk16_t m24 = __builtin_bit_cast(pk16_t, __builtin_amdgcn_perm(p4, p2, 0x07060302u));
 		if (KIND == 0) {
-			const uint32_t p1 = (uint32_t)mad_i16(w2, b, 32768 + 65536, 0, 0);  // FIX_MPY(wr, b.re) + 1
-			const uint32_t p3 = (uint32_t)mad_i16(w2, b, 32768, 0, 1);          // FIX_MPY(wr, b.im)
-			m13 = __builtin_amdgcn_perm(p3, p1, 0x07060302u);
+			const uint32_t p1 = (uint32_t)mad_i16(w2, b, 32768, 0, 0);  // FIX_MPY(wr, b.re)
+			const uint32_t p3 = (uint32_t)mad_i16(w2, b, 32768, 0, 1);  // FIX_MPY(wr, b.im)
+			const pk16_t m13 = __builtin_bit_cast(pk16_t, __builtin_amdgcn_perm(p3, p1, 0x07060302u));
+			tv = m24 * pm + m13;
+		} else {
+			tv = m24 * pm;
 		}
-		tv = __builtin_bit_cast(pk16_t, (upk16_t)(__builtin_bit_cast(upk16_t, m13) + __builtin_bit_cast(upk16_t, m24)));
 	}
 	const pk16_t q = __builtin_bit_cast(pk16_t, a) >> 1;
 	b = __builtin_bit_cast(uint32_t, (pk16_t)(q - tv));
@@ -162,40 +163,51 @@ __host__ __device__ constexpr unsigned brev_c(unsigned v)
 // consecutive lanes read consecutive dwords (or the same one), never a strided table.
 // ST >= 0: the stage is known at compile time (k_power_scan_big) and every point offset is an immediate.
 template <int R, int ST = -1>
-__device__ __forceinline__ void fft_pass(uint32_t *pts, const uint32_t *tw, int M, int st_rt, int t)
+__device__ __forceinline__ void fft_group(uint32_t *pts, const uint32_t *tw, int st_rt, int g)
 {
 	constexpr int G = 1 << R;
 	const int st = ST >= 0 ? ST : st_rt;
 	const int h = 1 << st;
-	auto group = [&](int g) {
-		const int glo = g & (h - 1), ghi = g >> st;
-		const int base = skew((ghi << (st + R)) | glo);
-		int off[G];
+	const int glo = g & (h - 1), ghi = g >> st;
+	const int base = skew((ghi << (st + R)) | glo);
+	int off[G];
 #pragma unroll
-		for (int k = 0; k < G; k++) off[k] = ST >= 0 ? skew_c(k << (ST >= 0 ? ST : 0)) : skew(k << st);
-		uint32_t x[G];
+	for (int k = 0; k < G; k++) off[k] = ST >= 0 ? skew_c(k << (ST >= 0 ? ST : 0)) : skew(k << st);
+	uint32_t x[G];
 #pragma unroll
-		for (int k = 0; k < G; k++) x[k] = pts[base + off[k]];
+	for (int k = 0; k < G; k++) x[k] = pts[base + off[k]];
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			const uint32_t *tws = tw + ((1 << (st + r)) - 1) + glo;
+	for (int r = 0; r < R; r++) {
+		const uint32_t *tws = tw + ((1 << (st + r)) - 1) + glo;
 #pragma unroll
-			for (int k = 0; k < G; k++) {
-				if (k & (1 << r)) continue;
-				const int kk = k & ((1 << r) - 1);
-				const uint32_t w = tws[kk * h];  // position m = glo + (k mod 2^r) * h of the stage's 2^(st+r)
-				// stages 0-2: position 0 is the real twiddle (16383, 0), the middle one (0, -16384)
-				if (ST == 0 && kk == 0) butterfly<1>(x[k], x[k + (1 << r)], w);
-				else if (ST == 0 && r > 0 && kk == (1 << r) / 2) butterfly<2>(x[k], x[k + (1 << r)], w);
-				else butterfly<0>(x[k], x[k + (1 << r)], w);
-			}
+		for (int k = 0; k < G; k++) {
+			if (k & (1 << r)) continue;
+			const int kk = k & ((1 << r) - 1);
+			const uint32_t w = tws[kk * h];  // position m = glo + (k mod 2^r) * h of the stage's 2^(st+r)
+			// stages 0-2: position 0 is the real twiddle (16383, 0), the middle one (0, -16384)
+			if (ST == 0 && kk == 0) butterfly<1>(x[k], x[k + (1 << r)], w);
+			else if (ST == 0 && r > 0 && kk == (1 << r) / 2) butterfly<2>(x[k], x[k + (1 << r)], w);
+			else butterfly<0>(x[k], x[k + (1 << r)], w);
 		}
+	}
 #pragma unroll
-		for (int k = 0; k < G; k++) pts[base + off[k]] = x[k];
-	};
+	for (int k = 0; k < G; k++) pts[base + off[k]] = x[k];
+}
+
+template <int R, int ST = -1>
+__device__ __forceinline__ void fft_pass(uint32_t *pts, const uint32_t *tw, int M, int st_rt, int t)
+{
 	// (unrolling k_power_scan_big's two or four rounds so that one round's LDS reads travel under the other's
 	// butterflies costs 9 more registers and measured 2 % SLOWER: four waves per SIMD already overlap them)
-	for (int g = t; g < (M >> R); g += kThreads) group(g);
+	for (int g = t; g < (M >> R); g += kThreads) fft_group<R, ST>(pts, tw, st_rt, g);
+}
+
+// The LDS traffic of one wave is in order: what its lanes wrote is there for its lanes' later reads.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
@@ -396,9 +408,15 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 		}
 		__syncthreads();
 		// ---- C: E = 13: four radix-8 passes and a radix-2 one; E = 14: four and a radix-4 one ----------
-		fft_pass<3, 0>(pts, tw, N, 0, t); __syncthreads();
-		fft_pass<3, 3>(pts, tw, N, 3, t); __syncthreads();
-		fft_pass<3, 6>(pts, tw, N, 6, t); __syncthreads();
+		// Stages 0-8 are 512-point transforms, and group g of passes 0, 1 and 2 reads only what groups of
+		// the SAME 64 (g & ~63 ..) wrote in the pass before: a wave's own lanes.  No workgroup barrier
+		// until stage 9 - the sixteen waves drift apart, one's LDS traffic under another's butterflies.
+		for (int g = t; g < N / 8; g += kThreads) {
+			fft_group<3, 0>(pts, tw, 0, g); wave_sync();
+			fft_group<3, 3>(pts, tw, 3, g); wave_sync();
+			fft_group<3, 6>(pts, tw, 6, g);
+		}
+		__syncthreads();
 		fft_pass<3, 9>(pts, tw, N, 9, t); __syncthreads();
 		fft_pass<E - 12, 12>(pts, tw, N, 12, t); __syncthreads();
 		// ---- D ------------------------------------------------------------------------
