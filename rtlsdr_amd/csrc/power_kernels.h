@@ -163,17 +163,15 @@ __host__ __device__ constexpr unsigned brev_c(unsigned v)
 // consecutive lanes read consecutive dwords (or the same one), never a strided table.
 // ST >= 0: the stage is known at compile time (k_power_scan_big) and every point offset is an immediate.
 template <int R, int ST = -1>
-__device__ __forceinline__ void fft_group(uint32_t *pts, const uint32_t *tw, int st_rt, int g)
+__device__ __forceinline__ int fft_group_regs(uint32_t *pts, const uint32_t *tw, int st_rt, int g, uint32_t (&x)[1 << R], int (&off)[1 << R])
 {
 	constexpr int G = 1 << R;
 	const int st = ST >= 0 ? ST : st_rt;
 	const int h = 1 << st;
 	const int glo = g & (h - 1), ghi = g >> st;
 	const int base = skew((ghi << (st + R)) | glo);
-	int off[G];
 #pragma unroll
 	for (int k = 0; k < G; k++) off[k] = ST >= 0 ? skew_c(k << (ST >= 0 ? ST : 0)) : skew(k << st);
-	uint32_t x[G];
 #pragma unroll
 	for (int k = 0; k < G; k++) x[k] = pts[base + off[k]];
 #pragma unroll
@@ -190,6 +188,22 @@ __device__ __forceinline__ void fft_group(uint32_t *pts, const uint32_t *tw, int
 			else butterfly<0>(x[k], x[k + (1 << r)], w);
 		}
 	}
+	return base;
+}
+template <int R, int ST>
+__device__ __forceinline__ void fft_group_regs(uint32_t *pts, const uint32_t *tw, int g, uint32_t (&x)[1 << R])
+{
+	int off[1 << R];
+	fft_group_regs<R, ST>(pts, tw, ST, g, x, off);
+}
+
+template <int R, int ST = -1>
+__device__ __forceinline__ void fft_group(uint32_t *pts, const uint32_t *tw, int st_rt, int g)
+{
+	constexpr int G = 1 << R;
+	uint32_t x[G];
+	int off[G];
+	const int base = fft_group_regs<R, ST>(pts, tw, st_rt, g, x, off);
 #pragma unroll
 	for (int k = 0; k < G; k++) pts[base + off[k]] = x[k];
 }
@@ -326,7 +340,6 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	uint32_t *pts = sm;                       // [skewed_size(N)]
 	uint32_t *tw = sm + skewed_size(N);       // [N]
 	__shared__ int red[2][kThreads / 64];
-	__shared__ int ave[2];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const size_t s = blockIdx.x / p.groups;
 	const int grp = (int)(blockIdx.x % p.groups);
@@ -339,8 +352,6 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	// wave hit only the even banks)
 	const int lane_r = (int)(__brev((unsigned)lane) >> 26);
 	const int j0 = (lane_r << (E - 6)) | (wave << (E - 10));
-	// the thread's window coefficients are fetched again for every read (64 bytes from a table that
-	// lives in L2): held in registers across the transform they pushed the radix-8 pass into spilling
 	const int4 *wp = reinterpret_cast<const int4 *>(p.window + j0);
 	const int scatter0 = skew((int)(__brev((unsigned)j0) >> (32 - E)));
 	long long acc[16];
@@ -351,16 +362,18 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 #pragma unroll
 	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base + (size_t)r_begin * p.buf_len)[v];
 
-	for (int r = r_begin; r < r_end; r++) {
-		// ---- A: remove_dc sums (all 2N elements are below len_dec here) ------------
-		// at most N * 128 = 2^21 in magnitude: 32-bit sums, one v_dot4 per dword and component, the wave's
-		// total by DPP (lane 63 holds it), and a division by a compile-time constant - rounds 1-2 did
-		// this in 64 bits, whose emulated division ran once per read on one lane while the other fifteen
-		// waves stood at the barrier
+	// ---- A: remove_dc sums (all 2N elements are below len_dec here), one read AHEAD ----------------------
+	// at most N * 128 = 2^21 in magnitude: 32-bit sums, one v_dot4 per dword and component, the wave's total
+	// by DPP (lane 63 holds it) into red[]; after a workgroup barrier every wave adds the sixteen partial
+	// sums itself (lanes 0-15: I, 16-31: Q; a DPP row is 16 lanes) and divides by a compile-time constant.
+	// Rounds 1-2 did this in 64 bits with an emulated division on one lane between two barriers of its own.
+	// The sums of read r + 1 are taken from its registers while read r is transformed and ride on the
+	// barriers the transform has anyway.
+	auto dc_partial = [&](const uint4 (&d4)[V]) {
 		int si = -127 * P, sq = -127 * P;
 #pragma unroll
 		for (int v = 0; v < V; v++) {
-			const uint32_t d[4] = {cur[v].x, cur[v].y, cur[v].z, cur[v].w};
+			const uint32_t d[4] = {d4[v].x, d4[v].y, d4[v].z, d4[v].w};
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
 				si = (int)__builtin_amdgcn_udot4(d[q], 0x00010001u, (uint32_t)si, false);
@@ -370,16 +383,34 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 		si = wave_total(si);
 		sq = wave_total(sq);
 		if (lane == 63) { red[0][wave] = si; red[1][wave] = sq; }
-		__syncthreads();  // the sums are out, and the previous read's phase D is done with pts
-		// every wave adds the sixteen partial sums itself (lanes 0-15: I, 16-31: Q; a DPP row is 16 lanes):
-		// no second barrier, no single lane working while fifteen waves wait
+	};
+	auto dc_average = [&](int &ai, int &aq) {
 		int part = lane < 2 * (kThreads / 64) ? (&red[0][0])[lane] : 0;
 		part += __builtin_amdgcn_update_dpp(0, part, 0x111, 0xf, 0xf, false);
 		part += __builtin_amdgcn_update_dpp(0, part, 0x112, 0xf, 0xf, false);
 		part += __builtin_amdgcn_update_dpp(0, part, 0x114, 0xf, 0xf, false);
 		part += __builtin_amdgcn_update_dpp(0, part, 0x118, 0xf, 0xf, false);
-		const int ai = (int)(int16_t)(__builtin_amdgcn_readlane(part, 15) / (2 * N));
-		const int aq = (int)(int16_t)(__builtin_amdgcn_readlane(part, 31) / (2 * N - 1));
+		ai = (int)(int16_t)(__builtin_amdgcn_readlane(part, 15) / (2 * N));
+		aq = (int)(int16_t)(__builtin_amdgcn_readlane(part, 31) / (2 * N - 1));
+	};
+	// the thread's window coefficients: fetched again for every read (64 bytes from a table that lives in
+	// L2; held in registers across the radix-8 passes they pushed those into spilling), but EARLY - in front
+	// of the final pass, whose few live registers leave room - so that phase B does not start with an L2
+	// round trip.  The asm keeps the loop-invariant loads where they are.
+	int w[P];
+	auto load_window = [&]() {
+		const int4 *wq = wp;
+		asm volatile("" : "+v"(wq));
+#pragma unroll
+		for (int k = 0; k < P / 4; k++) { const int4 v = wq[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+	};
+	load_window();
+	int ai, aq;
+	dc_partial(cur);
+	__syncthreads();  // also: the twiddle table is in place
+	dc_average(ai, aq);
+
+	for (int r = r_begin; r < r_end; r++) {
 		// ---- B: convert, DC, window, bit-reversed placement (conflict-free) ---------
 		// on packed pairs: v_perm lifts (I, Q) out of the dword as two zero-extended 16-bit halves, one
 		// v_pk_sub takes 127 + average off both, one v_pk_mul_lo_u16 applies the window coefficient (only
@@ -387,11 +418,6 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 		// point where the scalar form took eight and two quarter-rate 32-bit multiplies
 		typedef unsigned short upk16_t __attribute__((ext_vector_type(2)));
 		const upk16_t dcw = {(unsigned short)(127 + ai), (unsigned short)(127 + aq)};
-		int w[P];
-		const int4 *wq = wp;
-		asm volatile("" : "+v"(wq));  // keeps the loads inside the loop (they are loop-invariant, and hoisted they spill)
-#pragma unroll
-		for (int k = 0; k < P / 4; k++) { const int4 v = wq[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
 #pragma unroll
 		for (int k = 0; k < P; k++) {
 			const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
@@ -402,7 +428,8 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 			pts[scatter0 + skew_c((int)(brev_c(k) >> (32 - (E - 10))) << 10)] = __builtin_bit_cast(uint32_t, (upk16_t)((upk16_t)(iq - dcw) * ww));
 		}
 		// the next read's bytes travel while this one is transformed
-		if (r + 1 < r_end) {
+		const bool more = r + 1 < r_end;
+		if (more) {
 #pragma unroll
 			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
 		}
@@ -416,22 +443,41 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 			fft_group<3, 3>(pts, tw, 3, g); wave_sync();
 			fft_group<3, 6>(pts, tw, 6, g);
 		}
+		if (more) dc_partial(nxt);
 		__syncthreads();
-		fft_pass<3, 9>(pts, tw, N, 9, t); __syncthreads();
-		fft_pass<E - 12, 12>(pts, tw, N, 12, t); __syncthreads();
-		// ---- D ------------------------------------------------------------------------
-		// one |X|^2 is at most 2^31: the peak-hold maximum lives in 32 bits, the sum takes one 64-bit add
-		if (p.peak_hold) {
+		fft_pass<3, 9>(pts, tw, N, 9, t);
+		__syncthreads();
+		// ---- the last stages and D: the outputs of group g = t + 1024 it of the final pass are the bins
+		// g + 4096 k - the thread's own accumulators a = it + 4 k: |X|^2 goes from the butterfly's registers
+		// into them, the spectrum is never written back to LDS.  One |X|^2 is at most 2^31: the peak-hold
+		// maximum lives in 32 bits, the sum takes one 64-bit add.
+		if (more) load_window();
+		{
+			constexpr int R = E - 12, G = 1 << R;
+			// the LDS addresses of the four rounds are loop-invariant; hoisted out of the read loop they are
+			// spilled and reloaded - two integer operations each, recomputed here, are cheaper
+			int tl = t;
+			asm volatile("" : "+v"(tl));
 #pragma unroll
-			for (int a = 0; a < P; a++) {
-				const uint32_t pw = (uint32_t)power_of(pts[skew(t + kThreads * a)]);
-				const uint32_t m = (uint32_t)acc[a];
-				acc[a] = (long long)(pw > m ? pw : m);
+			for (int it = 0; it < 4; it++) {
+				uint32_t x[G];
+				if (it) __builtin_amdgcn_sched_barrier(0);  // one round's operands at a time: all four at once spill
+				fft_group_regs<R, 12>(pts, tw, tl + it * kThreads, x);
+#pragma unroll
+				for (int k = 0; k < G; k++) {
+					const int a = it + 4 * k;
+					if (p.peak_hold) {
+						const uint32_t pw = (uint32_t)power_of(x[k]);
+						const uint32_t m = (uint32_t)acc[a];
+						acc[a] = (long long)(pw > m ? pw : m);
+					} else {
+						acc[a] += power_of(x[k]);
+					}
+				}
 			}
-		} else {
-#pragma unroll
-			for (int a = 0; a < P; a++) acc[a] += power_of(pts[skew(t + kThreads * a)]);
 		}
+		if (more) dc_average(ai, aq);  // red[] was written before the barrier behind stage 8
+		__syncthreads();               // the final pass is done reading pts: the next read may be placed
 #pragma unroll
 		for (int v = 0; v < V; v++) cur[v] = nxt[v];
 	}
