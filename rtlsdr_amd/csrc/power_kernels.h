@@ -49,6 +49,7 @@ struct ScanParams {
 	int bin_e, chunks;       // FFT size exponent, chunks per read
 	int ds, peak_hold;
 	const int32_t *window;   // [N]
+	const uint16_t *window16; // [N] the low halves of window[] (k_power_scan_big multiplies in 16 bits)
 	const uint32_t *tw;      // [N] per-stage twiddles, see make_twiddles() in rtlpower_hip.hip
 	long long *avg;          // [stream][N]
 	int32_t *samples;        // [stream]
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 //    lane in its LOW bits: phase B's scattered stores are bank-conflict free (they were
 //    32-way conflicted with the natural mapping).
 template <int E>
-__global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
+__global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams p)
 {
 	constexpr int N = 1 << E;
 	constexpr int P = N / kThreads;  // points per thread: 8 or 16
@@ -352,7 +353,9 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 	// wave hit only the even banks)
 	const int lane_r = (int)(__brev((unsigned)lane) >> 26);
 	const int j0 = (lane_r << (E - 6)) | (wave << (E - 10));
-	const int4 *wp = reinterpret_cast<const int4 *>(p.window + j0);
+	// the window coefficients as 16-bit halves (only the low 16 bits of a product survive the reference's
+	// int16 stores), two to a register
+	const uint4 *wp = reinterpret_cast<const uint4 *>(p.window16 + j0);
 	const int scatter0 = skew((int)(__brev((unsigned)j0) >> (32 - E)));
 	long long acc[16];
 #pragma unroll
@@ -393,16 +396,16 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 		ai = (int)(int16_t)(__builtin_amdgcn_readlane(part, 15) / (2 * N));
 		aq = (int)(int16_t)(__builtin_amdgcn_readlane(part, 31) / (2 * N - 1));
 	};
-	// the thread's window coefficients: fetched again for every read (64 bytes from a table that lives in
+	// the thread's window coefficients: fetched again for every read (32 bytes from a table that lives in
 	// L2; held in registers across the radix-8 passes they pushed those into spilling), but EARLY - in front
 	// of the final pass, whose few live registers leave room - so that phase B does not start with an L2
 	// round trip.  The asm keeps the loop-invariant loads where they are.
-	int w[P];
+	uint32_t w2[P / 2];
 	auto load_window = [&]() {
-		const int4 *wq = wp;
+		const uint4 *wq = wp;
 		asm volatile("" : "+v"(wq));
 #pragma unroll
-		for (int k = 0; k < P / 4; k++) { const int4 v = wq[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+		for (int k = 0; k < P / 8; k++) { const uint4 v = wq[k]; w2[4 * k] = v.x; w2[4 * k + 1] = v.y; w2[4 * k + 2] = v.z; w2[4 * k + 3] = v.w; }
 	};
 	load_window();
 	int ai, aq;
@@ -422,7 +425,9 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_big(const ScanParams p)
 		for (int k = 0; k < P; k++) {
 			const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
 			const upk16_t iq = __builtin_bit_cast(upk16_t, __builtin_amdgcn_perm(0u, d, (k & 1) ? 0x0c030c02u : 0x0c010c00u));
-			const upk16_t ww = {(unsigned short)w[k], (unsigned short)w[k]};
+			const upk16_t wpair = __builtin_bit_cast(upk16_t, w2[k / 2]);
+			const unsigned short wk = (k & 1) ? wpair.y : wpair.x;
+			const upk16_t ww = {wk, wk};
 			// bit reversal of j0 + k: k's E - 10 bits land above bit 10 (a compile-time offset, additive
 			// under the skew), the wave's four bits at 6..9, the lane in the low six
 			pts[scatter0 + skew_c((int)(brev_c(k) >> (32 - (E - 10))) << 10)] = __builtin_bit_cast(uint32_t, (upk16_t)((upk16_t)(iq - dcw) * ww));

@@ -34,6 +34,7 @@ struct rtlpower_gpu {
 	int N = 1, len_dec = 0, chunks = 0, dec_elems = 0;
 	bool decimates = false;
 	int32_t *d_window = nullptr;
+	uint16_t *d_window16 = nullptr;  // the low halves (k_power_scan_big multiplies in 16 bits)
 	uint32_t *d_tw = nullptr;
 	long long *d_avg = nullptr;
 	int32_t *d_samples = nullptr;
@@ -269,6 +270,10 @@ static int power_create_body(rtlpower_gpu *h)
 		rtlpower_window_coefs(cfg->window, h->N, w.data());
 		HIP_TRY(hipMalloc(&h->d_window, w.size() * sizeof(int32_t)));
 		HIP_TRY(hipMemcpy(h->d_window, w.data(), w.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		std::vector<uint16_t> w16(w.size());
+		for (size_t i = 0; i < w.size(); i++) w16[i] = (uint16_t)(uint32_t)w[i];
+		HIP_TRY(hipMalloc(&h->d_window16, w16.size() * sizeof(uint16_t)));
+		HIP_TRY(hipMemcpy(h->d_window16, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 		// sine_table(), src/rtl_power.c:247-261, regrouped per FFT stage: stage s uses
 		// wr = Sinewave[j + N/4] >> 1, wi = -Sinewave[j] >> 1 at j = m << (log2N - 1 - s)
 		// for m < 2^s (:303-308); entry (1 << s) - 1 + m holds them DOUBLED and packed, (2 wr, 2 wi) - the
@@ -302,7 +307,7 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 		if (e) (void)hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_window, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
+	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -454,7 +459,7 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 	p.dec = dec; p.dec_stream_stride = dss; p.dec_read_stride = drs; p.dec_elems = h->dec_elems;
 	p.nreads = nreads; p.buf_len = (int)c.buf_len; p.len_dec = h->len_dec;
 	p.bin_e = c.bin_e; p.chunks = h->chunks; p.ds = c.downsample; p.peak_hold = c.peak_hold;
-	p.window = h->d_window; p.tw = h->d_tw; p.avg = h->d_avg; p.samples = h->d_samples;
+	p.window = h->d_window; p.window16 = h->d_window16; p.tw = h->d_tw; p.avg = h->d_avg; p.samples = h->d_samples;
 	const size_t lds = ((size_t)skewed_size(h->chunks * h->N) + (size_t)h->N) * 4;
 	static bool attr_set = false;
 	if (!attr_set) {

@@ -69,6 +69,10 @@ class GpuPower:
     def clear(self):
         check(self.lib.rtlpower_gpu_clear(self._h), "rtlpower_gpu_clear")
 
+    def set_option(self, name: str, value: int):
+        """Tunables by name (include/rtlpower_hip.h): "groups", "pair"."""
+        check(self.lib.rtlpower_gpu_set_option(self._h, name.encode(), int(value)), f"rtlpower_gpu_set_option({name})")
+
     def sync(self):
         check(self.lib.rtlpower_gpu_sync(self._h), "rtlpower_gpu_sync")
 
