@@ -660,12 +660,11 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : (STD && MFMA0 &
 			__builtin_amdgcn_wave_barrier();
 			// 16 segments of 128 outputs: lane (n = l&15, q = l>>4) feeds window n's bytes
 			// 16q..16q+15 = chunk 32s + 2n + q - 1 and receives outputs 128s + 8n + 2q + {0,1}
-			// (the lane index goes through an empty asm here and once more below: the half-dozen LDS addresses
-			// derived from it are loop-invariant, the compiler keeps each in a register across the whole tile,
-			// and recomputing them - a few VALU operations per tile - brings the kernel from 113 to 97 VGPRs
-			// (96 and no spill under a five-waves bound; see RTLFM_FUSED_WAVES_STD45))
-			int ln = lane;
-			asm volatile("" : "+v"(ln));
+			// (Sending the lane index through an empty asm here and behind pass 0 - so that the half-dozen
+			// loop-invariant LDS addresses derived from it are recomputed per tile instead of held - brings the
+			// kernel from 113 to 97 VGPRs, and with RTLFM_FUSED_WAVES_STD45 = 5 to five waves per SIMD without
+			// a spill: measured no faster with five waves and 2-3 % SLOWER with four, so it is not done.)
+			const int ln = lane;
 			const int n = ln & 15, q = ln >> 4;
 			const uint4 *rd = chunks + (2 * n + q - 1);
 			// Outputs go back in place, but the eight 16-byte slots of each lane's later
@@ -830,8 +829,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : (STD && MFMA0 &
 			}
 		};
 
-		int lz = lane;
-		asm volatile("" : "+v"(lz));  // see the MFMA phase: hand-off addresses recomputed, not carried
+		const int lz = lane;
 		RTLFM_MARK("pass0_special_done");
 		// ------------------------------------------------------------ passes 1.. ----
 		uint32_t Z[CZ];  // output of the last pass
