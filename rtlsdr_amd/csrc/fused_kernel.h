@@ -426,14 +426,10 @@ struct AtanNodesLds {
 #ifndef RTLFM_FUSED_WAVES_PER_SIMD
 #define RTLFM_FUSED_WAVES_PER_SIMD 4
 #endif
-// The 4- and 5-pass polar_discriminant kernels with the MFMA pass 0 fit 96 VGPRs without a spill (see the
-// note on the lane index in the MFMA phase), i.e. five waves per SIMD by registers and 19 per CU by LDS.
-// Measured with the wave count matched to the 4864 slots (tools/ab_engines.py --waves): no faster than four
-// (0.823-0.835 vs 0.822 ms at /16, 0.803-0.820 vs 0.796 at /32), so four it stays; -DRTLFM_FUSED_WAVES_STD45=5
-// builds the other.
-#ifndef RTLFM_FUSED_WAVES_STD45
-#define RTLFM_FUSED_WAVES_STD45 4
-#endif
+// (Five waves per SIMD for the 4- and 5-pass polar_discriminant kernels - 96 VGPRs by recomputing the
+// lane-derived LDS addresses per tile - were built and measured with the wave count matched to the 4864
+// slots, tools/ab_engines.py --waves: no faster than four, and the recomputation costs 2-3 % with four.
+// DESIGN.md section 4.2a.)
 #ifndef RTLFM_PASS0_DEFAULT
 #define RTLFM_PASS0_DEFAULT 1  // 0: always v_dot4 on the VALU, 1: int8 MFMA where it is faster (RTLFM_PASS0=valu|mfma overrides)
 #endif
@@ -457,7 +453,7 @@ struct AtanNodesLds {
 // rotation), and -16 C is what the MFMA accumulators start from instead of zero.  No instruction is
 // added to the tile; samples now span +-255, so pass 3 takes the 32-bit form as it does without rotation.
 template <int P, bool FIR9, bool STD, bool MFMA0, bool RDC = false>
-__global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : (STD && MFMA0 && !RDC && (P == 4 || P == 5)) ? RTLFM_FUSED_WAVES_STD45 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
+__global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
 {
 	static_assert(!RDC || MFMA0, "the raw DC block rides on the MFMA accumulators");
 	using L = Lds<P, FIR9, MFMA0>;
@@ -660,10 +656,6 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : (STD && MFMA0 &
 			__builtin_amdgcn_wave_barrier();
 			// 16 segments of 128 outputs: lane (n = l&15, q = l>>4) feeds window n's bytes
 			// 16q..16q+15 = chunk 32s + 2n + q - 1 and receives outputs 128s + 8n + 2q + {0,1}
-			// (Sending the lane index through an empty asm here and behind pass 0 - so that the half-dozen
-			// loop-invariant LDS addresses derived from it are recomputed per tile instead of held - brings the
-			// kernel from 113 to 97 VGPRs, and with RTLFM_FUSED_WAVES_STD45 = 5 to five waves per SIMD without
-			// a spill: measured no faster with five waves and 2-3 % SLOWER with four, so it is not done.)
 			const int ln = lane;
 			const int n = ln & 15, q = ln >> 4;
 			const uint4 *rd = chunks + (2 * n + q - 1);
