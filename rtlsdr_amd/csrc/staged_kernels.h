@@ -1374,26 +1374,38 @@ k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstr
 	// the state at the start of this lane's chunk (chunk pre + lane of the array): from the `pre` chunks before it
 	const int begin = k0 + lane * C, end = min(begin + C, T);
 	uint32_t v = (uint32_t)(carried + 32768);
-	if (begin > 0 && begin < T) {
+	{
+		// Both extreme states are walked over the samples before the chunk; where they have met, that is the
+		// state, whatever came earlier.  The window GROWS: one chunk (32 samples) first - with a = 2 the two
+		// walks of a moving signal meet after 17-23 samples -, and only if some lane of the wave is still
+		// undecided two chunks, then all `pre` of them (W samples).  Before, every lane walked W = 128
+		// samples twice for its 32: nine filter steps per sample where three do.
+		const bool mine = begin > 0 && begin < T;
 		uint32_t lo = 0, hi = 65535;
-		if (begin < W) lo = hi = v;  // the run starts inside the window: from the carried state, over the samples there are
-		for (int c = 0; c < pre; c++) {
-			if (begin - (pre - c) * C < 0) continue;
-			const uint4 *wp = reinterpret_cast<const uint4 *>(y + (lane + c) * Cp);
+		for (int nch = 1;; nch = nch * 2 < pre ? nch * 2 : pre) {
+			lo = 0; hi = 65535;
+			if (begin < nch * C) lo = hi = v;  // the run starts inside the window: from the carried state, over the samples there are
+			for (int c = pre - nch; c < pre; c++) {
+				if (begin - (pre - c) * C < 0) continue;
+				const uint4 *wp = reinterpret_cast<const uint4 *>(y + (lane + c) * Cp);
 #pragma unroll
-			for (int g = 0; g < C / 8; g++) {
-				const uint4 q4 = wp[g];
-				const uint32_t w4[4] = {q4.x, q4.y, q4.z, q4.w};
+				for (int g = 0; g < C / 8; g++) {
+					const uint4 q4 = wp[g];
+					const uint32_t w4[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-				for (int i = 0; i < 4; i++) {
-					const uint32_t b2 = w4[i] ^ 0x80008000u;
-					lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
-					lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
+					for (int i = 0; i < 4; i++) {
+						const uint32_t b2 = w4[i] ^ 0x80008000u;
+						lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
+						lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
+					}
 				}
 			}
+			if (nch >= pre || !__any(mine && lo != hi)) break;
 		}
-		if (lo != hi) fallback[s] = 1;  // what this workgroup writes for the stream is replaced afterwards
-		v = lo;
+		if (mine) {
+			if (lo != hi) fallback[s] = 1;  // what this workgroup writes for the stream is replaced afterwards
+			v = lo;
+		}
 	}
 	__syncthreads();
 	// the filtered sample before the span (left neighbour of its first sample), then the chunk in place
