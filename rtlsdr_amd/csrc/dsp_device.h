@@ -151,11 +151,9 @@ __device__ __forceinline__ int atan2_q14(int y, int x, Nodes nodes)
 	p = __builtin_fma(t2, p, RTLFM_ATAN_K);
 	const double w = __builtin_fma(t, p, nodes(i));  // K*atan(mn/mx) in [0, 4096.004]
 	const bool swap = ay > ax, neg = x < 0;
-	// x>=0: swap ? H - w : w ;  x<0: swap ? H + w : PIK - w.  PIK = 2 H bit for bit, so base + (-)w is
-	// one fused multiply-add m * H + (-)w with m = 0, 1, 2 exact - and of m only the high dword is selected
-	const double m = __builtin_bit_cast(double, (uint64_t)(swap ? 0x3ff00000u : neg ? 0x40000000u : 0u) << 32);
-	const double sw = __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, w) ^ ((uint64_t)(neg != swap) << 63));
-	const double v = __builtin_fma(m, RTLFM_ATAN_H, sw);
+	// x>=0: swap ? H - w : w ;  x<0: swap ? H + w : PIK - w
+	const double base = neg ? (swap ? RTLFM_ATAN_H : RTLFM_ATAN_PIK) : (swap ? RTLFM_ATAN_H : 0.0);
+	const double v = (neg != swap) ? base - w : base + w;
 	// trunc toward zero is odd-symmetric: give v the sign of y, then convert
 	return (int)__builtin_copysign(v, fy);
 }
