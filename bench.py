@@ -901,8 +901,15 @@ def main():
             # the whole step (front end + audio tail kernels), wall clock
             roof["step_frac"] = round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
         if a.tail == "power":
-            roof["note"] = ("not HBM-bound: ~250 integer operations per 2-byte sample in LDS-resident radix-2 stages "
-                            "(SURVEY §8d); see DESIGN.md §4.5 for the VALU/LDS ceiling from the PMC passes")
+            # 83 integer lane-operations per 2-byte sample (PMC, profiles/r03_pmc_c4_k_power_scan.txt): the bound is
+            # VALU issue, 1024 SIMDs x 16 lanes per cycle at the 2.4 GHz the part holds under this kernel
+            lane_ops, simds, ghz = 83.0, 1024, 2.4
+            valu_floor_ms = lane_ops * (a.streams * a.blocks * a.block_len / 2) / (simds * 16 * ghz * 1e9) * 1e3
+            roof["note"] = ("not HBM-bound: 83 integer lane-operations per 2-byte sample in LDS-resident radix-2 stages; "
+                            "valu_issue = the launch time that instruction count alone takes (DESIGN.md section 4.5)")
+            roof["valu_issue"] = {"floor_ms": round(valu_floor_ms, 3), "frac": round(valu_floor_ms / (front_ms / max(launches, 1)), 3),
+                                  "lane_ops_per_sample": lane_ops, "how": "SQ_INSTS_VALU x 64 / samples from the committed PMC pass; "
+                                  "not re-measured by this invocation"}
         if sustained:
             n_s, dt, s_launch = sustained
             roof["sustained"] = {
