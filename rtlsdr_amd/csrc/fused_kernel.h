@@ -1011,6 +1011,12 @@ struct Workspace {
 	bool want_stamps = false;                     // rtlfm_gpu_clock_probe(): every wave leaves its clock stamps
 	// segmentation (rtlfm_gpu_set_option: fused_waves, fused_min_tiles, fused_tiles_per_seg)
 	int target_waves = 8192;                      // enough waves to fill the 4096 wave slots of 256 CUs twice
+	// ... and when an audio tail follows the front end (its kernels share the GPU with the next step's
+	// front end): shorter segments, so that wave slots come free more often and the tail's waves get in.
+	// Same-box sweep of 8192 .. 32768: c3 step 0.907-0.926 -> 0.872-0.876 ms, wbfm
+	// 1.418 -> 1.309-1.315 ms at 20480; without a tail the launch time is flat from 8192 to 24576.
+	int target_waves_tail = 20480;
+	bool tail_follows = false;                    // set by the host per run (rtlfm_hip.hip: plan_tail)
 	int min_tiles = 8;                            // a segment pays one warm-up tile: at most 1/8 on top
 	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
 	int gss_x10 = 0;                              // guided segment lengths: remaining / (gss R) per round, x10 (0 = equal segments)
@@ -1054,7 +1060,8 @@ inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
 		return sp;
 	}
 	const int min_tiles = ws.min_tiles > 0 ? ws.min_tiles : 1;
-	int segs = (ws.target_waves + nstreams - 1) / nstreams;
+	const int target = ws.tail_follows ? ws.target_waves_tail : ws.target_waves;
+	int segs = (target + nstreams - 1) / nstreams;
 	int cap = total_tiles / min_tiles;
 	if (cap < 1) cap = 1;
 	const bool underfilled = (long long)nstreams * cap < kWaveSlots;

@@ -362,8 +362,11 @@ def test_options_by_name():
     cfg = make_cfg(dict(downsample=16, downsample_passes=4), 16384, 2)
     with GpuDemod(cfg, 2, 0) as g:
         assert g.get_option("fused_waves") == 8192 and g.get_option("fused_min_tiles") == 8
+        assert g.get_option("fused_waves_tail") == 20480  # shorter segments where an audio tail follows
         g.set_option("fused_waves", 100)
-        assert g.get_option("fused_waves") == 100
+        assert g.get_option("fused_waves") == 100 and g.get_option("fused_waves_tail") == 100  # one number for both
+        g.set_option("fused_waves_tail", 300)
+        assert g.get_option("fused_waves") == 100 and g.get_option("fused_waves_tail") == 300
         g.set_option("tail_serial", 1)
         assert g.get_option("tail_serial") == 1
         with pytest.raises(capi.RtlfmError) as e:
