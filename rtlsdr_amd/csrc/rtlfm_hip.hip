@@ -1903,33 +1903,41 @@ extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *othe
 	// a quarter is 72 GB: at most that much is walked over, and never more than what is free minus a reserve
 	size_t budget = (size_t)80 << 30;
 	if (free_b < budget + ((size_t)8 << 30)) budget = free_b > ((size_t)8 << 30) ? free_b - ((size_t)8 << 30) : 0;
-	std::vector<void *> keep;
-	void *win = nullptr, *last = nullptr;
+	std::vector<void *> keep;       // fillers
+	std::vector<void *> cand;       // candidates that did not pass, with their times
+	std::vector<float> cand_rw;
+	void *win = nullptr;
 	size_t walked = 0;
 	for (;;) {
 		void *p = nullptr;
 		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
 		float rw = 0;
-		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 6, &rw) < 0) { last = p; break; }
+		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 6, &rw) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
 		if (rw < kApartRatio * rd) { win = p; break; }
-		last = p;
+		cand.push_back(p); cand_rw.push_back(rw);
 		if (walked + step + bytes > budget) break;
-		keep.push_back(p);
-		last = nullptr;
 		void *f = nullptr;
 		if (hipMalloc(&f, step) != hipSuccess) { (void)hipGetLastError(); break; }
 		keep.push_back(f);
 		walked += step + bytes;
 	}
 	for (void *k : keep) hipFree(k);
-	if (win) {
-		if (last) hipFree(last);
-		*out = win;
-		if (apart) *apart = 1;
-		return 0;
+	// no candidate under the threshold (a noisy box, or the walk ran out of budget): the one that measured
+	// fastest is still the best place there is
+	if (!win && !cand.empty()) {
+		size_t best = 0;
+		for (size_t i = 1; i < cand.size(); i++)
+			if (cand_rw[i] < cand_rw[best]) best = i;
+		win = cand[best];
+		cand[best] = nullptr;
+		if (apart) *apart = 0;
+	} else if (win && apart) {
+		*apart = 1;
 	}
-	if (!last) HIP_TRY(hipMalloc(&last, bytes));
-	*out = last;
+	for (void *c : cand)
+		if (c) hipFree(c);
+	if (!win) HIP_TRY(hipMalloc(&win, bytes));
+	*out = win;
 	return 0;
 }
 
