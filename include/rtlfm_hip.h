@@ -272,6 +272,7 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   deemph_four_pass     1: no one-pass (speculative) deemph kernels
  *   lpr_separate         1: low_pass_real as a kernel of its own behind deemph_filter
  *   lpr_scalar_stores    1: the resampler's outputs one by one
+ *   lpr_chunk            samples per lane of the one-pass deemph + low_pass_real kernel (default 2720; >= 256)
  *   tail_sync            1: synchronise and report after every tail kernel (debugging)
  *   fused_debug          clock-stamp experiments (2 / 18 / 4, see fused_kernel.h)
  * Returns -ENOENT for an unknown name, -EINVAL for a value out of range.

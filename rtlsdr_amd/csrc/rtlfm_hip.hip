@@ -94,6 +94,7 @@ struct rtlfm_gpu {
 	// A/B switches (rtlfm_gpu_set_option); none of them changes a result
 	struct Options {
 		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
+		int lpr_chunk = 2720;  // samples per lane of the one-pass deemph + low_pass_real kernel
 	} opt;
 
 	// timing of the decimating front end
@@ -495,7 +496,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"fused_tiles_per_seg", &h->fws.tiles_per_seg}, {"fused_debug", &h->fws.debug}, {"fused_gss", &h->fws.gss_x10},
 		{"pass0_engine", &h->fws.pass0_engine},
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
-		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores},
+		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync},
 	};
 	for (auto &t : tab)
@@ -753,13 +754,14 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			// and a multiple of the resampler's period fast / gcd(fast, slow) where that is short - then all
 			// chunks of a stream start at the same phase, the lanes of a wave emit at the same samples and
 			// the emission branch is taken by whole waves instead of by a few lanes every sample
-			int Ls = 2720;
+			const int Lwant = h->opt.lpr_chunk >= 256 ? h->opt.lpr_chunk : 2720;
+			int Ls = Lwant;
 			if (tp.lpr && c.rate_out2 > 0) {
 				long long g = c.rate_out, b = c.rate_out2;
 				while (b) { const long long t = g % b; g = b; b = t; }
 				long long per = c.rate_out / g;
 				while (per % 8) per *= 2;
-				if (per <= 2720) Ls = (int)(per * ((2720 + per / 2) / per));
+				if (per <= Lwant) Ls = (int)(per * ((Lwant + per / 2) / per));
 			}
 			// ... and where arbitrary_resample follows directly, on uniform buffers that it upsamples
 			// (config 3): one pass from the demodulated samples to the resampled output
