@@ -43,6 +43,7 @@ struct rtlpower_gpu {
 	uint8_t *d_one = nullptr;  // landing zone of rtlpower_gpu_scan()
 	bool timing = false;
 	int groups = 0;  // option "groups": workgroups per stream of the FFT kernel (0 = automatic)
+	bool attr_set = false, attr_big = false;  // the kernels' dynamic-LDS limits are raised on this handle's device
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
 
@@ -461,11 +462,12 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 	p.bin_e = c.bin_e; p.chunks = h->chunks; p.ds = c.downsample; p.peak_hold = c.peak_hold;
 	p.window = h->d_window; p.window16 = h->d_window16; p.tw = h->d_tw; p.avg = h->d_avg; p.samples = h->d_samples;
 	const size_t lds = ((size_t)skewed_size(h->chunks * h->N) + (size_t)h->N) * 4;
-	static bool attr_set = false;
-	if (!attr_set) {
+	// per handle, not per process: the attribute belongs to the device the handle lives on, and one process
+	// may hold handles on several
+	if (!h->attr_set) {
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan),
 		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-		attr_set = true;
+		h->attr_set = true;
 	}
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	if (h->timing) {
@@ -475,13 +477,12 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 	}
 	const bool big = !dec && h->chunks == 1 && h->len_dec == 2 * h->N && (c.bin_e == 13 || c.bin_e == 14) &&
 	                 !(stream_stride & 15) && !((uintptr_t)d_iq & 15) && !(c.buf_len & 15);
-	static bool attr_big = false;
-	if (big && !attr_big) {
+	if (big && !h->attr_big) {
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_big<13>),
 		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_big<14>),
 		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-		attr_big = true;
+		h->attr_big = true;
 	}
 	// enough workgroups for the 256 CUs (a large-FFT workgroup fills a CU's LDS, the small ones share):
 	// a stream's reads are split when there are few streams (power_kernels.h)
