@@ -1009,8 +1009,7 @@ __device__ __forceinline__ void deemph_walk_pair(const int16_t *r, int n, uint32
 		const uint32_t x = (uint32_t)(uint16_t)r[k] ^ 0x8000u;
 		lo = ds.step<MAGIC>(x, lo); hi = ds.step<MAGIC>(x, hi);
 	}
-	for (; k + 8 <= n; k += 8) {
-		const uint4 g = *reinterpret_cast<const uint4 *>(r + k);
+	auto group = [&](const uint4 &g) {
 		const uint32_t w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
@@ -1018,7 +1017,26 @@ __device__ __forceinline__ void deemph_walk_pair(const int16_t *r, int n, uint32
 			lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
 			lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
 		}
+	};
+	// four 16-byte groups in flight ahead of the walk, as deemph_walk_sink has eight: a lane's loads are its
+	// own (a chunk per lane), and one L2 round trip per eight samples was most of the settle walk's time
+	constexpr int NG = 4, NS = 8 * NG;
+	if (k + NS <= n) {
+		uint4 cur[NG], nxt[NG];
+#pragma unroll
+		for (int j = 0; j < NG; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
+		for (; k + NS <= n; k += NS) {
+			const bool more = k + 2 * NS <= n;
+			const uint4 *np = reinterpret_cast<const uint4 *>(r + (more ? k + NS : k));
+#pragma unroll
+			for (int j = 0; j < NG; j++) nxt[j] = np[j];
+#pragma unroll
+			for (int j = 0; j < NG; j++) group(cur[j]);
+#pragma unroll
+			for (int j = 0; j < NG; j++) cur[j] = nxt[j];
+		}
 	}
+	for (; k + 8 <= n; k += 8) group(*reinterpret_cast<const uint4 *>(r + k));
 	for (; k < n; k++) {
 		const uint32_t x = (uint32_t)(uint16_t)r[k] ^ 0x8000u;
 		lo = ds.step<MAGIC>(x, lo); hi = ds.step<MAGIC>(x, hi);
