@@ -9,10 +9,12 @@ in HBM.
     python bench.py [--workload c2] --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Workloads (BASELINE.json `configs`; the default line is configs[1]):
+Workloads (BASELINE.json `configs`; the default line is north_star's own shape of configs[1]'s chain, and every
+other BASELINE configuration is timed by the same invocation as a short `also` leg):
 
-    c2      256 streams x 64 buffers x 262144 B @2.4 MS/s, -F 0 (4x fifth_order, /16), -A std   [default]
-    ns4096  north_star's target shape: 4096 streams x 4 buffers x 262144 B through the same /16 FM path
+    ns4096  north_star's target shape: 4096 batched 2.4 MS/s streams x 4 buffers x 262144 B, -F 0 (4x fifth_order,
+            /16), -A std                                                                          [default]
+    c2      configs[1] as BASELINE words it: 256 streams x 64 buffers x 262144 B through the same /16 FM path
     c1      config 0's chain batched: low_pass boxcar /10 + -A fast, 256 x 64 x 262144 B @2.4 MS/s
     wbfm    rtl_fm -M wbfm: boxcar /6, -A fast, deemph, low_pass_real 170k -> 32k, 1024 x 16 x 262144 B
     c3      4096 NBFM streams @1.024 MS/s: 6x fifth_order + FIR9 (/64), deemph, arbitrary_resample -> 22050
@@ -34,8 +36,10 @@ Besides the contract fields the line carries
                        pattern and none of its arithmetic (rtlfm_gpu_bw_probe): read only, and read + write at the
                        workload's own byte ratio; roofline.frac_of_ceiling = achieved / that read+write ceiling.
                        `frac` stays against the nominal 8 TB/s; the two together tell box from code.
-  also                 (default workload) north_star's shape through the same kernel in the same invocation:
-                       4096 streams x 4 buffers and x 1 buffer of 262144 B per launch
+  also                 (default workload) the other BASELINE shapes in the same invocation, each with its own
+                       HIP-event launch_ms, wall ms_per_step, frac / step_frac and frac_of_ceiling: ns4096x1 (one
+                       buffer per stream per launch: what a live capture hands over per callback round) and c2
+                       on the resident bytes, then c3, c1, wbfm and c4 (valu_issue) on inputs of their own
   e2e                  host buffers through rtlfm_gpu_push / _run / _fetch_all (PCIe-inclusive; never `value`)
   cpu_baseline         the reference's own code (oracle/_ref) or the oracle port on the host cores
 """
@@ -73,7 +77,7 @@ def parse():
     # a launch is ~0.9 ms; after idle the GPU needs ~50 of them to reach its steady clock
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ns4096")
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=None, help="callback buffers (c4: reads) per stream per step")
     ap.add_argument("--block-len", type=int, default=None)
@@ -92,7 +96,8 @@ def parse():
     ap.add_argument("--e2e", type=int, default=1, help="1: also time the PCIe-inclusive push / run / fetch path (N = 1)")
     ap.add_argument("--ceiling", type=int, default=1, help="1: measure this box's streaming ceilings (roofline.ceiling)")
     ap.add_argument("--colocate", type=int, default=0, help="1: leave the output wherever the allocator puts it (normally the input's HBM quarter)")
-    ap.add_argument("--also", type=int, default=1, help="1: default workload also times north_star's 4096-stream shapes")
+    ap.add_argument("--also", type=int, default=1, help="1: the default workload also times the other BASELINE shapes (short legs)")
+    ap.add_argument("--also-steps", type=int, default=200, help="timed launches per `also` leg (after 100 untimed)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scatter", action="store_true",
                     help="N > 1: also time shard.scatter_streams (root GPU -> its owner GPUs) of one step's IQ over RCCL")
@@ -148,12 +153,10 @@ def dominant_kernel(a) -> str:
     return "k_boxcar_scan" if a.boxcar else "k_fused"
 
 
-def pmc_traffic(a):
-    """HBM bytes per launch of the dominant kernel, measured now, on this box: two child runs of this
-    script under `rocprofv3 --pmc` (one counter per run, no tracing domains, as MI355X_MICROARCH.md
-    prescribes), started before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB at
-    the L2's memory side; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane
-    streaming loads at 64 bytes, so it is doubled (same guide)."""
+def pmc_counters(a, counters):
+    """Per-launch averages of hardware counters for the dominant kernel of workload `a`, measured now, on this
+    box: one child run of this script under `rocprofv3 --pmc` per counter (no tracing domains, as
+    MI355X_MICROARCH.md prescribes), started before this process touches the GPU.  None if anything fails."""
     rp = shutil.which("rocprofv3")
     if not rp:
         return None
@@ -170,16 +173,16 @@ def pmc_traffic(a):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in counters:
             d = os.path.join(tmp, ctr)
             cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + base
             t0 = time.perf_counter()
             try:
                 r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=240)
             except subprocess.TimeoutExpired:
-                print(f"bench.py: rocprofv3 --pmc {ctr} did not finish in 240 s; roofline.traffic left null", file=sys.stderr)
+                print(f"bench.py: rocprofv3 --pmc {ctr} did not finish in 240 s; left null", file=sys.stderr)
                 return None
-            print(f"bench.py: rocprofv3 --pmc {ctr} pass took {time.perf_counter() - t0:.0f} s", file=sys.stderr)
+            print(f"bench.py: rocprofv3 --pmc {ctr} pass ({a.workload}) took {time.perf_counter() - t0:.0f} s", file=sys.stderr)
             if r.returncode != 0:
                 print(f"bench.py: rocprofv3 --pmc {ctr} failed ({r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
                 return None
@@ -196,10 +199,33 @@ def pmc_traffic(a):
             out[ctr] = sum(big) / len(big)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def pmc_traffic(a):
+    """HBM bytes per launch of the dominant kernel.  FETCH_SIZE / WRITE_SIZE count KiB at the L2's memory side;
+    on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane streaming loads at 64 bytes, so it
+    is doubled (MI355X_MICROARCH.md)."""
+    out = pmc_counters(a, ("FETCH_SIZE", "WRITE_SIZE"))
+    if not out:
+        return None
     fetch_b, write_b = 2.0 * out["FETCH_SIZE"] * 1024.0, out["WRITE_SIZE"] * 1024.0
     return {"bytes": int(fetch_b + write_b), "fetch_bytes": int(fetch_b), "write_bytes": int(write_b),
-            "kernel": pat, "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this invocation on this box; "
+            "kernel": dominant_kernel(a), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this invocation on this box; "
                                   "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B), KiB -> bytes"}
+
+
+def workload_args(a, name):
+    """a copy of the parsed arguments with workload `name`'s shape"""
+    import copy
+    b = copy.copy(a)
+    b.workload = name
+    for k, v in WORKLOADS[name].items():
+        setattr(b, k, v)
+    b.rdc, b.path = 0, 0
+    if b.boxcar:
+        b.passes, b.fir9 = 0, 0
+    return b
 
 
 # --------------------------------------------------------------- CPU baseline ----
@@ -393,7 +419,7 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
                                     "what": "the same loop with rtlfm_gpu_acquire / _commit: the producer writes the pinned ring slot itself "
                                             "(here a repeating 64 KiB pattern per buffer: what a receiving socket or a DMA-capable device layer "
                                             "leaves behind), no memcpy between producer and H2D"}
-            if a.workload == "c2":
+            if a.workload in ("c2", "ns4096"):
                 # BASELINE configs[4]'s per-GPU share end to end: 4096 NBFM streams, /64 + FIR9 + deemph + arbitrary_resample
                 from rtlsdr_amd.capi import RESAMPLE_ARBITRARY, load
                 c3 = RtlfmCfg.default(downsample=64, downsample_passes=6, comp_fir_size=9, rate_out=16000, deemph=1,
@@ -453,10 +479,11 @@ class ApartRows:
         from rtlsdr_amd.capi import check, load
         self.lib = load()
         self.rows, self.cols = rows, cols
-        p, apart = C.c_void_p(), C.c_int()
-        check(self.lib.rtlfm_gpu_malloc_apart(device, rows * cols * 2, other_ptr, other_bytes, C.byref(p), C.byref(apart)),
-              "rtlfm_gpu_malloc_apart")
+        p, apart, ms, walked = C.c_void_p(), C.c_int(), C.c_double(), C.c_size_t()
+        check(self.lib.rtlfm_gpu_malloc_apart_ex(device, rows * cols * 2, other_ptr, other_bytes, 80 << 30, C.byref(p), C.byref(apart),
+                                                 C.byref(ms), C.byref(walked)), "rtlfm_gpu_malloc_apart_ex")
         self.ptr, self.apart = p.value, bool(apart.value)
+        self.search_ms, self.walked_mb = round(ms.value, 1), walked.value >> 20  # what finding the placement cost
 
     def data_ptr(self):
         return self.ptr
@@ -492,61 +519,106 @@ def ceiling_leg(job, local_rank):
                    "output: config.output_apart), read_write_colocated = both inside one allocation"}
 
 
-def also_leg(a, job, local_rank, ceiling):
-    """north_star's shape ("4096 batched 2.4 MS/s streams") through the same kernel, same invocation, same
-    bytes: the resident 4 GiB of IQ re-read as 4096 streams x 4 buffers of 262144 B per launch, and as
-    4096 x 1 buffer per launch (what a live capture delivers per callback round, src/rtl_fm.c:1339-1343)."""
+def _timed(job, warm, K):
+    """warm untimed steps, then K timed ones: (HIP-event ms per front-end launch, wall ms per step)."""
+    for _ in range(warm):
+        job.step()
+    job.sync()
+    job.g.timing_enable(True); job.g.timing_read()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        job.step()
+    job.sync()
+    dt = time.perf_counter() - t0
+    ms, cnt = job.g.timing_read()
+    job.g.timing_enable(False)
+    return ms / max(cnt, 1), dt / K * 1e3
+
+
+def _leg_entry(name, job, launch_ms, step_ms, K, ceiling):
+    alg = job.alg_bytes_per_sample * job.samples
+    ach = alg / (launch_ms * 1e-3) / 1e9
+    e = {"workload": f"{name}: " + job.describe(), "kernel": job.kernel_name(), "steps": K,
+         "launch_ms": round(launch_ms, 4), "ms_per_step": round(step_ms, 4),
+         "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+         # the whole step (front end + whatever follows it on the GPU: the audio tail), wall clock
+         "step_frac": round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "value": round(job.samples / (step_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+         "algorithmic_bytes_per_sample": round(job.alg_bytes_per_sample, 5)}
+    if getattr(job, "output_apart", None) is not None:
+        e["output_apart"] = job.output_apart
+    if ceiling and job.a.tail != "power":
+        e["frac_of_ceiling"] = round(ach / ceiling["read_write"], 4)
+    return e
+
+
+def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
+    """Every other BASELINE shape, timed by this invocation on this box (so that each has a driver-run figure):
+    `ns4096x1` and `c2` re-read the default workload's resident 4 GiB (4096 streams x ONE buffer per launch - what
+    a live capture hands over per callback round, src/rtl_fm.c:1339-1343 - and configs[1]'s 256 streams x 64
+    buffers); `c3`, `c1`, `wbfm`, `c4` get inputs of their own.  100 untimed + --also-steps timed launches each."""
     import torch
     from rtlsdr_amd.capi import RtlfmCfg
     from rtlsdr_amd.demod import GpuDemod
-    L = a.block_len
+    out = {}
+    L, K = a.block_len, a.also_steps
     total = job.iq.numel()
-    S = 4096
-    if total % (S * L) or total // (S * L) < 4:
-        return None
-    per_stream = total // S
-    out = []
-    for nb in (4, 1):
-        cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
-        cfg.max_blocks = nb
-        with GpuDemod(cfg, S, local_rank) as g:
-            cap = g.result_cap(nb)
-            o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
-            n = torch.zeros(S, dtype=torch.int32, device=job.iq.device)
 
-            def step():
-                g.run_device(job.iq.data_ptr(), per_stream, nb, o.data_ptr(), o.stride(0), n.data_ptr())
-            for _ in range(100 if nb == 4 else 400):
-                step()
-            g.sync()
-            g.timing_enable(True); g.timing_read()
-            K = 200 if nb == 4 else 800
-            t0 = time.perf_counter()
-            for _ in range(K):
-                step()
-            g.sync()
-            dt = time.perf_counter() - t0
-            ms, cnt = g.timing_read()
-            segs = None
-            g.clock_probe(True)
-            step()
-            st = g.clock_stamps()
-            g.clock_probe(False)
+    class Reuse:
+        """the resident bytes through the default chain under another (streams, buffers) shape"""
+
+        def __init__(self, S, nb, per_stream):
+            self.a = a
+            self.S, self.nb, self.per_stream = S, nb, per_stream
+            cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
+            cfg.max_blocks = nb
+            self.g = GpuDemod(cfg, S, local_rank)
+            self.o = ApartRows(S, self.g.result_cap(nb), job.iq.data_ptr(), job.iq.numel(), local_rank)
+            self.output_apart = self.o.apart
+            self.n = torch.zeros(S, dtype=torch.int32, device=dev)
+            self.samples = S * nb * L // 2
+            self.alg_bytes_per_sample = job.alg_bytes_per_sample
+
+        def step(self):
+            self.g.run_device(job.iq.data_ptr(), self.per_stream, self.nb, self.o.data_ptr(), self.o.stride(0), self.n.data_ptr())
+
+        def sync(self):
+            self.g.sync()
+
+        def describe(self):
+            return (f"{self.S} streams/GPU x {self.nb} buffer(s) x {L} B per launch, the default workload's chain and bytes")
+
+        def kernel_name(self):
+            return job.kernel_name()
+
+        def close(self):
+            self.g.close(); self.o.free()
+
+    if a.workload == "ns4096" and not a.boxcar and total == 4096 * 4 * L:
+        for name, S, nb, per in (("ns4096x1", 4096, 1, total // 4096), ("c2", 256, 64, total // 256)):
+            r = Reuse(S, nb, per)
+            launch_ms, step_ms = _timed(r, 400 if nb == 1 else 100, 4 * K if nb == 1 else K)
+            e = _leg_entry(name, r, launch_ms, step_ms, 4 * K if nb == 1 else K, ceiling)
+            r.g.clock_probe(True); r.step(); st = r.g.clock_stamps(); r.g.clock_probe(False); r.sync()
             if st is not None:
-                segs = len(st) // S
-            g.sync()
-        o.free()
-        samples = S * nb * L // 2
-        alg = job.alg_bytes_per_sample * samples
-        launch_ms = ms / max(cnt, 1)
-        ach = alg / (launch_ms * 1e-3) / 1e9
-        e = {"workload": f"ns4096x{nb}: 4096 streams x {nb} buffer(s) x {L} B per launch, same chain",
-             "launch_ms": round(launch_ms, 4), "ms_per_step": round(dt / K * 1e3, 4), "steps": K,
-             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-             "value": round(samples * K / dt / 1e6, 1), "waves_per_stream": segs}
-        if ceiling:
-            e["frac_of_ceiling"] = round(ach / ceiling["read_write"], 4)
-        out.append(e)
+                e["waves_per_stream"] = len(st) // S
+            out[name] = e
+            r.close()
+    for name in ("c3", "c1", "wbfm", "c4"):
+        b = workload_args(a, name)
+        try:
+            j = (PowerJob if b.tail == "power" else FmJob)(b, dev, local_rank, rank)
+        except Exception as ex:  # noqa: BLE001 - a leg that cannot be set up is reported, not fatal
+            out[name] = {"error": repr(ex)}
+            continue
+        launch_ms, step_ms = _timed(j, 100, K)
+        e = _leg_entry(name, j, launch_ms, step_ms, K, ceiling)
+        if b.tail == "power":
+            e["valu_issue"] = j.valu_issue(launch_ms, valu_insts)
+        out[name] = e
+        j.close()
+        del j
+        torch.cuda.empty_cache()
     return out
 
 
@@ -632,6 +704,7 @@ class FmJob:
         self.out = (torch.empty((S, cap), dtype=torch.int16, device=dev) if a.colocate
                     else ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank))
         self.output_apart = bool(getattr(self.out, "apart", False))
+        self.placement = {"search_ms": getattr(self.out, "search_ms", None), "walked_mb": getattr(self.out, "walked_mb", None)}
         self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
         self.local_rank = local_rank
         # u8 I + u8 Q in, int16 PCM out at 1/D (x the resampling ratio)
@@ -728,6 +801,26 @@ class PowerJob:
         sample = self.iq[:cs, :2 * self.a.block_len].contiguous().cpu().numpy()
         return cpu_baseline_power(self.cfg, sample, seconds, gate)
 
+    def valu_issue(self, launch_ms, valu_insts):
+        """The launch time the kernel's integer VALU instruction count alone takes: SQ_INSTS_VALU of a launch (this
+        invocation's own rocprofv3 --pmc child; wave-instructions) x 4 cycles of issue each, over 1024 SIMDs at the
+        shader clock the kernel's workgroups measured themselves (rtlpower_gpu_clock_probe)."""
+        self.g.clock_probe(True)
+        for _ in range(3):
+            self.step()
+        clk = self.g.clock_read()
+        self.g.clock_probe(False)
+        out = {"shader_mhz": round(clk[0], 0) if clk else None, "valu_insts_per_launch": valu_insts,
+               "how": "SQ_INSTS_VALU per launch from this invocation's rocprofv3 --pmc child run; shader clock from the kernel's own "
+                      "s_memtime / s_memrealtime stamps; floor = insts x 4 cycles / (1024 SIMDs x clock)"}
+        if valu_insts:
+            out["lane_ops_per_sample"] = round(valu_insts * 64.0 / self.samples, 2)
+            if clk:
+                floor_ms = valu_insts * 4.0 / (1024 * clk[0] * 1e6) * 1e3
+                out["floor_ms"] = round(floor_ms, 3)
+                out["frac"] = round(floor_ms / launch_ms, 3)
+        return out
+
     def describe(self):
         a = self.a
         return (f"rtl_power -w hamming: {a.streams} streams/GPU x {a.blocks} reads x {a.block_len} B u8 IQ @{a.fs / 1e6:g} MS/s, "
@@ -749,7 +842,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
     # Before this process touches the GPU: build (hipcc / gcc children) and the PMC child runs.
-    traffic = None
+    traffic, c4_valu = None, None
     under_profiler = any("ROCPROF" in k for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if under_profiler:
         # rocprofv3's preloaded library has initialised the GPU in this process already: nothing here may
@@ -769,6 +862,10 @@ def main():
         want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1)
         if want_pmc and rank == 0 and world == 1:
             traffic = pmc_traffic(a)
+            # rtl_power's bound is VALU issue: its instruction count comes from this invocation too
+            if a.tail == "power" or (a.workload == "ns4096" and a.also and not a.boxcar and not a.rdc):
+                v = pmc_counters(a if a.tail == "power" else workload_args(a, "c4"), ("SQ_INSTS_VALU",))
+                c4_valu = v["SQ_INSTS_VALU"] if v else None
 
     import torch
     if not torch.cuda.is_available():
@@ -850,8 +947,8 @@ def main():
     ceiling, also = None, None
     if rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child and a.ceiling:
         ceiling = ceiling_leg(job, local_rank)
-        if a.workload == "c2" and a.also and not a.boxcar:
-            also = also_leg(a, job, local_rank, ceiling)
+        if a.workload == "ns4096" and a.also and not a.boxcar and not a.rdc:
+            also = also_legs(a, job, dev, local_rank, rank, ceiling, c4_valu)
 
     e2e = None
     if a.e2e and rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child:
@@ -901,15 +998,9 @@ def main():
             # the whole step (front end + audio tail kernels), wall clock
             roof["step_frac"] = round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
         if a.tail == "power":
-            # 83 integer lane-operations per 2-byte sample (PMC, profiles/r03_pmc_c4_k_power_scan.txt): the bound is
-            # VALU issue, 1024 SIMDs x 16 lanes per cycle at the 2.4 GHz the part holds under this kernel
-            lane_ops, simds, ghz = 83.0, 1024, 2.4
-            valu_floor_ms = lane_ops * (a.streams * a.blocks * a.block_len / 2) / (simds * 16 * ghz * 1e9) * 1e3
-            roof["note"] = ("not HBM-bound: 83 integer lane-operations per 2-byte sample in LDS-resident radix-2 stages; "
-                            "valu_issue = the launch time that instruction count alone takes (DESIGN.md section 4.5)")
-            roof["valu_issue"] = {"floor_ms": round(valu_floor_ms, 3), "frac": round(valu_floor_ms / (front_ms / max(launches, 1)), 3),
-                                  "lane_ops_per_sample": lane_ops, "how": "SQ_INSTS_VALU x 64 / samples from the committed PMC pass; "
-                                  "not re-measured by this invocation"}
+            roof["note"] = ("not HBM-bound: integer VALU issue in LDS-resident radix-2 stages; valu_issue = the launch time "
+                            "the instruction count alone takes at the clock the launch ran at (DESIGN.md section 4.5)")
+            roof["valu_issue"] = job.valu_issue(front_ms / max(launches, 1), c4_valu)
         if sustained:
             n_s, dt, s_launch = sustained
             roof["sustained"] = {
@@ -949,6 +1040,7 @@ def main():
                 "requested_gpus": int(os.environ.get("RTLFM_BENCH_REQUESTED_GPUS", a.gpus)),
                 "prewarm_steps": prewarm,
                 "output_apart": getattr(job, "output_apart", None),
+                "output_placement": getattr(job, "placement", None),
                 "device": torch.cuda.get_device_name(local_rank),
             },
             "roofline": roof,

@@ -163,7 +163,8 @@ int rtlfm_gpu_destroy(rtlfm_gpu *h);
  * stage sees that buffer's own length).
  * Callable from the thread that runs rtlsdr_read_async, concurrently for different streams and
  * concurrently with rtlfm_gpu_run(): the ring has two halves, and a callback never waits for a
- * transfer or a kernel.  -ENOSPC when max_blocks buffers are already queued for the stream.
+ * transfer or a kernel.  -ENOSPC when max_blocks buffers are already queued for the stream, -EBUSY while
+ * the stream has a slot open between rtlfm_gpu_acquire() and rtlfm_gpu_commit() (one producer per stream).
  */
 int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint32_t len);
 
@@ -272,7 +273,17 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   deemph_four_pass     1: no one-pass (speculative) deemph kernels
  *   lpr_separate         1: low_pass_real as a kernel of its own behind deemph_filter
  *   lpr_scalar_stores    1: the resampler's outputs one by one
- *   lpr_chunk            samples per lane of the one-pass deemph + low_pass_real kernel (default 2720; >= 256)
+ *   lpr_chunk            samples per lane of the one-pass deemph + low_pass_real kernel (default 2720; 256 ... 2^20,
+ *                        anything else -EINVAL)
+ *   apart_budget_gb      most device memory (GiB, default 80, never more than half of what is free) a placement
+ *                        search may hold in temporary allocations; 0 = no search, plain allocations
+ * Read-only (rtlfm_gpu_get_option):
+ *   ring_apart           1 / 0: the result buffers behind rtlfm_gpu_push() / _run() are / are not a quarter of the HBM
+ *                        away from the ring's device input; -1 before the ring exists (it is built by the first push)
+ *   res_apart            the same for the audio tail's work buffers against the first run's input (-1: none yet;
+ *                        0 also on a caller-owned stream, where no search is made)
+ *   placement_ms         wall time the placement searches of this handle took, in all
+ *   placement_walked_mb  most a search held in temporary allocations (MiB)
  *   tail_sync            1: synchronise and report after every tail kernel (debugging)
  *   fused_debug          clock-stamp experiments (2 / 18 / 4, see fused_kernel.h)
  * Returns -ENOENT for an unknown name, -EINVAL for a value out of range.
@@ -369,6 +380,11 @@ int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream
  */
 int rtlfm_gpu_malloc(int device, size_t bytes, void **out);
 int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart);
+/* The same with the search's cost in the open: budget_bytes = most the filler walk may hold (0: no search, plain
+ * memory; rtlfm_gpu_malloc_apart uses 80 GiB; never more than half of the free device memory is taken),
+ * *search_ms = wall time of the call, *walked_bytes = most it held at once (either may be NULL). */
+int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
+                              void **out, int *apart, double *search_ms, size_t *walked_bytes);
 int rtlfm_gpu_placement_probe(int device, const void *in, size_t in_bytes, void *out, size_t out_bytes,
                               double *read_ms, double *rw_ms);
 int rtlfm_gpu_free(void *p);

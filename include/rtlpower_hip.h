@@ -91,8 +91,10 @@ int rtlpower_csv_dbm(const rtlpower_plan *plan, int tune, int64_t *avg, int32_t 
 /* window_coefs[i] = (int)(256 * window_fn(i, length)) (src/rtl_power.c:985-988); host only */
 int rtlpower_window_coefs(int window, int length, int32_t *out);
 
-/* What rtlpower_gpu_create() accepts, without a GPU: 0, or the error it would return (-EINVAL; -ENOTSUP
- * for bin_e 15..21).  Outside scanner()'s own domain - a trailing FFT frame that reaches past the read,
+/* What rtlpower_gpu_create() accepts, without a GPU: 0, or the error it would return (-EINVAL).  bin_e runs to 21,
+ * what frequency_range() can plan (src/rtl_power.c:483-486): up to 2^14 points per read the transform lives in a
+ * workgroup's LDS, beyond that (bin_e 15 ... 21, or more frames per read) the same stages run over a work buffer in HBM.
+ * Outside scanner()'s own domain - a trailing FFT frame that reaches past the read,
  * where the reference transforms whatever its static fft_buf still holds (src/rtl_power.c:695) - is refused. */
 int rtlpower_cfg_validate(const rtlpower_cfg *cfg);
 int rtlpower_gpu_create(const rtlpower_cfg *cfg, int nstreams, int device, rtlpower_gpu **out);
@@ -123,6 +125,15 @@ int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long value);
 /* HIP-event timing of the FFT kernel, as rtlfm_gpu_timing_*. */
 int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on);
 int rtlpower_gpu_timing_read(rtlpower_gpu *h, double *ms, int *launches);
+/*
+ * In-kernel clock probe of the large-FFT kernel (bin_e 13 / 14, one frame per read, raw input), as
+ * rtlfm_gpu_clock_probe: with probe(1) every workgroup of a launch records the shader clock counter and the
+ * 100 MHz real-time counter at its first and last instruction; read() synchronises and returns the mean shader
+ * clock (MHz) of the LAST launch and the span from the first workgroup's start to the last one's end (ms), or
+ * -ENODATA.  This path is bound by integer VALU issue, which scales with that clock.
+ */
+int rtlpower_gpu_clock_probe(rtlpower_gpu *h, int on);
+int rtlpower_gpu_clock_read(rtlpower_gpu *h, double *shader_mhz, double *span_ms);
 
 #ifdef __cplusplus
 }

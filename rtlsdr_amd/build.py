@@ -23,6 +23,31 @@ def _hipcc() -> str:
     raise FileNotFoundError("hipcc not found")
 
 
+OBJDIR = os.path.join(CSRC, "build")
+# which headers a translation unit sees (a header change recompiles only the units that include it)
+UNIT_HEADERS = {
+    "rtlfm_hip.hip": ["dsp_device.h", "staged_kernels.h", "fused_kernel.h", "boxcar_kernel.h", "bw_probe_kernel.h",
+                      os.path.join("..", "..", "include", "rtlfm_hip.h")],
+    "rtlpower_hip.hip": ["dsp_device.h", "power_kernels.h", os.path.join("..", "..", "include", "rtlpower_hip.h"),
+                         os.path.join("..", "..", "include", "rtlfm_hip.h")],
+}
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+
+
+def _unit_stale(src: str) -> bool:
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in UNIT_HEADERS[src]]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
@@ -33,11 +58,22 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
+    """One object per translation unit (compiled side by side), then one link: librtlfm_hip.so."""
     if not force and not needs_build():
         return OUT
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
-           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + (extra or [])
+    os.makedirs(OBJDIR, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        if not (force or extra or _unit_stale(src)):
+            continue
+        cmd = [_hipcc()] + FLAGS + ["-c", "-o", _obj(src), os.path.join(CSRC, src)] + (extra or [])
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", OUT] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

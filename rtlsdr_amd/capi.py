@@ -204,6 +204,8 @@ _SIGNATURES = [
     ("rtlfm_gpu_rotate_90_u8", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rtlfm_gpu_malloc", C.c_int, [C.c_int, C.c_size_t, _P(C.c_void_p)]),
     ("rtlfm_gpu_malloc_apart", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_void_p), _P(C.c_int)]),
+    ("rtlfm_gpu_malloc_apart_ex", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, _P(C.c_void_p), _P(C.c_int),
+                                            _P(C.c_double), _P(C.c_size_t)]),
     ("rtlfm_gpu_placement_probe", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_double), _P(C.c_double)]),
     ("rtlfm_gpu_free", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_device_numa_node", C.c_int, [C.c_int]),
@@ -244,6 +246,8 @@ _POWER_SIGNATURES = [
     ("rtlpower_gpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     ("rtlpower_gpu_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlpower_gpu_timing_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int)]),
+    ("rtlpower_gpu_clock_probe", C.c_int, [C.c_void_p, C.c_int]),
+    ("rtlpower_gpu_clock_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double)]),
 ]
 _SIGNATURES = _SIGNATURES + _POWER_SIGNATURES
 

@@ -1094,6 +1094,12 @@ inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
 	return sp;
 }
 
+// the pass-0 engine a launch will use: the handle's choice, else the compiled default
+inline int effective_engine(const Workspace &ws)
+{
+	return ws.pass0_engine >= 0 ? ws.pass0_engine : (RTLFM_PASS0_DEFAULT ? 1 : 0);
+}
+
 // What the front end in emit mode plus staged kernels covers beyond supported(): 7..10 passes,
 // -M raw, and the squelch (rtlfm_hip.hip: run_fused_emit)
 inline bool supported_emit(const rtlfm_cfg &c)
@@ -1168,8 +1174,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	// of mixing the PCM stores into the read stream, and with that it is the faster engine at
 	// every decimation depth on MI355X (tools/ab_engines.py, interleaved launches: 6 % at 4
 	// passes, 11 % at 5).  The v_dot4 form needs no matrix pipe and no LDS staging.
-	int engine = ws.pass0_engine;
-	if (engine < 0) engine = RTLFM_PASS0_DEFAULT ? 1 : 0;
+	const int engine = effective_engine(ws);
 	if (rdc_avg && engine != 1) return -ENOTSUP;
 	if (engine == 1) {
 		uint32_t *&t = ws.mfma_taps[p.rotate];

@@ -19,6 +19,7 @@
 #include <pthread.h>
 
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -55,7 +56,9 @@ double atofs(const char *s)
 struct Plumbing {
 	std::mutex m;
 	std::condition_variable cv_room, cv_work, cv_out;
-	int queued = 0;
+	int queued = 0;          // buffers committed to the ring and not yet handed to rtlfm_gpu_run()
+	bool slot_open = false;  // -Z: the device layer is writing into a slot of the ring (acquire ... commit)
+	bool want_run = false;   // the demod thread is about to run: no new slot is handed out until it has
 	bool eof = false, failed = false;
 	std::deque<std::vector<int16_t>> out_q;
 	bool out_done = false;
@@ -84,14 +87,21 @@ struct App {
 int next_slot(void *ctx, unsigned char **buf, uint32_t *cap)
 {
 	App *a = static_cast<App *>(ctx);
+	// rtlfm_gpu_run() refuses to start while a slot is open (it takes every buffer whole or not at all), and
+	// this thread asks for its next slot the moment a callback returns: the slot is handed out under the
+	// plumbing's lock, and not while the demod thread has announced a run or the ring is full - otherwise
+	// the demod thread would hardly ever find the ring closed and committed buffers would sit there.
+	std::unique_lock<std::mutex> g(a->p.m);
 	for (;;) {
+		a->p.cv_room.wait(g, [&] { return (!a->p.want_run && a->p.queued < a->cfg.max_blocks) || a->p.failed; });
+		if (a->p.failed) return -1;
 		uint8_t *p = nullptr;
 		int r = rtlfm_gpu_acquire(a->gpu, 0, &p, cap);
-		if (r == 0) { a->open_slot = p; *buf = p; return 0; }
+		if (r == 0) { a->open_slot = p; a->p.slot_open = true; *buf = p; return 0; }
 		if (r != -ENOSPC) return r;  // not fatal: the device layer falls back to its own buffer and the callback pushes
-		std::unique_lock<std::mutex> g(a->p.m);
-		a->p.cv_room.wait(g, [&] { return a->p.queued < a->cfg.max_blocks || a->p.failed; });
-		if (a->p.failed) return -1;
+		// the ring's filling half is full although `queued` says otherwise (a run that has not flipped the halves
+		// yet): wait for the demod thread's next notification instead of spinning
+		a->p.cv_room.wait_for(g, std::chrono::milliseconds(2));
 	}
 }
 
@@ -105,6 +115,7 @@ void on_buffer(unsigned char *buf, uint32_t len, void *ctx)
 		a->open_slot = nullptr;
 		int r = rtlfm_gpu_commit(a->gpu, 0, len);
 		std::lock_guard<std::mutex> g(a->p.m);
+		a->p.slot_open = false;
 		if (r < 0) {
 			fprintf(stderr, "rtlfm_gpu_commit: %s\n", rtlfm_gpu_strerror(r));
 			a->p.failed = true;
@@ -113,29 +124,30 @@ void on_buffer(unsigned char *buf, uint32_t len, void *ctx)
 			a->p.queued++;
 			a->blocks_in++;
 		}
-		a->p.cv_work.notify_one();
+		a->p.cv_work.notify_all();
 		return;
 	}
 	if (len == 0) return;
+	// the copy is made under the plumbing's lock and not while the demod thread has announced a run: `queued`
+	// is then exactly what the ring holds when rtlfm_gpu_run() takes it
+	std::unique_lock<std::mutex> g(a->p.m);
 	for (;;) {
+		a->p.cv_room.wait(g, [&] { return (!a->p.want_run && a->p.queued < a->cfg.max_blocks) || a->p.failed; });
+		if (a->p.failed) return;
 		int r = rtlfm_gpu_push(a->gpu, 0, buf, len);
 		if (r == 0) break;
 		if (r != -ENOSPC) {
 			fprintf(stderr, "rtlfm_gpu_push: %s\n", rtlfm_gpu_strerror(r));
-			std::lock_guard<std::mutex> g(a->p.m);
 			a->p.failed = true;
 			rtlsdr_cancel_async(a->dev);  // the reference's error pattern, src/rtl_sdr.c:109-112
 			a->p.cv_work.notify_all();
 			return;
 		}
-		std::unique_lock<std::mutex> g(a->p.m);
-		a->p.cv_room.wait(g, [&] { return a->p.queued < a->cfg.max_blocks || a->p.failed; });
-		if (a->p.failed) return;
+		a->p.cv_room.wait_for(g, std::chrono::milliseconds(2));
 	}
-	std::lock_guard<std::mutex> g(a->p.m);
 	a->p.queued++;
 	a->blocks_in++;
-	a->p.cv_work.notify_one();
+	a->p.cv_work.notify_all();
 }
 
 void dongle_thread(App *a)
@@ -151,18 +163,26 @@ void demod_thread(App *a)
 {
 	const int cap = rtlfm_result_cap(&a->cfg) * a->cfg.max_blocks + 16;
 	for (;;) {
+		int taken = 0;
 		{
 			std::unique_lock<std::mutex> g(a->p.m);
 			a->p.cv_work.wait(g, [&] { return a->p.queued > 0 || a->p.eof || a->p.failed; });
 			if (a->p.failed || (a->p.queued == 0 && a->p.eof)) break;
-			a->p.queued = 0;  // rtlfm_gpu_run takes everything that is queued
+			// -Z: no new slot from here on (next_slot), and the one that is open is committed first
+			a->p.want_run = true;
+			a->p.cv_work.wait(g, [&] { return !a->p.slot_open || a->p.failed; });
+			if (a->p.failed) break;
+			taken = a->p.queued;  // rtlfm_gpu_run takes everything that is queued
 		}
 		int r = rtlfm_gpu_run(a->gpu);
 		{
 			std::lock_guard<std::mutex> g(a->p.m);
+			a->p.want_run = false;
+			// the count goes down only for a run that has started: on -EAGAIN the buffers are still in the ring
+			if (r == 0) a->p.queued -= taken;
 			a->p.cv_room.notify_all();
 		}
-		if (r == -EAGAIN) continue;
+		if (r == -EAGAIN) { std::this_thread::yield(); continue; }
 		std::vector<int16_t> pcm((size_t)cap);
 		int n = 0;
 		if (r == 0) r = rtlfm_gpu_fetch(a->gpu, 0, pcm.data(), cap, &n);

@@ -238,7 +238,10 @@ int rtlsdr_read_async(rtlsdr_dev_t *d, rtlsdr_read_async_cb_t cb, void *ctx, uin
 		if (d->source) {
 			/* the consumer's own memory (e.g. a slot of the GPU layer's pinned ring): read straight into it */
 			unsigned char *p = NULL;
-			if (d->source(d->source_ctx, &p, &cap) == 0 && p && cap >= buf_len) dst = p;
+			if (d->source(d->source_ctx, &p, &cap) == 0 && p) {
+				if (cap >= buf_len) dst = p;
+				else if (cb) cb(p, 0, ctx);  /* too small for a transfer: handed back unused (0 bytes), our own buffer instead */
+			}
 		}
 		size_t got = read_some(d, dst, buf_len);
 		if (got == 0 && dst == bufs[k]) break;  /* end of file */

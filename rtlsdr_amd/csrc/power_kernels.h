@@ -54,6 +54,7 @@ struct ScanParams {
 	long long *avg;          // [stream][N]
 	int32_t *samples;        // [stream]
 	int groups;              // workgroups per stream: group g takes reads [g, g + 1) * nreads / groups
+	unsigned long long *stamps;  // rtlpower_gpu_clock_probe: [workgroups][4] shader clock first / last, 100 MHz counter first / last
 };
 
 // FIX_MPY, src/rtl_power.c:263-269
@@ -346,6 +347,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 	const int grp = (int)(blockIdx.x % p.groups);
 	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
 	if (r_begin >= r_end) return;
+	unsigned long long st_clk = 0, st_rt = 0;
+	if (p.stamps) { st_clk = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
 	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
 	// the thread's points: the BIT-REVERSED lane index in the top bits of j, so that the bit-reversed LDS
 	// address of point j0 + k has the lane itself in its low bits - consecutive lanes, consecutive dwords
@@ -493,6 +496,167 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 		else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + bin), (unsigned long long)acc[a]);
 	}
 	if (t == 0) atomicAdd(p.samples + s, p.ds * (r_end - r_begin));
+	if (p.stamps && t == 0) {
+		unsigned long long *o = p.stamps + (size_t)blockIdx.x * 4;
+		o[0] = st_clk; o[1] = __builtin_amdgcn_s_memtime(); o[2] = st_rt; o[3] = __builtin_amdgcn_s_memrealtime();
+	}
+}
+
+// ---- transforms that do not fit one workgroup's LDS: bin_e 15 ... 21, or more frames per read than 16384 points ----
+// frequency_range() plans up to 2^21 bins (src/rtl_power.c:483-486) and fix_fft (:271-327) has no size limit.  The
+// same radix-2 DIT stages, with the same FIX_MPY rounding and the same ">> 1" per stage, run over a work buffer in
+// HBM: after the bit-reversed placement, stages 0 .. 13 stay inside contiguous blocks of 16384 points (one block =
+// one workgroup's LDS, the k_power_scan machinery), and stages 14 .. E-1 are passes over the whole frame, three
+// stages per pass (a thread holds the eight points of a radix-8 group at stride 2^st in registers).  The integers
+// are those of the reference stage by stage; only where the intermediate array lives differs.
+//   k_power_dc      remove_dc's averages of every (stream, read)           (:581-596, the half-DC quirk)
+//   k_power_place   convert, DC, window (int16 wrap), bit-reversed store   (:666-668, 697-706, 282-297)
+//   k_power_fft_lds stages 0 .. min(E, 14) - 1 of every block of 2^min(E,14) points
+//   k_power_fft_gl  stages st .. st + R - 1 for st >= 14
+//   k_power_accum   avg[] += |X|^2 or peak hold over the batch's reads and frames (:708-716), samples (:717)
+struct StagedParams {
+	const uint8_t *iq8; size_t stride8;
+	const int16_t *dec; size_t dec_stream_stride, dec_read_stride; int dec_elems;
+	int nreads;              // reads of this batch
+	int buf_len, len_dec, bin_e, chunks, ds, peak_hold;
+	const int32_t *window;   // [N]
+	const uint32_t *tw;      // [N] per-stage twiddles
+	int2 *ave;               // [stream][read] (avgI, avgQ)
+	uint32_t *work;          // [stream][read][chunks][N] packed (re, im)
+	long long *avg; int32_t *samples;
+	int nstreams;
+};
+
+__device__ __forceinline__ int staged_element(const StagedParams &p, const uint8_t *raw, const int16_t *dec, int e)
+{
+	if (dec) return e < p.dec_elems ? (int)dec[e] : 0;
+	return e < p.buf_len ? (int)raw[e] - 127 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_power_dc(const StagedParams p)
+{
+	const size_t sr = blockIdx.x;  // (stream, read)
+	const size_t s = sr / p.nreads;
+	const int r = (int)(sr % p.nreads);
+	const uint8_t *raw = p.iq8 ? p.iq8 + s * p.stride8 + (size_t)r * p.buf_len : nullptr;
+	const int16_t *dec = p.dec ? p.dec + s * p.dec_stream_stride + (size_t)r * p.dec_read_stride : nullptr;
+	long long si = 0, sq = 0;
+	for (int pnt = threadIdx.x; 2 * pnt < p.len_dec; pnt += 256) {
+		si += staged_element(p, raw, dec, 2 * pnt);
+		if (2 * pnt + 1 < p.len_dec) sq += staged_element(p, raw, dec, 2 * pnt + 1);
+	}
+	__shared__ long long red[2][256];
+	red[0][threadIdx.x] = si; red[1][threadIdx.x] = sq;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)  // as k_power_scan's phase A: the sum over N/2 values divided by N (and N - 1)
+		p.ave[sr] = make_int2((int)(int16_t)(red[0][0] / (long long)p.len_dec),
+		                      p.len_dec > 1 ? (int)(int16_t)(red[1][0] / (long long)(p.len_dec - 1)) : 0);
+}
+
+__global__ void __launch_bounds__(256) k_power_place(const StagedParams p)
+{
+	const int N = 1 << p.bin_e;
+	const size_t M = (size_t)p.chunks * N;
+	const size_t total = (size_t)p.nstreams * p.nreads * M;
+	for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+		const size_t sr = g / M;
+		const int pnt = (int)(g % M);
+		const size_t s = sr / p.nreads;
+		const int r = (int)(sr % p.nreads);
+		const uint8_t *raw = p.iq8 ? p.iq8 + s * p.stride8 + (size_t)r * p.buf_len : nullptr;
+		const int16_t *dec = p.dec ? p.dec + s * p.dec_stream_stride + (size_t)r * p.dec_read_stride : nullptr;
+		const int2 a = p.ave[sr];
+		const int c = pnt >> p.bin_e, j = pnt & (N - 1);
+		int vi = staged_element(p, raw, dec, 2 * pnt), vq = staged_element(p, raw, dec, 2 * pnt + 1);
+		if (2 * pnt < p.len_dec) vi = (int16_t)(vi - a.x);
+		if (2 * pnt + 1 < p.len_dec) vq = (int16_t)(vq - a.y);
+		const int w = p.window[j];
+		vi = (int16_t)(vi * w);
+		vq = (int16_t)(vq * w);
+		const int rj = (int)(__brev((unsigned)j) >> (32 - p.bin_e));
+		p.work[sr * M + ((size_t)c << p.bin_e) + rj] = pack_iq(vi, vq);
+	}
+}
+
+// stages 0 .. eb - 1 (eb = min(bin_e, 14)) of one block of 2^eb points per workgroup
+__global__ void __launch_bounds__(kThreads) k_power_fft_lds(uint32_t *work, const uint32_t *twg, int eb, size_t nblocks_total)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+	const int B = 1 << eb;
+	uint32_t *pts = sm;                  // [skewed_size(B)]
+	uint32_t *tw = sm + skewed_size(B);  // [B]: the stages below eb use the table's first 2^eb - 1 entries
+	const int t = threadIdx.x;
+	for (int k = t; k < B; k += kThreads) tw[k] = twg[k];
+	for (size_t blk = blockIdx.x; blk < nblocks_total; blk += gridDim.x) {
+		uint32_t *w = work + blk * (size_t)B;
+		__syncthreads();
+		for (int k = t; k < B; k += kThreads) pts[skew(k)] = w[k];
+		__syncthreads();
+		for (int st = 0; st < eb;) {
+			const int R = eb - st >= 3 ? 3 : eb - st;
+			if (R == 3) fft_pass<3>(pts, tw, B, st, t);
+			else if (R == 2) fft_pass<2>(pts, tw, B, st, t);
+			else fft_pass<1>(pts, tw, B, st, t);
+			st += R;
+			__syncthreads();
+		}
+		for (int k = t; k < B; k += kThreads) w[k] = pts[skew(k)];
+	}
+}
+
+// stages st .. st + R - 1 (st >= 14) over frames of N points in HBM: one thread per group of 2^R points at stride 2^st
+template <int R>
+__global__ void __launch_bounds__(256) k_power_fft_gl(uint32_t *work, const uint32_t *tw, int bin_e, int st, size_t frames)
+{
+	constexpr int G = 1 << R;
+	const size_t per_frame = (size_t)1 << (bin_e - R);
+	const size_t total = frames * per_frame;
+	const int h = 1 << st;
+	for (size_t g0 = (size_t)blockIdx.x * 256 + threadIdx.x; g0 < total; g0 += (size_t)gridDim.x * 256) {
+		const size_t f = g0 >> (bin_e - R);
+		const int g = (int)(g0 & (per_frame - 1));
+		const int glo = g & (h - 1), ghi = g >> st;
+		uint32_t *base = work + (f << bin_e) + (((size_t)ghi << (st + R)) | (size_t)glo);
+		uint32_t x[G];
+#pragma unroll
+		for (int k = 0; k < G; k++) x[k] = base[(size_t)k << st];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint32_t *tws = tw + (((size_t)1 << (st + r)) - 1) + glo;
+#pragma unroll
+			for (int k = 0; k < G; k++) {
+				if (k & (1 << r)) continue;
+				const int kk = k & ((1 << r) - 1);
+				butterfly<0>(x[k], x[k + (1 << r)], tws[(size_t)kk * h]);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < G; k++) base[(size_t)k << st] = x[k];
+	}
+}
+
+// one thread per (stream, bin): the batch's reads and frames in order (no atomics, one owner per accumulator)
+__global__ void __launch_bounds__(256) k_power_accum(const StagedParams p)
+{
+	const int N = 1 << p.bin_e;
+	const size_t M = (size_t)p.chunks * N;
+	const size_t total = (size_t)p.nstreams * N;
+	for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+		const size_t s = g >> p.bin_e;
+		const int bin = (int)(g & (size_t)(N - 1));
+		long long a = p.avg[g];
+		for (int r = 0; r < p.nreads; r++)
+			for (int c = 0; c < p.chunks; c++) {
+				const long long pw = power_of(p.work[(s * p.nreads + r) * M + ((size_t)c << p.bin_e) + bin]);
+				a = p.peak_hold ? (pw > a ? pw : a) : a + pw;
+			}
+		p.avg[g] = a;
+		if (bin == 0) p.samples[s] += p.ds * p.chunks * p.nreads;  // :717, once per frame
+	}
 }
 
 // rms_power(), src/rtl_power.c:410-436 (bin_e == 0): one workgroup per stream

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,11 +63,14 @@ struct rtlfm_gpu {
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
-	int32_t *d_deemph_fb = nullptr;       // [nstreams] streams the one-pass filter hands to the four passes
-	int32_t *d_deemph_list = nullptr;     // [1 + nstreams] ... compacted: count, then indices (k_flag_list)
+	// the one-pass tail kernels (k_deemph_spec_arb / _lpr) settle their own stragglers: per stream a flag that
+	// carries the number of the step that raised it (nobody clears it) and a ticket counter that the stream's last
+	// workgroup leaves at zero; [2][nstreams] by step parity, since two tails may be in flight on views' streams
+	uint32_t *d_tail_flag = nullptr, *d_tail_ticket = nullptr;
 	double arb_rinv = 0;                  // k_deemph_spec_arb: RN(1 / len2) and whether it reproduces tick / len2
 	int arb_len2 = 0, arb_fast = 0;
-	int deemph_chunks = 0;
+	int deemph_chunks = 0;   // capacity of d_deemph_tab / d_deemph_inc, chunks per stream
+	int lpr_chunks_cap = 0;  // ... of d_lpr_chunks
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
 	size_t deep_stride = 0;
 	// Carried state, three copies in rotation: step k reads st[cur] and writes st[(cur + 1) % 3].
@@ -90,6 +94,14 @@ struct rtlfm_gpu {
 	int32_t *d_adc_avg = nullptr;
 	struct Ingest *ing = nullptr;     // the callback side (push / run / fetch), allocated on first use
 	bool no_deemph_scan = false;      // stream-range views (ragged runs) keep to the sequential filter
+	// placement of the write streams (rtlfm_gpu_malloc_apart_ex): what the searches found and what they cost
+	struct Placement {
+		int budget_gb = 80;             // option apart_budget_gb: most the filler walk may hold; 0 = no search
+		int ring_apart = -1;            // -1: not allocated yet; 0 / 1: the ring's result buffers (both halves) are a quarter away from d_in
+		int res_apart = -1;             // the same for the audio tail's work buffers against the first run's input
+		double search_ms = 0;           // wall time of all searches of this handle
+		size_t walked_peak = 0;         // most a search held in temporary allocations (bytes)
+	} place;
 	fused::Workspace fws;
 	// A/B switches (rtlfm_gpu_set_option); none of them changes a result
 	struct Options {
@@ -355,7 +367,8 @@ static int ensure_deep_buffers(rtlfm_gpu *h)
 	HIP_TRY(hipMalloc(&h->deepB, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
 	return 0;
 }
-extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart);
+extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
+                                         void **out, int *apart, double *search_ms, size_t *walked_bytes);
 
 // d_iq / iq_bytes: the input the first run streams from - the buffers the front end writes the demodulated
 // samples into ([parity][0]) go a quarter of the HBM away from it where they are large enough to matter
@@ -363,19 +376,34 @@ static int ensure_res_buffers(rtlfm_gpu *h, const uint8_t *d_iq = nullptr, size_
 {
 	const size_t S = (size_t)h->nstreams;
 	if (!h->res[0][0]) {
+		// The search times probe launches on the null stream and synchronises the device: not in the middle
+		// of an asynchronous call on a stream the caller owns - there the buffers are plain allocations.
+		const bool search = d_iq && h->stream == h->own_stream && h->place.budget_gb > 0;
+		int all_apart = search ? 1 : 0;
 		for (int p = 0; p < 2; p++)
 			for (int k = 0; k < 2; k++) {
 				void *q = nullptr;
-				if (k == 0 && d_iq) {
-					int r = rtlfm_gpu_malloc_apart(h->device, S * h->tstride * sizeof(int16_t), d_iq, iq_bytes, &q, nullptr);
+				if (k == 0 && search) {
+					int apart = 0; double ms = 0; size_t walked = 0;
+					int r = rtlfm_gpu_malloc_apart_ex(h->device, S * h->tstride * sizeof(int16_t), d_iq, iq_bytes,
+					                                  (size_t)h->place.budget_gb << 30, &q, &apart, &ms, &walked);
 					if (r < 0) return r;
+					h->place.search_ms += ms;
+					if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+					if (!apart) all_apart = 0;
 				} else {
 					HIP_TRY(hipMalloc(&q, S * h->tstride * sizeof(int16_t)));
 				}
 				h->res[p][k] = (int16_t *)q;
 			}
+		h->place.res_apart = all_apart;
 	}
 	return 0;
+}
+// bytes of the caller's input a run really covers: (S - 1) strides + the last stream's buffers (the stride may be padded)
+static inline size_t iq_extent(const rtlfm_gpu *h, size_t stream_stride, int nblocks)
+{
+	return (size_t)(h->nstreams - 1) * stream_stride + (size_t)nblocks * h->cfg.block_len;
 }
 
 extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
@@ -388,7 +416,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_deemph_fb, h->d_deemph_list, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_tail_flag, h->d_tail_ticket, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -497,7 +525,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"pass0_engine", &h->fws.pass0_engine},
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
-		{"tail_sync", &h->opt.tail_sync},
+		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -520,6 +548,9 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
 	if (!strcmp(name, "pass0_engine") && (value < -1 || value > 1)) return -EINVAL;
 	if ((!strcmp(name, "fused_min_tiles") || !strcmp(name, "fused_tiles_per_seg")) && value < 0) return -EINVAL;
+	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
+	// the chunk tables of the one-pass deemph + low_pass_real kernel are sized from it: keep it in a sane range
+	if (!strcmp(name, "lpr_chunk") && (value < 256 || value > (1 << 20))) return -EINVAL;
 	*slot = (int)value;
 	return 0;
 }
@@ -528,6 +559,11 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 {
 	if (!h || !name || !value) return -EINVAL;
 	if (!strcmp(name, "tail_serial")) { *value = h->tail_overlap ? 0 : 1; return 0; }
+	// read-only: where the write streams' buffers ended up (rtlfm_gpu_malloc_apart_ex) and what finding out cost
+	if (!strcmp(name, "ring_apart")) { *value = h->place.ring_apart; return 0; }
+	if (!strcmp(name, "res_apart")) { *value = h->place.res_apart; return 0; }
+	if (!strcmp(name, "placement_ms")) { *value = (long)(h->place.search_ms + 0.5); return 0; }
+	if (!strcmp(name, "placement_walked_mb")) { *value = (long)(h->place.walked_peak >> 20); return 0; }
 	int *slot = option_slot(h, name);
 	if (!slot) return -ENOENT;
 	*value = *slot;
@@ -653,6 +689,24 @@ static void tail_route(rtlfm_gpu *h, const TailPlan &tp, int16_t *final_dst, siz
 	}
 }
 
+// Does this tail run as ONE kernel (run_tail: k_deemph_spec_arb = 1, k_deemph_spec_lpr = 2), 0 if not?
+static int one_pass_tail(const rtlfm_gpu *h, const TailPlan &tp, const int16_t *cur, size_t cur_stride, int T, bool varcnt,
+                         int nblocks, int Nblk, int D)
+{
+	const rtlfm_cfg &c = h->cfg;
+	if (!tp.deemph || tp.post || tp.adc || h->opt.deemph_four_pass) return 0;
+	const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan &&
+	                  !h->opt.deemph_sequential;
+	if (!scan) return 0;
+	if (tp.lpr) return h->opt.lpr_separate ? 0 : 2;
+	if (!tp.arb) return 0;
+	const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
+	const int arb_l2 = (int)((long long)Nblk * c.rate_out2 / c.rate_out);
+	const bool ok = D == 1 && !varcnt && Nblk >= 2 && arb_l2 > Nblk && (long long)(Nblk + 1) * arb_l2 < (1ll << 31) && Ws <= 256 &&
+	                (uintptr_t)cur % 16 == 0 && cur_stride % 8 == 0 && T == nblocks * Nblk;
+	return ok ? 1 : 0;
+}
+
 // Buffer extents: buffer b of a stream owns the decimated samples [dec_block_begin(b),
 // dec_block_begin(b + 1)) of the run — Nblk input samples per buffer through a boxcar D with the
 // carried prev_index; (Nblk, 1) describes a uniform count of Nblk per buffer.
@@ -680,7 +734,9 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		// have been writing the tail's fields of sin.  The tail stream is in order, so here those are
 		// final: carry them over before any stage of this tail runs (a stage that leaves a field
 		// alone - a skipped stream, an early return - then leaves the right value behind).
-		k_tail_state_copy<<<grid_for(S, 64), 64, 0, q>>>(sin, sout, S);
+		// The one-kernel tails write every field a tail of their configuration owns, for every stream: no copy.
+		if (!one_pass_tail(h, tp, cur, cur_stride, T, varcnt, nblocks, Nblk, D))
+			k_tail_state_copy<<<grid_for(S, 64), 64, 0, q>>>(sin, sout, S);
 	}
 	struct Done {  // whatever path leaves: mark the end of this step's tail
 		rtlfm_gpu *h; int par; bool on;
@@ -712,71 +768,40 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		st.magic = 0;
 		if (pow2) { while ((1u << st.magic) < st.a) st.magic++; }
 		else if (magic) st.magic = (uint32_t)((0x100000000ull + st.a - 1) / st.a);
+		const int M = pow2 ? 2 : magic ? 1 : 0;
 		const unsigned grid = (unsigned)((S + 63) / 64);
 		// few, long streams: parallel over time (staged_kernels.h, k_deemph_scan_*); the interval
 		// of candidate states must fit a wave (2a + 2 <= kDeemphGap)
 		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan &&
 		                  !h->opt.deemph_sequential;
-		if (scan) {
-			// chunk length: each of the passes A1 and C is one chunk long in time; a chunk must be
-			// long enough for the interval to contract (~100 samples) and, normally, to merge
-			const int L = T >= 8192 ? 1024 : 512;
-			const int mc = T / L + 2;
-			if ((size_t)mc > (size_t)h->deemph_chunks) {
-				if (h->d_deemph_tab) { HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); HIP_TRY(hipFree(h->d_lpr_chunks)); }
-				h->d_deemph_tab = nullptr; h->d_deemph_inc = nullptr; h->d_lpr_chunks = nullptr;
-				HIP_TRY(hipMalloc(&h->d_deemph_tab, (size_t)S * mc * sizeof(DeemphChunk)));
-				HIP_TRY(hipMalloc(&h->d_deemph_inc, (size_t)S * mc * sizeof(uint32_t)));
-				HIP_TRY(hipMalloc(&h->d_lpr_chunks, (size_t)S * mc * sizeof(LprChunk)));
-				h->deemph_chunks = mc;
-			}
-			if (!h->d_deemph_fb) HIP_TRY(hipMalloc(&h->d_deemph_fb, (size_t)S * sizeof(int32_t)));
-			if (!h->d_deemph_list) HIP_TRY(hipMalloc(&h->d_deemph_list, ((size_t)S + 1) * sizeof(int32_t)));
-			const int mcs = mc;
-			const bool dbg_sync = h->opt.tail_sync != 0;
-			// deemph_filter followed directly by low_pass_real (-M wbfm): the replay pass feeds the
-			// resampler's accumulator instead of writing the filtered samples (staged_kernels.h)
-			fuse_lpr = tp.lpr && !tp.adc && !h->opt.lpr_separate;
-			if (fuse_lpr) next_dst(&lpr_dst, &lpr_ds);
-			// outputs leave in 16-byte groups where the rows allow it (staged_kernels.h, LprSink)
-			const int lpr_vec = fuse_lpr && (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
-			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
-			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
-			const size_t per_wave = 64 / lpc;
-			const unsigned ga = (unsigned)(((size_t)S * mcs + per_wave - 1) / per_wave), gc = (unsigned)(((size_t)S * mcs + 63) / 64);
+		const bool dbg_sync = h->opt.tail_sync != 0;
 #define RTLFM_DBG_SYNC(what) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(q); fprintf(stderr, "rtlfm_hip[tail]: %s done (%s)\n", what, hipGetErrorString(e_)); } } while (0)
+		if (scan) {
+			// deemph_filter followed directly by low_pass_real (-M wbfm): the filtered samples go straight
+			// into the resampler's accumulator instead of back to memory (staged_kernels.h)
+			fuse_lpr = tp.lpr && !tp.adc && !h->opt.lpr_separate;
 			// One pass where the resampler follows directly: every chunk finds its incoming state from the
-			// W samples before it (staged_kernels.h, k_deemph_spec_lpr); the streams it cannot settle
-			// that way (silence) raise a flag and alone go through the four passes below.
-			const bool spec = fuse_lpr && !h->opt.deemph_four_pass;
-			const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
-			// chunk length of the one-pass form: about 2720 samples (2040: +1 %, 1360: +2 % on the wbfm step),
-			// and a multiple of the resampler's period fast / gcd(fast, slow) where that is short - then all
-			// chunks of a stream start at the same phase, the lanes of a wave emit at the same samples and
-			// the emission branch is taken by whole waves instead of by a few lanes every sample
-			const int Lwant = h->opt.lpr_chunk >= 256 ? h->opt.lpr_chunk : 2720;
-			int Ls = Lwant;
-			if (tp.lpr && c.rate_out2 > 0) {
-				long long g = c.rate_out, b = c.rate_out2;
-				while (b) { const long long t = g % b; g = b; b = t; }
-				long long per = c.rate_out / g;
-				while (per % 8) per *= 2;
-				if (per <= Lwant) Ls = (int)(per * ((Lwant + per / 2) / per));
-			}
+			// W samples before it (staged_kernels.h, k_deemph_spec_lpr); a stream it cannot settle that way
+			// (silence) is redone by the kernel's own last lane for that stream.
 			// ... and where arbitrary_resample follows directly, on uniform buffers that it upsamples
-			// (config 3): one pass from the demodulated samples to the resampled output
-			// (staged_kernels.h, k_deemph_spec_arb), the same fall-back for the streams it flags
+			// (config 3): one pass from the demodulated samples to the resampled output (k_deemph_spec_arb)
+			const int one = one_pass_tail(h, tp, cur, cur_stride, T, varcnt, nblocks, Nblk, D);
+			const bool spec = one == 2, spec_arb = one == 1;
+			const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
 			const int arb_l2 = (int)((long long)Nblk * c.rate_out2 / c.rate_out);
 			const size_t arb_lds = (size_t)(Ws / kArbChunk + 64) * kArbStride * sizeof(int16_t);
-			const bool spec_arb = tp.arb && !tp.adc && !tp.lpr && D == 1 && !varcnt && Nblk >= 2 && arb_l2 > Nblk &&
-			                      (long long)(Nblk + 1) * arb_l2 < (1ll << 31) && Ws <= 256 &&
-			                      (uintptr_t)cur % 16 == 0 && cur_stride % 8 == 0 && T == nblocks * Nblk &&
-			                      !h->opt.deemph_four_pass;
-			// the four passes (and the separate resampler) afterwards: for every stream, or - behind a
-			// one-pass kernel - for the streams it flagged, listed by k_flag_list and walked by small grids
-			const int32_t *only = spec || spec_arb ? h->d_deemph_list : nullptr;
-			int16_t *arb_dst = nullptr; size_t arb_ds = 0;
-			const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
+			if (spec || spec_arb) {
+				if (!h->d_tail_flag) {
+					HIP_TRY(hipMalloc(&h->d_tail_flag, 2 * (size_t)S * sizeof(uint32_t)));
+					HIP_TRY(hipMalloc(&h->d_tail_ticket, 2 * (size_t)S * sizeof(uint32_t)));
+					HIP_TRY(hipMemsetAsync(h->d_tail_flag, 0, 2 * (size_t)S * sizeof(uint32_t), q));
+					HIP_TRY(hipMemsetAsync(h->d_tail_ticket, 0, 2 * (size_t)S * sizeof(uint32_t), q));
+				}
+			}
+			uint32_t *tflag = h->d_tail_flag ? h->d_tail_flag + (size_t)par * S : nullptr;
+			uint32_t *tticket = h->d_tail_ticket ? h->d_tail_ticket + (size_t)par * S : nullptr;
+			const uint32_t epoch = h->step + 1u;  // never 0: a flag is "raised" when it holds this step's number
+			int32_t *cnt_dst = d_out_len ? d_out_len : h->d_cnt2;
 			if (spec_arb) {
 				if (h->arb_len2 != arb_l2) {
 					// frac = (double)tick / (double)len2 (src/rtl_fm.c:1122) as two fused multiply-adds with
@@ -789,64 +814,101 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 					}
 					h->arb_len2 = arb_l2;
 				}
+				int16_t *arb_dst = nullptr; size_t arb_ds = 0;
 				next_dst(&arb_dst, &arb_ds);
-				HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
+				if (arb_dst != final_dst) return -EFAULT;  // routing bug
+				const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
+				const unsigned g = (unsigned)((size_t)S * arb_spans);
+#define RTLFM_SPEC_ARB(MM) k_deemph_spec_arb<MM><<<g, 64, arb_lds, q>>>(cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, \
+				h->arb_rinv, h->arb_fast, arb_dst, arb_ds, sin, sout, tflag, tticket, epoch, cnt_dst)
+				if (M == 2) RTLFM_SPEC_ARB(2); else if (M == 1) RTLFM_SPEC_ARB(1); else RTLFM_SPEC_ARB(0);
+#undef RTLFM_SPEC_ARB
+				RTLFM_DBG_SYNC("one pass (arb)");
+				return 0;  // the one operation of this tail: filter, resampler, state and counts
 			}
-			const int mcsp = T / Ls + 2;
-			const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
-			if (spec) HIP_TRY(hipMemsetAsync(h->d_deemph_fb, 0, (size_t)S * sizeof(int32_t), q));
-			const unsigned gcl = only ? std::min(gc, 1024u) : gc, gal = only ? std::min(ga, 1024u) : ga;
-#define RTLFM_DEEMPH_SCAN(M)                                                                                        \
+			if (spec) {
+				// chunk length of the one-pass form: about 2720 samples (2040: +1 %, 1360: +2 % on the wbfm step),
+				// and a multiple of the resampler's period fast / gcd(fast, slow) where that is short - then all
+				// chunks of a stream start at the same phase, the lanes of a wave emit at the same samples and
+				// the emission branch is taken by whole waves instead of by a few lanes every sample
+				const int Lwant = h->opt.lpr_chunk;  // 256 .. 2^20 (rtlfm_gpu_set_option)
+				int Ls = Lwant;
+				{
+					long long gg = c.rate_out, bb = c.rate_out2;
+					while (bb) { const long long t = gg % bb; gg = bb; bb = t; }
+					long long per = c.rate_out / gg;
+					while (per % 8) per *= 2;
+					if (per <= Lwant) Ls = (int)(per * ((Lwant + per / 2) / per));
+				}
+				const int mcsp = T / Ls + 2;
+				if ((size_t)mcsp > (size_t)h->lpr_chunks_cap) {
+					if (h->d_lpr_chunks) { HIP_TRY(hipStreamSynchronize(q)); HIP_TRY(hipFree(h->d_lpr_chunks)); }
+					h->d_lpr_chunks = nullptr; h->lpr_chunks_cap = 0;
+					HIP_TRY(hipMalloc(&h->d_lpr_chunks, (size_t)S * mcsp * sizeof(LprChunk)));
+					h->lpr_chunks_cap = mcsp;
+				}
+				next_dst(&lpr_dst, &lpr_ds);
+				if (lpr_dst != final_dst) return -EFAULT;  // routing bug
+				// outputs leave in 16-byte groups where the rows allow it (staged_kernels.h, LprSink)
+				const int lpr_vec = (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
+				const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
+#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
+				c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, tflag, tticket, epoch, cnt_dst)
+				if (M == 2) RTLFM_SPEC_LPR(2); else if (M == 1) RTLFM_SPEC_LPR(1); else RTLFM_SPEC_LPR(0);
+#undef RTLFM_SPEC_LPR
+				RTLFM_DBG_SYNC("one pass (lpr)");
+				return 0;
+			}
+			// the four passes, for every stream
+			// chunk length: each of the passes A1 and C is one chunk long in time; a chunk must be
+			// long enough for the interval to contract (~100 samples) and, normally, to merge
+			const int L = T >= 8192 ? 1024 : 512;
+			const int mc = T / L + 2;
+			if ((size_t)mc > (size_t)h->deemph_chunks) {
+				if (h->d_deemph_tab) { HIP_TRY(hipStreamSynchronize(q)); HIP_TRY(hipFree(h->d_deemph_tab)); HIP_TRY(hipFree(h->d_deemph_inc)); }
+				h->d_deemph_tab = nullptr; h->d_deemph_inc = nullptr; h->deemph_chunks = 0;
+				HIP_TRY(hipMalloc(&h->d_deemph_tab, (size_t)S * mc * sizeof(DeemphChunk)));
+				HIP_TRY(hipMalloc(&h->d_deemph_inc, (size_t)S * mc * sizeof(uint32_t)));
+				h->deemph_chunks = mc;
+			}
+			if (fuse_lpr && (size_t)mc > (size_t)h->lpr_chunks_cap) {
+				if (h->d_lpr_chunks) { HIP_TRY(hipStreamSynchronize(q)); HIP_TRY(hipFree(h->d_lpr_chunks)); }
+				h->d_lpr_chunks = nullptr; h->lpr_chunks_cap = 0;
+				HIP_TRY(hipMalloc(&h->d_lpr_chunks, (size_t)S * mc * sizeof(LprChunk)));
+				h->lpr_chunks_cap = mc;
+			}
+			const int mcs = mc;
+			if (fuse_lpr) next_dst(&lpr_dst, &lpr_ds);
+			const int lpr_vec = fuse_lpr && (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
+			int lpc = 8;  // lanes per chunk in pass A2: the contracted interval (<= 2a + 2 states) must fit
+			while (lpc < 2 * c.deemph_a + 3) lpc *= 2;
+			const size_t per_wave = 64 / lpc;
+			const unsigned ga = (unsigned)(((size_t)S * mcs + per_wave - 1) / per_wave), gc = (unsigned)(((size_t)S * mcs + 63) / 64);
+#define RTLFM_DEEMPH_SCAN(MM)                                                                                       \
 	do {                                                                                                            \
-		RTLFM_DBG_SYNC("before deemph scan");                                                                          \
-		if (spec_arb) {                                                                                              \
-			k_deemph_spec_arb<M><<<(unsigned)((size_t)S * arb_spans), 64, arb_lds, q>>>(                               \
-			    cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, h->arb_rinv, h->arb_fast, arb_dst,    \
-			    arb_ds, sin, sout, h->d_deemph_fb, h->d_cnt2);                                                         \
-			RTLFM_DBG_SYNC("one pass (arb)");                                                                          \
-		}                                                                                                            \
-		if (spec) {                                                                                                  \
-			k_deemph_spec_lpr<M><<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds,     \
-			                                         c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, h->d_deemph_fb); \
-			k_lpr_fixup<<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcsp, Ls, h->d_lpr_chunks, lpr_dst, lpr_ds,       \
-			                               c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, nullptr, h->d_deemph_fb);   \
-			RTLFM_DBG_SYNC("one pass");                                                                                \
-		}                                                                                                            \
-		if (only) {                                                                                                  \
-			HIP_TRY(hipMemsetAsync(h->d_deemph_list, 0, sizeof(int32_t), q));                                          \
-			k_flag_list<<<(unsigned)((S + 255) / 256), 64, 0, q>>>(h->d_deemph_fb, S, h->d_deemph_list);               \
-		}                                                                                                            \
-		k_deemph_scan_a1<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
+		k_deemph_scan_a1<MM><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);        \
 		RTLFM_DBG_SYNC("a1");                                                                                          \
-		k_deemph_scan_a2<M><<<gal, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab, only);   \
+		k_deemph_scan_a2<MM><<<ga, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, lpc, h->d_deemph_tab);        \
 		RTLFM_DBG_SYNC("a2");                                                                                          \
-		k_deemph_scan_b<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,                \
-		                                       h->d_deemph_inc, sin, sout, only);                                   \
+		k_deemph_scan_b<MM><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_tab,               \
+		                                       h->d_deemph_inc, sin, sout);                                         \
 		RTLFM_DBG_SYNC("b");                                                                                           \
 		if (fuse_lpr) {                                                                                              \
-			k_deemph_scan_c_lpr<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst,  \
-			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, only); \
-			k_lpr_fixup<<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,         \
-			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2, only);                        \
+			k_deemph_scan_c_lpr<MM><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, lpr_dst, \
+			                                           lpr_ds, c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec); \
+			k_lpr_fixup<<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, mcs, L, h->d_lpr_chunks, lpr_dst, lpr_ds,        \
+			                              c.rate_out, c.rate_out2, sin, sout, h->d_cnt2);                            \
 		} else {                                                                                                     \
-			k_deemph_scan_c<M><<<gcl, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout, only); \
+			k_deemph_scan_c<MM><<<gc, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcs, L, h->d_deemph_inc, sout);      \
 		}                                                                                                            \
 		RTLFM_DBG_SYNC("c");                                                                                           \
 	} while (0)
-			if (pow2) RTLFM_DEEMPH_SCAN(2);
-			else if (magic) RTLFM_DEEMPH_SCAN(1);
+			if (M == 2) RTLFM_DEEMPH_SCAN(2);
+			else if (M == 1) RTLFM_DEEMPH_SCAN(1);
 			else RTLFM_DEEMPH_SCAN(0);
 #undef RTLFM_DEEMPH_SCAN
-			if (spec_arb) {
-				k_arb_upsample_only<<<(unsigned)std::min((size_t)S * nblocks, (size_t)1024), 256, 0, q>>>(
-				    cur, cur_stride, arb_dst, arb_ds, Nblk, arb_l2, nblocks, h->d_deemph_list);
-				if (arb_dst != final_dst) return -EFAULT;  // routing bug
-				if (d_out_len)
-					HIP_TRY(hipMemcpyAsync(d_out_len, h->d_cnt2, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
-				return 0;
-			}
-		} else if (pow2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
-		else if (magic) k_deemph<1><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		} else if (M == 2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+		else if (M == 1) k_deemph<1><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 	}
 	if (tp.adc) {
@@ -976,7 +1038,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	// --- mode_demod (src/rtl_fm.c:1256-1259)
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
+		r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
 	}
 	int16_t *dd; size_t dds;
@@ -1056,7 +1118,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		int r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
+		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
 	}
 	int16_t *dd; size_t dds;
@@ -1069,7 +1131,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 		// dc_block_raw_filter needs every buffer's mean before its first sample: one more pass over the
 		// input (the per-buffer sums), the smoothing recurrence over a stream's buffers, and then the
 		// averages ride on the front end's MFMA accumulators (fused_kernel.h, RDC)
-		k_rdc_sums_wide<<<dim3((unsigned)nblocks, (unsigned)S), 256, 0, q>>>(d_iq, stream_stride, c.block_len, h->d_sums);
+		k_rdc_sums_wide<<<(unsigned)((size_t)S * nblocks), 256, 0, q>>>(d_iq, stream_stride, c.block_len, nblocks, h->d_sums);
 		k_rdc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, sin, sout, h->d_rdc_avg);
 		rdc = h->d_rdc_avg;
 	}
@@ -1111,7 +1173,7 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	}
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		int r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
+		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
 	}
 	std::pair<hipEvent_t, hipEvent_t> ev;
@@ -1170,7 +1232,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
-		int r = ensure_res_buffers(h, d_iq, (size_t)S * stream_stride);
+		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
 	}
 	int16_t *dd; size_t dds;
@@ -1200,7 +1262,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	HIP_TRY(hipSetDevice(h->device));
 	const size_t S = (size_t)h->nstreams;
 	bool can_fuse = fused::supported(h->cfg, nblocks);
-	if (h->cfg.dc_block_raw && h->fws.pass0_engine == 0) can_fuse = false;  // the raw DC block rides on the MFMA pass 0
+	if (h->cfg.dc_block_raw && fused::effective_engine(h->fws) != 1) can_fuse = false;  // the raw DC block rides on the MFMA pass 0
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
@@ -1337,9 +1399,14 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 			// the results a quarter of the HBM away from the input they are demodulated from (see
 			// rtlfm_gpu_malloc_apart; plain memory when the ring is too small for it to matter)
 			void *p = nullptr;
-			int r = rtlfm_gpu_malloc_apart(h->device, S * in->ostride * sizeof(int16_t), in->d_in[k], bytes, &p, nullptr);
+			int apart = 0; double ms = 0; size_t walked = 0;
+			int r = rtlfm_gpu_malloc_apart_ex(h->device, S * in->ostride * sizeof(int16_t), in->d_in[k], bytes,
+			                                  (size_t)h->place.budget_gb << 30, &p, &apart, &ms, &walked);
 			if (r < 0) return r;
 			in->d_result[k] = (int16_t *)p;
+			h->place.search_ms += ms;
+			if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+			h->place.ring_apart = (k == 0 ? 1 : h->place.ring_apart) && apart ? 1 : 0;
 		}
 		HIP_TRY(hipMalloc(&in->d_result_len[k], S * sizeof(int32_t)));
 		HIP_TRY(hipEventCreateWithFlags(&in->ev_h2d[k], hipEventDisableTiming));
@@ -1409,6 +1476,8 @@ extern "C" int rtlfm_gpu_push(rtlfm_gpu *h, int stream, const uint8_t *iq, uint3
 	// shared: pushes of different streams run side by side; rtlfm_gpu_run() takes the lock
 	// exclusively only to flip the halves, so it sees every buffer whole or not at all
 	std::shared_lock<std::shared_mutex> g(in->mu);
+	// a slot of this stream is out between acquire and commit: a push would land in that very slot
+	if (in->open_slot[stream].load(std::memory_order_acquire)) return -EBUSY;
 	const int f = in->fill;
 	const int slot = in->pushed[f][stream].fetch_add(1, std::memory_order_acq_rel);
 	if (slot >= h->cap_blocks) {
@@ -1869,6 +1938,7 @@ size_t probe_region(size_t in_bytes, size_t out_bytes)
 }
 
 constexpr float kApartRatio = 1.21f;  // read+write over read-only time: 1.12 apart, 1.31 in the same quarter
+constexpr size_t kApartBudgetDefault = (size_t)80 << 30;
 
 }  // namespace
 
@@ -1879,15 +1949,26 @@ constexpr float kApartRatio = 1.21f;  // read+write over read-only time: 1.12 ap
 // winner is freed at the end.  *apart = 1 when a quarter away was found, 0 when the buffers are too
 // small for it to matter (< 256 MiB streamed), the search ran out of memory budget, or the probe
 // failed - the memory returned is good device memory in every case.  `other` is only read.
-extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart)
+extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
+                                         void **out, int *apart, double *search_ms, size_t *walked_bytes)
 {
 	if (!out || !bytes) return -EINVAL;
 	if (apart) *apart = 0;
+	if (search_ms) *search_ms = 0;
+	if (walked_bytes) *walked_bytes = 0;
+	const auto t_begin = std::chrono::steady_clock::now();
+	struct Clock {  // whatever way the search ends: how long it took, how much it held at its peak
+		std::chrono::steady_clock::time_point t0; double *ms; size_t *wb; size_t peak = 0;
+		~Clock() {
+			if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			if (wb) *wb = peak;
+		}
+	} clk{t_begin, search_ms, walked_bytes};
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
 	HIP_TRY(hipSetDevice(device));
 	const size_t region = other ? probe_region(other_bytes, bytes) : 0;
-	if (region < ((size_t)256 << 20)) {
+	if (region < ((size_t)256 << 20) || budget_bytes == 0) {  // too small to matter, or the search is switched off
 		void *p = nullptr;
 		HIP_TRY(hipMalloc(&p, bytes));
 		*out = p;
@@ -1902,9 +1983,10 @@ extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *othe
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	const size_t step = (size_t)4 << 30;
-	// a quarter is 72 GB: at most that much is walked over, and never more than what is free minus a reserve
-	size_t budget = (size_t)80 << 30;
-	if (free_b < budget + ((size_t)8 << 30)) budget = free_b > ((size_t)8 << 30) ? free_b - ((size_t)8 << 30) : 0;
+	// a quarter is 72 GB: at most that much (the caller's budget) is walked over, and never more than HALF of what
+	// is free - the device may have other tenants, whose next allocation must not fail because of a search
+	size_t budget = budget_bytes;
+	if (budget > free_b / 2) budget = free_b / 2;
 	std::vector<void *> keep;       // fillers
 	std::vector<void *> cand;       // candidates that did not pass, with their times
 	std::vector<float> cand_rw;
@@ -1922,6 +2004,7 @@ extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *othe
 		if (hipMalloc(&f, step) != hipSuccess) { (void)hipGetLastError(); break; }
 		keep.push_back(f);
 		walked += step + bytes;
+		clk.peak = walked;
 	}
 	for (void *k : keep) hipFree(k);
 	// no candidate under the threshold (a noisy box, or the walk ran out of budget): the one that measured
@@ -1941,6 +2024,11 @@ extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *othe
 	if (!win) HIP_TRY(hipMalloc(&win, bytes));
 	*out = win;
 	return 0;
+}
+
+extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart)
+{
+	return rtlfm_gpu_malloc_apart_ex(device, bytes, other, other_bytes, kApartBudgetDefault, out, apart, nullptr, nullptr);
 }
 
 // Are two existing buffers a quarter apart?  1 = yes, 0 = no / too small to tell; `in` is read,

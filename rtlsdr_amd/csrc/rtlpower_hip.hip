@@ -43,6 +43,13 @@ struct rtlpower_gpu {
 	uint8_t *d_one = nullptr;  // landing zone of rtlpower_gpu_scan()
 	bool timing = false;
 	int groups = 0;  // option "groups": workgroups per stream of the FFT kernel (0 = automatic)
+	bool staged = false;                   // bin_e 15 .. 21 or more points per read than a workgroup's LDS holds: transform in HBM
+	uint32_t *d_work = nullptr; int2 *d_ave = nullptr;
+	size_t work_reads = 0;                 // reads the work buffer holds per stream
+	bool attr_lds = false;
+	bool want_stamps = false;              // rtlpower_gpu_clock_probe
+	unsigned long long *d_stamps = nullptr;
+	int stamp_cap = 0, stamp_last = 0;     // workgroups the buffer holds / of the last stamped launch
 	bool attr_set = false, attr_big = false;  // the kernels' dynamic-LDS limits are raised on this handle's device
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
@@ -189,9 +196,9 @@ extern "C" int rtlpower_csv_dbm(const rtlpower_plan *p, int tune, int64_t *avg, 
 
 static int validate(const rtlpower_cfg *c)
 {
-	if (c->bin_e < 0 || c->bin_e > 14) return c->bin_e > 14 && c->bin_e <= 21 ? -ENOTSUP : -EINVAL;
+	if (c->bin_e < 0 || c->bin_e > 21) return -EINVAL;  // frequency_range() plans 2^1 .. 2^21 bins (src/rtl_power.c:483-486)
 	if (c->window < 0 || c->window > RTLPOWER_WIN_BARTLETT) return -EINVAL;
-	if (c->buf_len < 16 || c->buf_len % 4 || c->buf_len > (1u << 24)) return -EINVAL;
+	if (c->buf_len < 16 || c->buf_len % 4 || c->buf_len > (1u << 26)) return -EINVAL;
 	if (c->downsample < 1) return -EINVAL;
 	if (c->comp_fir_size != 0 && c->comp_fir_size != 9) return -EINVAL;
 	if (!c->boxcar && c->downsample_passes) {
@@ -257,7 +264,8 @@ static int power_create_body(rtlpower_gpu *h)
 	h->len_dec = (int)cfg->buf_len / ds;  // what remove_dc() and the chunk loop are given (:692-696)
 	if (cfg->bin_e > 0) {
 		h->chunks = (h->len_dec + 2 * h->N - 1) / (2 * h->N);
-		if ((long long)h->chunks * h->N > kMaxPoints) return -ENOTSUP;
+		// what one workgroup's LDS cannot hold goes through the work buffer in HBM (power_kernels.h, k_power_fft_*)
+		h->staged = cfg->bin_e > 14 || (long long)h->chunks * h->N > kMaxPoints;
 		if (cfg->boxcar && ds > 1) h->dec_elems = 2 * (((int)cfg->buf_len / 2 + ds - 1) / ds);
 		else if (h->decimates) h->dec_elems = (int)cfg->buf_len >> cfg->downsample_passes;
 	}
@@ -308,7 +316,7 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 		if (e) (void)hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one};
+	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one, h->d_stamps, h->d_work, h->d_ave};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -373,6 +381,38 @@ extern "C" int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long v
 		return 0;
 	}
 	return -ENOENT;
+}
+
+// The shader clock the FFT kernel's workgroups actually ran at (k_power_scan_big stamps s_memtime and the
+// 100 MHz s_memrealtime at its first and last instruction): what the VALU-issue ceiling of a launch is priced at.
+extern "C" int rtlpower_gpu_clock_probe(rtlpower_gpu *h, int on)
+{
+	if (!h) return -EINVAL;
+	h->want_stamps = on != 0;
+	if (!on) h->stamp_last = 0;
+	return 0;
+}
+
+extern "C" int rtlpower_gpu_clock_read(rtlpower_gpu *h, double *shader_mhz, double *span_ms)
+{
+	if (!h) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	if (!h->d_stamps || h->stamp_last <= 0) return -ENODATA;
+	std::vector<unsigned long long> st((size_t)h->stamp_last * 4);
+	HIP_TRY(hipMemcpy(st.data(), h->d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+	double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+	for (int w = 0; w < h->stamp_last; w++) {
+		const double dc = (double)(st[w * 4 + 1] - st[w * 4]), dr = (double)(st[w * 4 + 3] - st[w * 4 + 2]);
+		if (st[w * 4 + 3] == 0 || dr <= 0) continue;  // a workgroup that had no reads
+		sum += dc / dr * 100.0; n++;
+		if (st[w * 4 + 2] < t0) t0 = st[w * 4 + 2];
+		if (st[w * 4 + 3] > t1) t1 = st[w * 4 + 3];
+	}
+	if (!n) return -ENODATA;
+	if (shader_mhz) *shader_mhz = sum / n;
+	if (span_ms) *span_ms = (double)(t1 - t0) / 1e5;
+	return 0;
 }
 
 extern "C" int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on)
@@ -455,6 +495,64 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		}
 		dec = cur;
 	}
+	if (h->staged) {
+		// bin_e 15 .. 21 (or frames beyond one workgroup's LDS): the same stages over a work buffer in HBM,
+		// a batch of reads at a time (at most ~1 GiB of work buffer)
+		const size_t M = (size_t)h->chunks * h->N;
+		size_t batch = ((size_t)1 << 28) / ((size_t)S * M);
+		if (batch < 1) batch = 1;
+		if (batch > (size_t)nreads) batch = (size_t)nreads;
+		if (h->work_reads < batch) {
+			HIP_TRY(hipStreamSynchronize(q));
+			if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_ave); h->d_work = nullptr; h->d_ave = nullptr; }
+			h->work_reads = 0;
+			HIP_TRY(hipMalloc(&h->d_work, (size_t)S * batch * M * sizeof(uint32_t)));
+			HIP_TRY(hipMalloc(&h->d_ave, (size_t)S * batch * sizeof(int2)));
+			h->work_reads = batch;
+		}
+		const int eb = c.bin_e < 14 ? c.bin_e : 14;
+		const size_t lds = ((size_t)skewed_size(1 << eb) + ((size_t)1 << eb)) * 4;
+		if (!h->attr_lds) {
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_fft_lds),
+			                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+			h->attr_lds = true;
+		}
+		std::pair<hipEvent_t, hipEvent_t> ev;
+		if (h->timing) {
+			if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+			else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+			HIP_TRY(hipEventRecord(ev.first, q));
+		}
+		for (int r0 = 0; r0 < nreads; r0 += (int)batch) {
+			const int nb = nreads - r0 < (int)batch ? nreads - r0 : (int)batch;
+			StagedParams sp{};
+			sp.iq8 = dec ? nullptr : d_iq + (size_t)r0 * c.buf_len; sp.stride8 = stream_stride;
+			sp.dec = dec ? dec + (size_t)r0 * drs : nullptr; sp.dec_stream_stride = dss; sp.dec_read_stride = drs; sp.dec_elems = h->dec_elems;
+			sp.nreads = nb; sp.buf_len = (int)c.buf_len; sp.len_dec = h->len_dec; sp.bin_e = c.bin_e; sp.chunks = h->chunks;
+			sp.ds = c.downsample; sp.peak_hold = c.peak_hold; sp.window = h->d_window; sp.tw = h->d_tw;
+			sp.ave = h->d_ave; sp.work = h->d_work; sp.avg = h->d_avg; sp.samples = h->d_samples; sp.nstreams = S;
+			const size_t frames = (size_t)S * nb * h->chunks;
+			k_power_dc<<<(unsigned)((size_t)S * nb), 256, 0, q>>>(sp);
+			k_power_place<<<grid_for((size_t)S * nb * M, 256, 256 * 64), 256, 0, q>>>(sp);
+			const size_t nblk = frames << (c.bin_e - eb);
+			hipLaunchKernelGGL(k_power_fft_lds, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(kThreads), lds, q, h->d_work, h->d_tw, eb, nblk);
+			for (int st = 14; st < c.bin_e;) {
+				const int R = c.bin_e - st >= 3 ? 3 : c.bin_e - st;
+				const int g = grid_for(frames << (c.bin_e - R), 256, 256 * 64);
+				if (R == 3) k_power_fft_gl<3><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
+				else if (R == 2) k_power_fft_gl<2><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
+				else k_power_fft_gl<1><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
+				st += R;
+			}
+			k_power_accum<<<grid_for((size_t)S * h->N, 256, 256 * 64), 256, 0, q>>>(sp);
+		}
+		HIP_TRY(hipGetLastError());
+		if (h->timing) {
+			HIP_TRY(hipEventRecord(ev.second, q));
+			h->ev_pending.push_back(ev);
+		}
+		return 0;
+	}
 	ScanParams p{};
 	p.iq8 = dec ? nullptr : d_iq; p.stride8 = stream_stride;
 	p.dec = dec; p.dec_stream_stride = dss; p.dec_read_stride = drs; p.dec_elems = h->dec_elems;
@@ -495,6 +593,17 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		p.groups = groups;
 	}
 	const unsigned grid = (unsigned)S * (unsigned)p.groups;
+	if (big && h->want_stamps) {
+		if (h->stamp_cap < (int)grid) {
+			if (h->d_stamps) (void)hipFree(h->d_stamps);
+			h->d_stamps = nullptr; h->stamp_cap = 0;
+			HIP_TRY(hipMalloc(&h->d_stamps, (size_t)grid * 32));
+			h->stamp_cap = (int)grid;
+		}
+		HIP_TRY(hipMemsetAsync(h->d_stamps, 0, (size_t)grid * 32, q));
+		p.stamps = h->d_stamps;
+		h->stamp_last = (int)grid;
+	}
 	if (big && c.bin_e == 14) hipLaunchKernelGGL(k_power_scan_big<14>, dim3(grid), dim3(kThreads), lds, q, p);
 	else if (big) hipLaunchKernelGGL(k_power_scan_big<13>, dim3(grid), dim3(kThreads), lds, q, p);
 	else hipLaunchKernelGGL(k_power_scan, dim3(grid), dim3(kThreads), lds, q, p);
@@ -519,10 +628,12 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	view.d_avg = h->d_avg + (size_t)stream * h->N;
 	view.d_samples = h->d_samples + stream;
 	view.d_decA = view.d_decB = nullptr; view.dec_cap_reads = 0;
+	view.d_work = nullptr; view.d_ave = nullptr; view.work_reads = 0;
 	view.ev_pending.clear(); view.ev_free.clear(); view.timing = false;
 	int r = rtlpower_gpu_scan_device(&view, h->d_one, h->cfg.buf_len, 1);
 	const hipError_t e = hipStreamSynchronize(h->stream);
 	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }  // also when the sync failed
+	if (view.d_work) { (void)hipFree(view.d_work); (void)hipFree(view.d_ave); }
 	if (e != hipSuccess) return -EIO;
 	return r;
 }

@@ -108,10 +108,11 @@ k_rdc_sums(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, int
 // (buffer, stream), 16-byte loads, v_dot4 against (1, 0, 1, 0) / (0, 1, 0, 1) byte masks (u8 sums;
 // the -127 per sample is taken off once at the end), wave reduction by DPP.
 __global__ void __launch_bounds__(256)
-k_rdc_sums_wide(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, long long *__restrict__ sums /* [s][b][2] */)
+k_rdc_sums_wide(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, int nblocks, long long *__restrict__ sums /* [s][b][2] */)
 {
-	const int b = blockIdx.x, nblocks = gridDim.x;
-	const size_t s = blockIdx.y;
+	// (stream, buffer) folded into grid.x: grid.y stops at 65535 streams
+	const size_t s = blockIdx.x / (unsigned)nblocks;
+	const int b = (int)(blockIdx.x % (unsigned)nblocks);
 	const uint8_t *src = iq + s * stream_stride + (size_t)b * L;
 	unsigned si = 0, sq = 0;  // <= 262144 * 255 / 2: fits
 	const uint32_t n16 = L / 16;
@@ -621,37 +622,16 @@ __device__ __forceinline__ int deemph_chunks(int n, int head, int L)
 	return m <= L ? 1 : (m + L - 1) / L;
 }
 
-// (stream, chunk) pairs for the kernels of the four-pass filter.  Without a list: every stream of
-// the handle, one pair per lane (or per `lanes` lanes), the grid covers nstreams * max_chunks
-// pairs.  With a list (list[0] = count, then stream indices: the streams the one-pass kernels
-// flagged, k_flag_list): only those, walked grid-stride by whatever small grid was launched - the
-// host does not know the count, and a full grid of workgroups that look at a flag and leave costs
-// 0.04-0.3 ms per run of the wbfm tail (175 000 workgroups for pass A2 alone).
+// (stream, chunk) pairs for the kernels of the four-pass filter: every stream of the handle, one pair per
+// lane (or per `lanes` lanes); the grid covers nstreams * max_chunks pairs.
 template <class Body>
-__device__ __forceinline__ void for_stream_chunks(int nstreams, int max_chunks, const int32_t *__restrict__ list, int lanes, Body body)
+__device__ __forceinline__ void for_stream_chunks(int nstreams, int max_chunks, int lanes, Body body)
 {
 	const int per_wg = 64 / lanes;
 	const int sub = (int)threadIdx.x % lanes, slot = (int)threadIdx.x / lanes;
-	if (!list) {
-		const size_t g = (size_t)blockIdx.x * per_wg + slot;
-		const size_t s = g / max_chunks;
-		if (s < (size_t)nstreams) body(s, (int)(g % max_chunks), sub);
-		return;
-	}
-	const size_t total = (size_t)list[0] * max_chunks;
-	for (size_t g = (size_t)blockIdx.x * per_wg + slot; g < total; g += (size_t)gridDim.x * per_wg)
-		body((size_t)list[1 + g / max_chunks], (int)(g % max_chunks), sub);
-}
-
-// the streams with a raised flag, compacted: list[0] = count (zeroed by the host), list[1..] =
-// indices in any order.  One-wave workgroups of 256 streams each: a wave finds a slot beside the
-// front end's waves at once, a 256-thread workgroup waited 0.14 ms for four on one CU.
-__global__ void __launch_bounds__(64) k_flag_list(const int32_t *__restrict__ flags, int nstreams, int32_t *__restrict__ list)
-{
-	for (int k = 0; k < 4; k++) {
-		const int s = ((int)blockIdx.x * 4 + k) * 64 + (int)threadIdx.x;
-		if (s < nstreams && flags[s]) list[1 + atomicAdd(&list[0], 1)] = s;
-	}
+	const size_t g = (size_t)blockIdx.x * per_wg + slot;
+	const size_t s = g / max_chunks;
+	if (s < (size_t)nstreams) body(s, (int)(g % max_chunks), sub);
 }
 
 // A1: one lane per chunk walks the two extreme states through the whole chunk.  It records where
@@ -661,10 +641,9 @@ __global__ void __launch_bounds__(64) k_flag_list(const int32_t *__restrict__ fl
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab,
-                 const int32_t *__restrict__ only = nullptr)
+                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab)
 {
-	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
+	for_stream_chunks(nstreams, max_chunks, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -727,10 +706,9 @@ k_deemph_scan_a1(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_a2(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab,
-                 const int32_t *__restrict__ only = nullptr)
+                 DeemphStep ds, int max_chunks, int L, int lpc, DeemphChunk *__restrict__ tab)
 {
-	for_stream_chunks(nstreams, max_chunks, only, lpc, [&](const size_t s, const int c, const int sub) {
+	for_stream_chunks(nstreams, max_chunks, lpc, [&](const size_t s, const int c, const int sub) {
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -755,9 +733,9 @@ template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                 DeemphStep ds, int max_chunks, int L, const DeemphChunk *__restrict__ tab, uint32_t *__restrict__ incoming,
-                const state_t *__restrict__ sin, state_t *__restrict__ sout, const int32_t *__restrict__ only = nullptr)
+                const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
-	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
+	for_stream_chunks(nstreams, max_chunks, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
 	uint32_t *inc = incoming + s * max_chunks;
@@ -796,10 +774,9 @@ k_deemph_scan_b(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *_
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
 k_deemph_scan_c(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
-                DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout,
-                const int32_t *__restrict__ only = nullptr)
+                DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, state_t *__restrict__ sout)
 {
-	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
+	for_stream_chunks(nstreams, max_chunks, 1, [&](const size_t s, const int c, int) {
 	if (incoming[s * max_chunks] == 0xffffffffu) return;
 	const int n = cnt ? cnt[s] : T;
 	int16_t *r = R + s * rstride;
@@ -968,9 +945,9 @@ __global__ void __launch_bounds__(64)
 k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                     DeemphStep ds, int max_chunks, int L, const uint32_t *__restrict__ incoming, int16_t *__restrict__ B,
                     size_t bstride, int fast, int slow, const state_t *__restrict__ sin, state_t *__restrict__ sout,
-                    LprChunk *__restrict__ lc, int vec, const int32_t *__restrict__ only = nullptr)
+                    LprChunk *__restrict__ lc, int vec)
 {
-	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
+	for_stream_chunks(nstreams, max_chunks, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	const int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -998,8 +975,8 @@ k_deemph_scan_c_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const 
 // extremes over the W samples before its own first one, and if they have met, that IS the state the
 // chunk starts from, exactly, whatever came before.  Then it replays its samples into the
 // resampler as k_deemph_scan_c_lpr does.  One read of the run plus W / L instead of two.  A chunk
-// whose extremes have not met (a silent stream) raises its stream's flag, and the flagged streams
-// go through the four passes afterwards (`only`); a filter state outside int16 likewise.
+// whose extremes have not met (a silent stream) raises its stream's flag, and the lane that is last
+// to finish a flagged stream redoes it with the reference's sequential loop; a filter state outside int16 likewise.
 template <int MAGIC>
 __device__ __forceinline__ void deemph_walk_pair(const int16_t *r, int n, uint32_t &lo, uint32_t &hi, const DeemphStep &ds)
 {
@@ -1043,63 +1020,127 @@ __device__ __forceinline__ void deemph_walk_pair(const int16_t *r, int n, uint32
 	}
 }
 
+// One launch, no helpers around it: a stream this kernel cannot settle (fallback) is redone by the kernel itself.
+// Every workgroup of a stream draws a ticket when it is done (ticket[s], zero between launches); the one that
+// draws the last finds the stream's flag raised (flag[s] == epoch: flags carry the launch's number, so nobody
+// has to clear them) or the carried state outside int16, and then runs the reference's own sequential loop over
+// the stream's run - deemph_filter in place, arbitrary_upsample per buffer - over what the others wrote.
+// (Round 3 had two memsets, k_flag_list, the four passes of the time-parallel filter, k_arb_upsample_only and a
+// copy of the counts around this kernel: ten operations per step on the tail's stream, each of which waited
+// for room beside the next step's front end.)
+__device__ __forceinline__ bool tail_last_ticket(uint32_t *ticket, uint32_t total)
+{
+	__threadfence();  // release: what this workgroup wrote is visible before its ticket counts
+	const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (old + 1 != total) return false;
+	__hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+	__threadfence();  // acquire: what the others wrote before their tickets
+	return true;
+}
+
+// low_pass_real's totals over a run of n samples from the carried phase p0 (src/rtl_fm.c:755-775): outputs, phase left
+__device__ __forceinline__ void lpr_totals(long long p0, int n, int slow, int fast, int &E, int &phase)
+{
+	const long long tot = p0 + (long long)n * slow;
+	E = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(tot, fast) : (int)(tot / fast);
+	phase = (int)(tot - (long long)E * fast);
+}
+
+// One launch (see k_deemph_spec_arb): every chunk's lane draws a ticket of its stream when it is done, and the
+// lane that draws the last one finishes the stream - the outputs that straddle chunk boundaries, the carried
+// accumulator, phase and count (what k_lpr_fixup does for the four-pass route), or, if some chunk could not
+// settle (flag[s] == epoch) or the carried filter state lies outside int16, the reference's own sequential
+// loop over the whole run: deemph_filter feeding low_pass_real.
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
-k_deemph_spec_lpr(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                   DeemphStep ds, int max_chunks, int L, int W, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
-                  const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *__restrict__ lc, int vec,
-                  int32_t *__restrict__ fallback)
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *lc, int vec,
+                  uint32_t *flag, uint32_t *ticket, uint32_t epoch, int32_t *__restrict__ cnt_out)
 {
 	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
 	const size_t s = g / max_chunks;
 	const int c = (int)(g % max_chunks);
 	if (s >= (size_t)nstreams) return;
 	const int n = cnt ? cnt[s] : T;
-	const int16_t *r = R + s * rstride;
+	int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
 	const int nc = deemph_chunks(n, head, L);
 	if (c >= nc) return;
-	if ((uint32_t)(sin[s].deemph_avg + 32768) > 65535u) {  // only rtlfm_gpu_state_set can do that: the four passes' plain form
-		if (c == 0) fallback[s] = 1;
-		return;
-	}
-	int begin, end;
-	deemph_chunk_range(c, n, head, L, begin, end);
-	uint32_t v = (uint32_t)(sin[s].deemph_avg + 32768);
-	if (begin > 0) {
-		if (begin <= W) {
-			// close to the start of the run: from the carried state itself
-			uint32_t v2 = v;
-			deemph_walk_pair<MAGIC>(r, begin, v, v2, ds);
-		} else {
-			uint32_t lo = 0, hi = 65535;
-			deemph_walk_pair<MAGIC>(r + begin - W, W, lo, hi, ds);
-			if (lo != hi) {
-				fallback[s] = 1;
-				return;
+	const int carried = sin[s].deemph_avg;
+	const bool plain = (uint32_t)(carried + 32768) > 65535u;  // only rtlfm_gpu_state_set can do that
+	const long long p0 = sin[s].prev_lpr_index;
+	if (!plain) {
+		int begin, end;
+		deemph_chunk_range(c, n, head, L, begin, end);
+		uint32_t v = (uint32_t)(carried + 32768);
+		bool settled = true;
+		if (begin > 0) {
+			if (begin <= W) {
+				// close to the start of the run: from the carried state itself
+				uint32_t v2 = v;
+				deemph_walk_pair<MAGIC>(r, begin, v, v2, ds);
+			} else {
+				uint32_t lo = 0, hi = 65535;
+				deemph_walk_pair<MAGIC>(r + begin - W, W, lo, hi, ds);
+				settled = lo == hi;
+				v = lo;
 			}
-			v = lo;
+		}
+		if (settled) {
+			const long long idx0 = p0 + (long long)begin * slow;
+			const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
+			LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
+			v = deemph_walk_sink<MAGIC>(r + begin, end - begin, v, ds, true, sink);
+			sink.finish();
+			lc[s * max_chunks + c] = sink.out;
+			if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+		} else {
+			__hip_atomic_store(flag + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
-	const long long p0 = sin[s].prev_lpr_index;
-	const long long idx0 = p0 + (long long)begin * slow;
-	const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
-	LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
-	v = deemph_walk_sink<MAGIC>(r + begin, end - begin, v, ds, true, sink);
-	sink.finish();
-	lc[s * max_chunks + c] = sink.out;
-	if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+	if (!tail_last_ticket(ticket + s, (uint32_t)nc)) return;
+	int E, phase;
+	lpr_totals(p0, n, slow, fast, E, phase);
+	if (plain || __hip_atomic_load(flag + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+		// the reference's loop over the whole run, on this lane
+		const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(p0, fast) : (int)(p0 / fast);
+		LprSink sink(B + s * bstride, m0, (int)(p0 - (long long)m0 * fast), slow, fast, (uint32_t)sin[s].now_lpr, vec != 0);
+		if (plain) {
+			sout[s].deemph_avg = deemph_plain(r, n, carried, (int)ds.a);
+			deemph_walk_sink<MAGIC>(r, n, 0u, ds, false, sink);
+		} else {
+			sout[s].deemph_avg = (int)deemph_walk_sink<MAGIC>(r, n, (uint32_t)(carried + 32768), ds, true, sink) - 32768;
+		}
+		sink.finish();
+		sout[s].now_lpr = (int)sink.out.tail;
+	} else {
+		// the one output per chunk boundary that began in the chunks before, and what the run leaves in the accumulator
+		const LprChunk *l0 = lc + s * max_chunks;
+		const int div = fast / slow;
+		uint32_t carry = 0;  // what the chunks so far have left in the accumulator since their last emission
+		for (int j = 0; j < nc; j++) {
+			const LprChunk k = l0[j];
+			if (k.mfirst >= 0) {
+				if (j > 0) B[s * bstride + k.mfirst] = (int16_t)((int)(k.head + carry) / div);
+				carry = k.tail;
+			} else {
+				carry += k.tail;
+			}
+		}
+		sout[s].now_lpr = (int)carry;
+	}
+	sout[s].prev_lpr_index = phase;
+	if (cnt_out) cnt_out[s] = E;
 }
 
 // the outputs that straddle chunk boundaries, the carried accumulator and the output count
 __global__ void __launch_bounds__(64)
 k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams, int max_chunks,
             int L, const LprChunk *__restrict__ lc, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
-            const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out,
-            const int32_t *__restrict__ only = nullptr, const int32_t *__restrict__ skip = nullptr)
+            const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out)
 {
-	for_stream_chunks(nstreams, max_chunks, only, 1, [&](const size_t s, const int c, int) {
-	if (skip && skip[s]) return;
+	for_stream_chunks(nstreams, max_chunks, 1, [&](const size_t s, const int c, int) {
 	const int n = cnt ? cnt[s] : T;
 	const int16_t *r = R + s * rstride;
 	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
@@ -1352,12 +1393,30 @@ __device__ __forceinline__ int arb_first_output(int i, int len1, int len2)
 	return (int)(((uint32_t)(i - 1) * (uint32_t)len2) / (uint32_t)len1) + 1;
 }
 
+// (one launch, its own stragglers: see tail_last_ticket above)
+// arbitrary_upsample (src/rtl_fm.c:1114-1135) of buffer b of a stream by one wave: N samples at a -> len2 at bo
+__device__ __forceinline__ void arb_upsample_wave(const int16_t *a, int16_t *bo, int len1, int len2, int lane)
+{
+	for (int j = lane; j < len2; j += 64) {
+		int i = 1, tick = 0;
+		if (j) {
+			const uint32_t adv = (uint32_t)j * (uint32_t)len1;
+			const uint32_t q = (adv - 1u) / (uint32_t)len2;
+			i = 1 + (int)q;
+			tick = (int)(adv - q * (uint32_t)len2);
+		}
+		if (i >= len1) { i = len1 - 1; tick = len2; }
+		const double frac = (double)tick / (double)len2;
+		bo[j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
+	}
+}
+
 template <int MAGIC>
 __global__ void __launch_bounds__(64)
-k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
+k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
                   int N, int len2, int nblocks, double rinv, int fast, int16_t *__restrict__ B, size_t bstride,
-                  const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ fallback,
-                  int32_t *__restrict__ cnt_out)
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, uint32_t *flag, uint32_t *ticket,
+                  uint32_t epoch, int32_t *__restrict__ cnt_out)
 {
 	extern __shared__ uint4 arb_lds[];
 	int16_t *y = reinterpret_cast<int16_t *>(arb_lds);
@@ -1367,13 +1426,13 @@ k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstr
 	constexpr int C = kArbChunk, Cp = kArbStride, span = 64 * C;
 	const int pre = W / C;  // chunks before the span
 	const int k0 = sp * span, k1 = min(k0 + span, T);
-	const int16_t *r = R + s * rstride;
+	int16_t *r = R + s * rstride;
 	const int carried = sin[s].deemph_avg;
-	if (sp == 0 && lane == 0) cnt_out[s] = nblocks * len2;
-	if ((uint32_t)(carried + 32768) > 65535u) {  // only rtlfm_gpu_state_set can do that: deemph_plain in the separate kernels
-		if (sp == 0 && lane == 0) fallback[s] = 1;
-		return;
-	}
+	if (sp == 0 && lane == 0 && cnt_out) cnt_out[s] = nblocks * len2;
+	// a carried state outside int16 (only rtlfm_gpu_state_set can do that) has no biased form: the plain loop below
+	const bool plain = (uint32_t)(carried + 32768) > 65535u;
+	bool unsettled = false;
+	if (!plain) {
 	// samples [k0 - W, k0 + span), zero outside the run
 	for (int g = lane; g < (pre + 64) * (C / 8); g += 64) {
 		const int q = g >> 2, w = g & 3;
@@ -1421,7 +1480,7 @@ k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstr
 			if (nch >= pre || !__any(mine && lo != hi)) break;
 		}
 		if (mine) {
-			if (lo != hi) fallback[s] = 1;  // what this workgroup writes for the stream is replaced afterwards
+			unsettled = lo != hi;  // what this workgroup writes for the stream is replaced afterwards
 			v = lo;
 		}
 	}
@@ -1495,34 +1554,23 @@ k_deemph_spec_arb(const int16_t *__restrict__ R, size_t rstride, int T, int nstr
 			if (tick > len2) { tick -= len2; i++; }
 		}
 	}
-}
-
-// k_arb_upsample for the streams of a list (the ones k_deemph_spec_arb gave up on, k_flag_list):
-// a workgroup per (listed stream, buffer), grid-stride; uniform buffers
-__global__ void __launch_bounds__(256)
-k_arb_upsample_only(const int16_t *__restrict__ A, size_t astride, int16_t *__restrict__ B, size_t bstride, int N, int len2,
-                    int nblocks, const int32_t *__restrict__ list)
-{
-	const size_t total = (size_t)list[0] * nblocks;
-	for (size_t w = blockIdx.x; w < total; w += gridDim.x) {
-		const size_t s = (size_t)list[1 + w / nblocks];
-		const int b = (int)(w % nblocks);
-		const int len1 = N;
-		const int16_t *a = A + s * astride + (size_t)b * N;
-		int16_t *bo = B + s * bstride + (size_t)b * len2;
-		for (int j = (int)threadIdx.x; j < len2; j += 256) {
-			int i = 1, tick = 0;
-			if (j) {
-				const uint32_t adv = (uint32_t)j * (uint32_t)len1;
-				const uint32_t q = (adv - 1u) / (uint32_t)len2;
-				i = 1 + (int)q;
-				tick = (int)(adv - q * (uint32_t)len2);
-			}
-			if (i >= len1) { i = len1 - 1; tick = len2; }
-			const double frac = (double)tick / (double)len2;
-			bo[j] = (int16_t)(a[i - 1] * (1 - frac) + a[i] * frac);
-		}
+	}  // !plain
+	// ---- the stream's last workgroup: redo it sequentially if anybody could not settle ------------------
+	if (__any(unsettled) && lane == 0) __hip_atomic_store(flag + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	int last = 0;
+	if (lane == 0) last = tail_last_ticket(ticket + s, (uint32_t)spans) ? 1 : 0;
+	last = __shfl(last, 0, 64);
+	if (!last) return;
+	if (!plain && __hip_atomic_load(flag + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) return;
+	if (lane == 0) {
+		// deemph_filter (src/rtl_fm.c:1011-1026) over the run, in place
+		if (plain) sout[s].deemph_avg = deemph_plain(r, T, carried, (int)ds.a);
+		else sout[s].deemph_avg = (int)deemph_walk<MAGIC, true>(r, T, (uint32_t)(carried + 32768), ds) - 32768;
 	}
+	__threadfence();
+	__syncthreads();
+	for (int b = 0; b < nblocks; b++)
+		arb_upsample_wave(r + (size_t)b * N, B + s * bstride + (size_t)b * len2, N, len2, lane);
 }
 
 // arbitrary_downsample (src/rtl_fm.c:1137-1166): the double remainder makes it

@@ -85,6 +85,16 @@ class GpuPower:
         return ms.value, n.value
 
 
+    def clock_probe(self, on=True):
+        check(self.lib.rtlpower_gpu_clock_probe(self._h, int(on)), "rtlpower_gpu_clock_probe")
+
+    def clock_read(self):
+        """(mean shader MHz of the last launch's workgroups, first-start-to-last-end span in ms) or None."""
+        mhz, span = C.c_double(), C.c_double()
+        r = self.lib.rtlpower_gpu_clock_read(self._h, C.byref(mhz), C.byref(span))
+        return (mhz.value, span.value) if r == 0 else None
+
+
 def window_coefs(window: int, length: int) -> np.ndarray:
     out = np.zeros(length, dtype=np.int32)
     check(capi.load().rtlpower_window_coefs(window, length, out.ctypes.data), "rtlpower_window_coefs")

@@ -28,7 +28,12 @@ CASES = [
     ("b9_bartlett_fifth1", dict(bin_e=9, window=7, downsample=2, downsample_passes=1, boxcar=0, buf_len=16384)),
     ("b12_hamming", dict(bin_e=12, window=1, buf_len=16384)),
     ("c4_b14_hamming", dict(bin_e=14, window=1, buf_len=32768)),
+    # beyond one workgroup's LDS: eight frames of 4096 points per read, and frequency_range()'s fine-bin plans
+    ("b12_8frames_hamming", dict(bin_e=12, window=1, buf_len=65536)),
+    ("b15_blackman", dict(bin_e=15, window=2, buf_len=65536)),
+    ("b17_hamming", dict(bin_e=17, window=1, buf_len=262144)),
 ]
+READS = {"b17_hamming": 2}
 
 
 def main():
@@ -37,7 +42,7 @@ def main():
     man = {}
     for name, kw in CASES:
         cfg = RtlpowerCfg.default(**kw)
-        L, nr = int(cfg.buf_len), 3
+        L, nr = int(cfg.buf_len), READS.get(name, 3)
         for kind in ("tone", "fullscale"):
             if kind == "tone":
                 iq = synth.fm_iq_u8(1, L // 2 * nr, fs=2.048e6, dev_hz=20e3, seed=11)[0]

@@ -1121,6 +1121,41 @@ def test_caller_stream_orders_the_audio_tail(oracle_lib):
         assert np.array_equal(snap[s, :nsnap[s]], want[s, :want_len[s]]), s
 
 
+def test_placement_is_observable_and_bounded():
+    """The search that places the write streams a quarter of the HBM away from the read stream
+    (rtlfm_gpu_malloc_apart_ex) is a measured walk over temporary allocations: what it found, how long it took and
+    how much it held are readable per handle, the walk is capped (apart_budget_gb), and two handles created back to
+    back on one device both come up - neither search may starve the other of memory."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, ns = 262144, 1024                     # a 256 MiB ring half: large enough for the search to run
+    ov = dict(downsample=16, downsample_passes=4)
+    cfg = make_cfg(ov, L, 1)
+    buf = np.full(L, 127, dtype=np.uint8)
+    hs = []
+    try:
+        for k in range(2):
+            g = GpuDemod(cfg, ns, 0)
+            hs.append(g)
+            assert g.get_option("ring_apart") == -1
+            for s in range(ns):
+                g.rtlsdr_callback(buf, s)    # the first push builds the ring
+            assert g.get_option("ring_apart") in (0, 1)
+            assert g.get_option("placement_walked_mb") < 100 * 1024
+            assert g.get_option("placement_ms") >= 0
+            g.full_demod(); g.fetch_all()
+        with pytest.raises(Exception):
+            hs[0].set_option("apart_budget_gb", -1)
+        # no search at all when the budget is zero
+        g0 = GpuDemod(cfg, ns, 0, options=dict(apart_budget_gb=0))
+        hs.append(g0)
+        for s in range(ns):
+            g0.rtlsdr_callback(buf, s)
+        assert g0.get_option("ring_apart") == 0 and g0.get_option("placement_walked_mb") == 0
+    finally:
+        for g in hs:
+            g.close()
+
+
 def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
     """The staging ring has two halves: callbacks keep pushing (from several threads) while the
     previous run's transfer and kernels are in flight, results are fetched one run late, nothing is
@@ -1160,13 +1195,39 @@ def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
 @pytest.mark.parametrize("a,rates,scalar", [(13, (170000, 32000), 0), (2, (48000, 11025), 0), (30, (240000, 96000), 0),
                                             (9, (170000, 169999), 0), (13, (170000, 32000), 1)])
 def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates, scalar):
-    """deemph_filter followed directly by low_pass_real on long runs (-M wbfm's tail): the time-parallel
-    filter's replay pass feeds the resampler's accumulator itself; outputs that straddle chunk
-    boundaries are put together afterwards.  Carried / injected accumulator, phase and filter state
-    (one stream with a filter state outside int16: the plain form), a silent stream and one that falls
-    silent half way (there the one-pass filter cannot settle its chunks and hands the stream to the
-    four passes), runs split over launches.  The resampler's outputs leave in 16-byte groups
-    (LprSink); `scalar`: one by one, as for output rows that are not 16-byte aligned."""
+    """deemph_filter followed directly by low_pass_real on long runs (-M wbfm's tail): ONE kernel
+    (k_deemph_spec_lpr) - every chunk settles its own incoming filter state and feeds the resampler's
+    accumulator; the lane that finishes a stream last puts the outputs that straddle chunk boundaries
+    together.  Carried / injected accumulator, phase and filter state (one stream with a filter state
+    outside int16: the plain form), a silent stream and one that falls silent half way (there the chunks
+    cannot settle and that last lane redoes the stream with the reference's sequential loop), runs split
+    over launches.  The resampler's outputs leave in 16-byte groups (LprSink); `scalar`: one by one, as
+    for output rows that are not 16-byte aligned."""
+    _lpr_tail_case(oracle_lib, a, rates, dict(lpr_scalar_stores=scalar))
+
+
+@pytest.mark.parametrize("opts", [dict(lpr_chunk=256), dict(lpr_chunk=5440), dict(deemph_four_pass=1),
+                                  dict(deemph_four_pass=1, lpr_chunk=256), dict(lpr_separate=1)])
+def test_lpr_tail_options(oracle_lib, opts):
+    """The same tail under its options: chunk lengths below and above the four-pass route's own chunk
+    (the chunk tables are sized per route), the four passes instead of the one-pass kernel, low_pass_real as a
+    kernel of its own."""
+    _lpr_tail_case(oracle_lib, 13, (170000, 32000), opts)
+
+
+def test_lpr_chunk_range():
+    from rtlsdr_amd.demod import GpuDemod
+    cfg = make_cfg(dict(downsample=6, custom_atan=1, deemph=1, deemph_a=13, rate_out=170000, rate_out2=32000,
+                        resampler=capi.RESAMPLE_LOW_PASS_REAL), 32768, 2)
+    with GpuDemod(cfg, 2, 0) as g:
+        for bad in (0, 255, (1 << 20) + 1, -5):
+            with pytest.raises(Exception):
+                g.set_option("lpr_chunk", bad)
+        g.set_option("lpr_chunk", 256)
+        assert g.get_option("lpr_chunk") == 256
+
+
+def _lpr_tail_case(oracle_lib, a, rates, options):
     from rtlsdr_amd.demod import GpuDemod
     L, nb, ns = 32768, 6, 6
     ov = dict(downsample=6, custom_atan=1, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],
@@ -1185,7 +1246,7 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates, scalar):
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
     for splits in (None, [(0, 2), (2, 3), (3, 6)]):
         outs = [[] for _ in range(ns)]
-        with GpuDemod(cfg, ns, 0, options=dict(lpr_scalar_stores=scalar)) as g:
+        with GpuDemod(cfg, ns, 0, options=options) as g:
             for s in range(ns):
                 g.state_set(s, st_copy[s])
             d = torch.from_numpy(iq).cuda()
@@ -1196,8 +1257,8 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates, scalar):
                     outs[s].append(o[s, :n[s]].copy())
             sts = [g.state_get(s) for s in range(ns)]
         for s in range(ns):
-            assert np.array_equal(np.concatenate(outs[s]), want[s, :want_len[s]]), (a, rates, splits, s)
-            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (a, rates, splits, s)
+            assert np.array_equal(np.concatenate(outs[s]), want[s, :want_len[s]]), (a, rates, options, splits, s)
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (a, rates, options, splits, s)
 
 
 @pytest.mark.parametrize("passes,L,nb,a,rates", [(6, 262144, 4, 2, (16000, 22050)),     # config 3: a span per buffer
@@ -1209,7 +1270,8 @@ def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
     """deemph_filter followed directly by arbitrary_resample on uniform buffers (config 3's tail): one
     pass from the demodulated samples to the resampled output (k_deemph_spec_arb).  Carried / injected
     filter state (one stream outside int16: the plain form), a silent stream and one that falls silent
-    half way (flagged: the separate kernels redo them), runs split over launches."""
+    half way (flagged: the stream's last workgroup redoes it with the reference's sequential loop), runs split
+    over launches."""
     from rtlsdr_amd.demod import GpuDemod
     ns = 6
     ov = dict(downsample=1 << passes, downsample_passes=passes, deemph=1, deemph_a=a, rate_out=rates[0], rate_out2=rates[1],

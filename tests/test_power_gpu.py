@@ -49,10 +49,19 @@ def test_power_golden_fixture(name):
     dict(bin_e=10, window=4, downsample=8, downsample_passes=3, boxcar=0, comp_fir_size=9, buf_len=16384),
     dict(bin_e=13, window=5, downsample=2, downsample_passes=1, boxcar=0, buf_len=32768),
     dict(bin_e=0, buf_len=16384),
+    # beyond one workgroup's LDS: the transform over the work buffer in HBM (power_kernels.h, k_power_fft_*)
+    dict(bin_e=14, window=1, buf_len=65536),                          # two frames of 16384 points per read
+    dict(bin_e=10, window=6, buf_len=262144, peak_hold=1),            # 64 frames per read
+    dict(bin_e=15, window=1, buf_len=65536),
+    dict(bin_e=16, window=3, downsample=2, boxcar=1, buf_len=262144),
+    dict(bin_e=15, window=2, downsample=2, downsample_passes=1, boxcar=0, comp_fir_size=9, buf_len=131072),
+    dict(bin_e=18, window=5, buf_len=524288),
 ])
 def test_power_batched_vs_oracle(oracle_lib, kw):
     cfg = RtlpowerCfg.default(**kw)
     L, nr, ns = int(cfg.buf_len), 5, 12
+    if L > 65536:
+        nr, ns = 3, 4
     iq = np.concatenate([synth.fm_iq_u8(ns // 2, L // 2 * nr, fs=2.048e6, dev_hz=30e3, seed=77),
                          synth.random_u8(ns // 2, L * nr, seed=78)])
     want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=4)
@@ -61,6 +70,27 @@ def test_power_batched_vs_oracle(oracle_lib, kw):
         for s in range(ns):
             assert res[s][1] == wn[s]
             assert np.array_equal(res[s][0], want[s]), (kw, s, split)
+
+
+def _skip_only_outside_scanner_domain(cfg, err):
+    """rtlpower_gpu_create may only reject what scanner() itself cannot run as a function of its input
+    (include/rtlpower_hip.h, rtlpower_cfg_validate): a trailing FFT frame that reaches past the read - there the
+    reference transforms what its static fft_buf still holds from the read before (src/rtl_power.c:695) -, a
+    partial trailing frame behind fifth_order passes, or reads too short for the passes' ease-in.  Its own
+    planner (frequency_range, :501-504: buf_len = 2N * downsample, at least 16384) produces none of these.
+    Anything else the library refuses fails the test."""
+    two_n = 2 << int(cfg.bin_e)
+    ds = max(1, int(cfg.downsample))
+    per = int(cfg.buf_len) // ds
+    frames = (per + two_n - 1) // two_n
+    passes = int(cfg.downsample_passes) if not cfg.boxcar else 0
+    outside = frames * two_n > int(cfg.buf_len) or (passes and per % two_n) or (passes and (int(cfg.buf_len) >> passes) < 48)
+    if cfg.bin_e == 0:
+        outside = False
+    if outside:
+        pytest.skip(f"outside scanner()'s own domain: {err}")
+    raise AssertionError(f"the library rejects a configuration the reference's scanner() runs: {err} "
+                         f"(bin_e={cfg.bin_e} buf_len={cfg.buf_len} ds={cfg.downsample} passes={cfg.downsample_passes} boxcar={cfg.boxcar})")
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_POWER", "40"))))
@@ -83,7 +113,7 @@ def test_power_random_configurations(oracle_lib, seed):
     try:
         GpuPower(cfg, ns, 0).close()
     except capi.RtlfmError as e:
-        pytest.skip(f"rejected by rtlpower_gpu_create: {e}")
+        _skip_only_outside_scanner_domain(cfg, e)
     L, nr = int(cfg.buf_len), int(rng.integers(2, 5))
     iq = np.concatenate([synth.fm_iq_u8(ns, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=100 + seed),
                          synth.random_u8(1, L * nr, seed=200 + seed)])
@@ -93,6 +123,55 @@ def test_power_random_configurations(oracle_lib, seed):
         for s in range(ns + 1):
             assert res[s][1] == wn[s], (kw, s, split)
             assert np.array_equal(res[s][0], want[s]), (kw, s, split)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_POWER_BIG", "10"))))
+def test_power_fine_bins_random(oracle_lib, seed):
+    """frequency_range()'s fine-bin plans, 2^15 .. 2^18 bins (src/rtl_power.c:483-486: up to 2^21): windows,
+    boxcar / fifth_order decimation in front, peak hold, reads split over launches, against the oracle."""
+    from rtlsdr_amd import capi
+    from rtlsdr_amd.power import GpuPower
+    rng = np.random.default_rng(15000 + seed)
+    bin_e = int(rng.integers(15, 19))
+    kw = dict(bin_e=bin_e, window=int(rng.integers(0, 8)), peak_hold=int(rng.random() < 0.25))
+    ds = 1
+    r = rng.random()
+    if r < 0.25:
+        ds = int(rng.choice([2, 3]))
+        kw.update(downsample=ds, boxcar=1)
+    elif r < 0.5:
+        ds = 2
+        kw.update(downsample=2, downsample_passes=1, boxcar=0, comp_fir_size=int(rng.choice([0, 9])))
+    kw["buf_len"] = (2 << bin_e) * ds  # frequency_range(): buf_len = 2 * 2^bin_e * downsample (:501)
+    cfg = RtlpowerCfg.default(**kw)
+    ns = int(rng.choice([1, 2]))
+    try:
+        GpuPower(cfg, ns, 0).close()
+    except capi.RtlfmError as e:
+        _skip_only_outside_scanner_domain(cfg, e)
+    L, nr = int(cfg.buf_len), int(rng.integers(2, 4))
+    iq = np.concatenate([synth.fm_iq_u8(ns, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=300 + seed),
+                         synth.random_u8(1, L * nr, seed=400 + seed)])
+    want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=3)
+    for split in (None, 1):
+        res = gpu_scan(cfg, iq, split=split)
+        for s in range(ns + 1):
+            assert res[s][1] == wn[s], (kw, s, split)
+            assert np.array_equal(res[s][0], want[s]), (kw, s, split)
+
+
+def test_power_clock_probe():
+    """rtlpower_gpu_clock_probe: the large-FFT kernel's workgroups stamp the shader clock they ran at."""
+    from rtlsdr_amd.power import GpuPower
+    cfg = RtlpowerCfg.default(bin_e=14, window=1, buf_len=32768)
+    iq = torch.from_numpy(synth.random_u8(64, 32768 * 4, seed=3)).cuda()
+    with GpuPower(cfg, 64, 0) as g:
+        assert g.clock_read() is None
+        g.clock_probe(True)
+        g.scan_torch(iq)
+        mhz, span = g.clock_read()
+        assert 500.0 < mhz < 3500.0 and 0 < span < 1000.0, (mhz, span)
+        g.clock_probe(False)
 
 
 def test_power_host_scanner_and_clear(oracle_lib):
