@@ -47,6 +47,11 @@ struct Params {
 	const uint8_t *dummy_tile;  // what the reload reads after a segment's last tile (fused_kernel.h)
 	int has_first;              // k_boxcar_scan: the LDS copy of each dword's first sample exists (odd D)
 	int R;                      // k_boxcar_scan: outputs per lane and tile, ceil((4096 / D + 1) / 64)
+	// emit mode (k_boxcar_scan<3>): the decimated IQ itself - what full_demod() hands on after low_pass()
+	// (src/rtl_fm.c:1200-1202) - as packed int16 pairs, output k of the run at emit_iq[s * emit_iq_stride + k]:
+	// the input of the squelch / -L level / -M raw kernels (rtlfm_hip.hip, run_boxfused_emit)
+	uint32_t *emit_iq;
+	size_t emit_iq_stride;      // dwords between streams
 };
 
 // Per 8 KiB tile (round 1 walked every window: O(D/2) LDS gathers and dot products per output and
@@ -82,7 +87,11 @@ struct ScanLds {
 	// all odd for the whole run (4096 and the buffer are even), and odd only if an odd prev_index was
 	// injected through rtlfm_gpu_state_set: that run fetches the bytes from the input itself.
 	__host__ __device__ static int pcm(bool has_first) { return has_first ? first + 64 * first_stride : first; }
-	__host__ __device__ static int total(int out_cap, bool has_first) { return pcm(has_first) + (out_cap + 16) / 2; }
+	// the tile's outputs waiting for their aligned 16-byte stores: int16 PCM, or (emit mode) packed IQ dwords
+	__host__ __device__ static int total(int out_cap, bool has_first, bool emit = false)
+	{
+		return pcm(has_first) + (emit ? out_cap + 8 : (out_cap + 16) / 2);
+	}
 };
 
 // inclusive scan over the 64 lanes of a wave
@@ -143,7 +152,8 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fu
 
 // V: 1 = -M fm -A std, 2 = -M fm -A fast (each with its discriminator compiled in: as run-time
 // choices inside the output loop they cost ~40 scalar instructions per output), 0 = everything else
-// (-A lut, AM / USB / LSB), chosen at run time
+// (-A lut, AM / USB / LSB), chosen at run time; 3 = emit mode: no demodulator, the decimated IQ is stored
+// (the power squelch, -L and -M raw work on it: src/rtl_fm.c:1204-1237, 1006-1009)
 template <int V>
 __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_scan(const Params p)
 {
@@ -197,7 +207,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	const int tQ_odd = p.rotate ? (int)0x00FF0100u : tQ_even;
 
 	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
-	int16_t *out_base = p.out + (size_t)s * p.out_stride;
+	constexpr bool EMIT = V == 3;
+	int16_t *out_base = EMIT ? nullptr : p.out + (size_t)s * p.out_stride;
+	uint32_t *emit_base = EMIT ? p.emit_iq + (size_t)s * p.emit_iq_stride : nullptr;
 	uint4 cur[8];
 	auto load_from = [&](const uint8_t *tb) {
 #pragma unroll
@@ -209,10 +221,23 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	// inside its 16-byte line: LDS group j of eight then is one aligned 16-byte piece of d_out and
 	// leaves as one dwordx4 per lane (all groups read first, then stored); the partial groups at
 	// both ends go element by element.
-	const int al = (int)(((uintptr_t)out_base >> 1) & 7);
+	const int al = EMIT ? (int)(((uintptr_t)emit_base >> 2) & 3) : (int)(((uintptr_t)out_base >> 1) & 7);
 	int flush_n = 0, flush_kb = 0;
 	auto flush = [&]() {
 		if (flush_n <= 0) return;
+		if (EMIT) {
+			// the same with 4-byte elements: LDS group j of four dwords is one aligned 16-byte piece of the row
+			const int a = (al + flush_kb) & 3, last = a + flush_n;
+			uint32_t *g32 = emit_base + ((ptrdiff_t)flush_kb - a);
+			const uint4 *e128 = reinterpret_cast<const uint4 *>(lds + pcm_at);
+			const int j0 = (a + 3) >> 2, j1 = last >> 2;
+			for (int j = j0 + lane; j < j1; j += 64) reinterpret_cast<uint4 *>(g32)[j] = e128[j];
+			const int lead_end = 4 * j0 < last ? 4 * j0 : last;
+			if (lane < 4 && a + lane < lead_end) g32[a + lane] = lds[pcm_at + a + lane];
+			const int t = 4 * j1 + (lane - 4);
+			if (lane >= 4 && lane < 8 && j1 >= j0 && t < last) g32[t] = lds[pcm_at + t];
+			return;
+		}
 		const int a = (al + flush_kb) & 7, last = a + flush_n;
 		int16_t *g16 = out_base + ((ptrdiff_t)flush_kb - a);
 		typedef uint4 __attribute__((may_alias)) u128_alias;  // the PCM is written as uint16
@@ -320,7 +345,12 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			const int e = e0 + r;
 			const uint32_t nxtP = P_at(e + 1);
 			const uint32_t z = pk_sub16(curP, prevP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
-			if (e < Et) {
+			if (EMIT) {
+				if (e < Et) {
+					lds[pcm_at + ((al + kb) & 3) + e] = z;
+					if (e == Et - 1) { lds[ScanLds::scratch] = curP; lds[ScanLds::scratch + 1] = z; }
+				}
+			} else if (e < Et) {
 				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
 				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
 				const int cr = fused::dot2_first(z, b);
@@ -339,7 +369,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			prevP = curP; b = z; curP = nxtP;
 		}
-		if (V != 1 && bs && (V != 0 || p.mode == RTLFM_MODE_FM) && Et > 0) {
+		if (V != 1 && !EMIT && bs && (V != 0 || p.mode == RTLFM_MODE_FM) && Et > 0) {
 			// fm_demod's first sample of a buffer is always polar_discriminant, whatever -A says
 			// (src/rtl_fm.c:935-937): redone here, once per buffer, instead of as a second discriminator
 			// under a per-lane condition inside the output loop (where it cost every output of a -A fast
@@ -370,7 +400,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		sout->now_r = carry_r;
 		sout->now_j = carry_j;
 		const iq16 w = unpack_iq(last_out);
-		if (V != 0 || p.mode == RTLFM_MODE_FM) { sout->pre_r = w.i; sout->pre_j = w.q; }  // only fm_demod keeps them
+		// only fm_demod keeps them (in emit mode the demodulating kernel behind this one does)
+		if (!EMIT && (V != 0 || p.mode == RTLFM_MODE_FM)) { sout->pre_r = w.i; sout->pre_j = w.q; }
 		p.cnt[s] = kb;
 	}
 }
@@ -403,23 +434,40 @@ __global__ void __launch_bounds__(64) k_boxcar_partial32(const Params p)
 	p.sout[s].now_j = aj;
 }
 
-inline bool supported(const rtlfm_cfg &c)
+// the decimator itself: what both forms of the launch need
+inline bool supported_front(const rtlfm_cfg &c)
 {
-	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
-		return false;
 	// at least two outputs per 4096-sample tile: a wave that starts mid-stream takes its first
 	// "previous output" from its warm-up tile
 	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > kMaxD) return false;
-	if (c.comp_fir_size || c.dc_block_raw || c.squelch_level || c.report_levels) return false;
+	if (c.comp_fir_size || c.dc_block_raw) return false;
 	if (c.block_len % kTileBytes) return false;
 	return true;
 }
 
+// one launch from the bytes to the PCM
+inline bool supported(const rtlfm_cfg &c)
+{
+	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
+		return false;
+	if (c.squelch_level || c.report_levels) return false;
+	return supported_front(c);
+}
+
+// emit mode: the launch stores the decimated IQ, and the squelch (src/rtl_fm.c:1204-1215), the -L levels
+// (:1217-1237) and mode_demod incl. -M raw (:1006-1009, 1256-1259) follow on 1 / D of the data
+inline bool supported_emit(const rtlfm_cfg &c)
+{
+	if (!supported_front(c)) return false;
+	return c.mode == RTLFM_MODE_RAW || c.squelch_level != 0 || c.report_levels != 0;
+}
+
 inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, int32_t *d_cnt, const state_t *sin, state_t *sout,
-                  hipStream_t q)
+                  hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0)
 {
 	Params p{};
+	p.emit_iq = emit_iq; p.emit_iq_stride = emit_iq_stride;
 	if (int r = fused::ensure_dummy_tile(ws)) return r;
 	p.dummy_tile = ws.dummy_tile;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
@@ -437,9 +485,10 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	const bool std_fm = c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM;
 	p.has_first = (p.D & 1) ? 1 : 0;
 	p.R = (p.q4096 + 1 + 63) / 64;
-	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0) * 4;
+	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0, emit_iq != nullptr) * 4;
 	const bool fast_fm = c.custom_atan == RTLFM_ATAN_FAST && c.mode == RTLFM_MODE_FM;
-	if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1>), dim3(waves), dim3(64), lds_bytes, q, p);
+	if (emit_iq) hipLaunchKernelGGL((k_boxcar_scan<3>), dim3(waves), dim3(64), lds_bytes, q, p);
+	else if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else if (fast_fm) hipLaunchKernelGGL((k_boxcar_scan<2>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else hipLaunchKernelGGL((k_boxcar_scan<0>), dim3(waves), dim3(64), lds_bytes, q, p);
 	if (p.D > 256) hipLaunchKernelGGL(k_boxcar_partial32, dim3((nstreams + 63) / 64), dim3(64), 0, q, p);

@@ -63,10 +63,6 @@ struct rtlfm_gpu {
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
-	// the one-pass tail kernels (k_deemph_spec_arb / _lpr) settle their own stragglers: per stream a flag that
-	// carries the number of the step that raised it (nobody clears it) and a ticket counter that the stream's last
-	// workgroup leaves at zero; [2][nstreams] by step parity, since two tails may be in flight on views' streams
-	uint32_t *d_tail_flag = nullptr, *d_tail_ticket = nullptr;
 	double arb_rinv = 0;                  // k_deemph_spec_arb: RN(1 / len2) and whether it reproduces tick / len2
 	int arb_len2 = 0, arb_fast = 0;
 	int deemph_chunks = 0;   // capacity of d_deemph_tab / d_deemph_inc, chunks per stream
@@ -356,15 +352,21 @@ static int ensure_work_buffers(rtlfm_gpu *h)
 	}
 	return 0;
 }
-// the /2^level IQ the fused front end emits for the staged kernels (run_fused_emit)
+// the decimated IQ a front end in emit mode leaves for the staged kernels: /2^level behind fifth_order passes
+// (run_fused_emit), 1 / D (+ 1 per buffer) behind the boxcar (run_boxfused_emit)
 static int ensure_deep_buffers(rtlfm_gpu *h)
 {
-	if (h->deepA || !fused::supported_emit(h->cfg)) return 0;
+	if (h->deepA) return 0;
 	const int N0 = (int)(h->cfg.block_len / 2);
-	const int level = h->cfg.downsample_passes < fused::kMaxP ? h->cfg.downsample_passes : fused::kMaxP;
-	h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
-	HIP_TRY(hipMalloc(&h->deepA, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc(&h->deepB, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
+	if (fused::supported_emit(h->cfg)) {
+		const int level = h->cfg.downsample_passes < fused::kMaxP ? h->cfg.downsample_passes : fused::kMaxP;
+		h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
+		HIP_TRY(hipMalloc(&h->deepA, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc(&h->deepB, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
+	} else if (boxfused::supported_emit(h->cfg)) {
+		h->deep_stride = (((size_t)h->cap_blocks * N0) / h->cfg.downsample + 1 + 16 + 3) & ~(size_t)3;  // rows start on 16-byte lines
+		HIP_TRY(hipMalloc(&h->deepA, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
+	}
 	return 0;
 }
 extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
@@ -416,7 +418,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->d_tail_flag, h->d_tail_ticket, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -790,17 +792,6 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
 			const int arb_l2 = (int)((long long)Nblk * c.rate_out2 / c.rate_out);
 			const size_t arb_lds = (size_t)(Ws / kArbChunk + 64) * kArbStride * sizeof(int16_t);
-			if (spec || spec_arb) {
-				if (!h->d_tail_flag) {
-					HIP_TRY(hipMalloc(&h->d_tail_flag, 2 * (size_t)S * sizeof(uint32_t)));
-					HIP_TRY(hipMalloc(&h->d_tail_ticket, 2 * (size_t)S * sizeof(uint32_t)));
-					HIP_TRY(hipMemsetAsync(h->d_tail_flag, 0, 2 * (size_t)S * sizeof(uint32_t), q));
-					HIP_TRY(hipMemsetAsync(h->d_tail_ticket, 0, 2 * (size_t)S * sizeof(uint32_t), q));
-				}
-			}
-			uint32_t *tflag = h->d_tail_flag ? h->d_tail_flag + (size_t)par * S : nullptr;
-			uint32_t *tticket = h->d_tail_ticket ? h->d_tail_ticket + (size_t)par * S : nullptr;
-			const uint32_t epoch = h->step + 1u;  // never 0: a flag is "raised" when it holds this step's number
 			int32_t *cnt_dst = d_out_len ? d_out_len : h->d_cnt2;
 			if (spec_arb) {
 				if (h->arb_len2 != arb_l2) {
@@ -818,9 +809,14 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				next_dst(&arb_dst, &arb_ds);
 				if (arb_dst != final_dst) return -EFAULT;  // routing bug
 				const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
-				const unsigned g = (unsigned)((size_t)S * arb_spans);
-#define RTLFM_SPEC_ARB(MM) k_deemph_spec_arb<MM><<<g, 64, arb_lds, q>>>(cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, \
-				h->arb_rinv, h->arb_fast, arb_dst, arb_ds, sin, sout, tflag, tticket, epoch, cnt_dst)
+				// a workgroup per stream (nothing crosses workgroups), its spans dealt to up to eight waves: enough
+				// waves in all to fill the GPU when the streams alone do not
+				int wpw = 8192 / S;
+				if (wpw > arb_spans) wpw = arb_spans;
+				if (wpw > kSpecArbMaxWaves) wpw = kSpecArbMaxWaves;
+				if (wpw < 1) wpw = 1;
+#define RTLFM_SPEC_ARB(MM) k_deemph_spec_arb<MM><<<(unsigned)S, 64 * wpw, arb_lds * wpw, q>>>(cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, \
+				h->arb_rinv, h->arb_fast, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
 				if (M == 2) RTLFM_SPEC_ARB(2); else if (M == 1) RTLFM_SPEC_ARB(1); else RTLFM_SPEC_ARB(0);
 #undef RTLFM_SPEC_ARB
 				RTLFM_DBG_SYNC("one pass (arb)");
@@ -851,9 +847,11 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				if (lpr_dst != final_dst) return -EFAULT;  // routing bug
 				// outputs leave in 16-byte groups where the rows allow it (staged_kernels.h, LprSink)
 				const int lpr_vec = (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
-				const unsigned gsp = (unsigned)(((size_t)S * mcsp + 63) / 64);
-#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
-				c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, tflag, tticket, epoch, cnt_dst)
+				// a workgroup owns whole streams: 256 / chunks of them, or one with a loop over its chunks
+				const int spw = mcsp >= kSpecLprThreads ? 1 : kSpecLprThreads / mcsp;
+				const unsigned gsp = (unsigned)((S + spw - 1) / spw);
+#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, kSpecLprThreads, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
+				c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, cnt_dst)
 				if (M == 2) RTLFM_SPEC_LPR(2); else if (M == 1) RTLFM_SPEC_LPR(1); else RTLFM_SPEC_LPR(0);
 #undef RTLFM_SPEC_LPR
 				RTLFM_DBG_SYNC("one pass (lpr)");
@@ -1252,6 +1250,67 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, N0, D, d_out, out_stride, d_out_len);
 }
 
+// The boxcar front end in emit mode + staged kernels on 1 / D of the data, as full_demod() goes on behind
+// low_pass(): power squelch (src/rtl_fm.c:1204-1215), -L levels (:1217-1237), mode_demod incl. -M raw
+// (:1006-1009, 1256-1259), audio tail.  The everyday scanner line - rtl_fm -M fm -s 12k -l 50 - is this.
+static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
+                             size_t out_stride, int32_t *d_out_len)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	hipStream_t q = h->stream;
+	const state_t *sin = h->st[h->st_cur];
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
+	int r = ensure_deep_buffers(h);
+	if (r < 0) return r;
+	TailPlan tp = plan_tail(c);
+	if (tp.any()) {
+		r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
+		if (r < 0) return r;
+	}
+	std::pair<hipEvent_t, hipEvent_t> ev;
+	r = timing_begin(h, ev);
+	if (r < 0) return r;
+	h->fws.tail_follows = true;  // kernels follow on this stream and, with a tail, on the tail's
+	int32_t *dcnt = h->d_cnt[h->step & 1];
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, dcnt, sin, sout, q, h->deepA, h->deep_stride);
+	if (r < 0) return r;
+	r = timing_end(h, ev);
+	if (r < 0) return r;
+	const int N0 = (int)(c.block_len / 2), D = c.downsample;
+	const int Tin = nblocks * N0;
+	const bool varcnt = (N0 % D) != 0;
+	const int T = varcnt ? Tin / D + 1 : Tin / D;
+	uint32_t *cur = h->deepA;
+	if (c.squelch_level || c.report_levels)
+		k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, N0, D, nblocks, sin, c.squelch_level, c.dc_block_raw,
+		                                         h->d_mute, h->d_levels);
+	if (c.squelch_level) {
+		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
+		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, N0, D, nblocks, S, T, sin, h->d_mute);
+	}
+	int16_t *dd; size_t dds;
+	tail_route(h, tp, d_out, out_stride, &dd, &dds);
+	const int32_t *cnt = varcnt ? dcnt : nullptr;
+	if (c.mode == RTLFM_MODE_FM)
+		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, N0, D, c.custom_atan, h->d_lut, cnt,
+		                                                 sin, sout);
+	else
+		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, c.mode, c.output_scale, cnt);
+	if (c.mode == RTLFM_MODE_RAW) {
+		if (d_out_len) {
+			if (varcnt) {
+				HIP_TRY(hipMemcpyAsync(d_out_len, dcnt, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+				k_scale_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2, 1);
+			} else {
+				k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T);
+			}
+		}
+		return 0;
+	}
+	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, N0, D, d_out, out_stride, d_out_len);
+}
+
 extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
                                     int16_t *d_out, size_t out_stride, int32_t *d_out_len)
 {
@@ -1266,6 +1325,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
+	const bool can_box_emit = boxfused::supported_emit(h->cfg);
 	const bool can_deep = fused::supported_emit(h->cfg);
 	int r;
 	{
@@ -1277,14 +1337,17 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 			h->tail_pending[par] = false;
 		}
 	}
-	if (h->path == 2 && !can_fuse && !can_box && !can_deep) return -ENOTSUP;
+	if (h->path == 2 && !can_fuse && !can_box && !can_box_emit && !can_deep) return -ENOTSUP;
 	// state is double-buffered: kernels read st[cur], write st[cur^1].  The staged kernels each
 	// update their own fields, so the record is copied first; the fused kernels copy it themselves.
-	if (!(h->path != 1 && (can_fuse || can_box || can_deep)))
+	if (!(h->path != 1 && (can_fuse || can_box || can_box_emit || can_deep)))
 		HIP_TRY(hipMemcpyAsync(h->st[(h->st_cur + 1) % 3], h->st[h->st_cur], S * sizeof(state_t),
 		                       hipMemcpyDeviceToDevice, h->stream));
 	if (h->path != 1 && can_box) {
 		r = run_boxfused(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+		h->last_path = 2;
+	} else if (h->path != 1 && can_box_emit) {
+		r = run_boxfused_emit(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
 	} else if (h->path != 1 && can_deep) {
 		r = run_fused_emit(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
@@ -1578,7 +1641,8 @@ static rtlfm_gpu make_view(rtlfm_gpu *h, int s0, int ns, uint32_t block_len)
 	v.d_rdc_avg = h->d_rdc_avg + s0 * cb;
 	v.d_adc_avg = h->d_adc_avg + s0 * cb;
 	if (h->bufA) { v.bufA = h->bufA + (size_t)s0 * h->xstride; v.bufB = h->bufB + (size_t)s0 * h->xstride; }
-	if (h->deepA) { v.deepA = h->deepA + (size_t)s0 * h->deep_stride; v.deepB = h->deepB + (size_t)s0 * h->deep_stride; }
+	if (h->deepA) v.deepA = h->deepA + (size_t)s0 * h->deep_stride;
+	if (h->deepB) v.deepB = h->deepB + (size_t)s0 * h->deep_stride;
 	return v;
 }
 

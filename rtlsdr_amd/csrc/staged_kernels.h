@@ -1020,24 +1020,15 @@ __device__ __forceinline__ void deemph_walk_pair(const int16_t *r, int n, uint32
 	}
 }
 
-// One launch, no helpers around it: a stream this kernel cannot settle (fallback) is redone by the kernel itself.
-// Every workgroup of a stream draws a ticket when it is done (ticket[s], zero between launches); the one that
-// draws the last finds the stream's flag raised (flag[s] == epoch: flags carry the launch's number, so nobody
-// has to clear them) or the carried state outside int16, and then runs the reference's own sequential loop over
-// the stream's run - deemph_filter in place, arbitrary_upsample per buffer - over what the others wrote.
-// (Round 3 had two memsets, k_flag_list, the four passes of the time-parallel filter, k_arb_upsample_only and a
-// copy of the counts around this kernel: ten operations per step on the tail's stream, each of which waited
-// for room beside the next step's front end.)
-__device__ __forceinline__ bool tail_last_ticket(uint32_t *ticket, uint32_t total)
-{
-	__threadfence();  // release: what this workgroup wrote is visible before its ticket counts
-	const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	if (old + 1 != total) return false;
-	__hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-	__threadfence();  // acquire: what the others wrote before their tickets
-	return true;
-}
-
+// The one-pass tail kernels (k_deemph_spec_lpr, k_deemph_spec_arb) are ONE launch with no helpers around them: a
+// workgroup owns whole streams, so a stream that cannot be settled (a chunk whose two extreme walks do not meet:
+// silence; a carried filter state outside int16) is redone inside the workgroup that found out, after a workgroup
+// barrier, with the reference's own sequential loop - nothing crosses workgroups.  (Round 3 had two memsets,
+// k_flag_list, the four passes of the time-parallel filter, k_arb_upsample_only and a copy of the counts around
+// these kernels: ten operations per step on the tail's stream, each of which waited for room beside the next
+// step's front end.  A first one-launch form of round 4 let the workgroups of a stream meet through a per-stream
+// ticket in global memory: on this part an agent-scope release / acquire is a write-back / invalidate of the
+// XCD's whole L2, and sixteen thousand of them made the kernel ten times slower - and the front end beside it.)
 // low_pass_real's totals over a run of n samples from the carried phase p0 (src/rtl_fm.c:755-775): outputs, phase left
 __device__ __forceinline__ void lpr_totals(long long p0, int n, int slow, int fast, int &E, int &phase)
 {
@@ -1046,48 +1037,61 @@ __device__ __forceinline__ void lpr_totals(long long p0, int n, int slow, int fa
 	phase = (int)(tot - (long long)E * fast);
 }
 
-// One launch (see k_deemph_spec_arb): every chunk's lane draws a ticket of its stream when it is done, and the
-// lane that draws the last one finishes the stream - the outputs that straddle chunk boundaries, the carried
-// accumulator, phase and count (what k_lpr_fixup does for the four-pass route), or, if some chunk could not
-// settle (flag[s] == epoch) or the carried filter state lies outside int16, the reference's own sequential
-// loop over the whole run: deemph_filter feeding low_pass_real.
+// A workgroup of `nthreads` lanes owns spw = max(1, nthreads / max_chunks) whole streams (one stream and a loop over
+// its chunks when it has more chunks than the workgroup has lanes).  Lane (stream, chunk) settles its chunk's
+// incoming filter state from the W samples before it and walks the chunk into the resampler; after a workgroup
+// barrier the lane of chunk 0 finishes its stream: the outputs that straddle chunk boundaries, the carried
+// accumulator, phase and count (what k_lpr_fixup does for the four-pass route) - or, if a chunk could not settle
+// (flag in LDS) or the carried filter state lies outside int16, the reference's own sequential loop over the run.
+constexpr int kSpecLprThreads = 256;
 template <int MAGIC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(kSpecLprThreads)
 k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                   DeemphStep ds, int max_chunks, int L, int W, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *lc, int vec,
-                  uint32_t *flag, uint32_t *ticket, uint32_t epoch, int32_t *__restrict__ cnt_out)
+                  int32_t *__restrict__ cnt_out)
 {
-	const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
-	const size_t s = g / max_chunks;
-	const int c = (int)(g % max_chunks);
-	if (s >= (size_t)nstreams) return;
-	const int n = cnt ? cnt[s] : T;
-	int16_t *r = R + s * rstride;
-	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
-	const int nc = deemph_chunks(n, head, L);
-	if (c >= nc) return;
-	const int carried = sin[s].deemph_avg;
-	const bool plain = (uint32_t)(carried + 32768) > 65535u;  // only rtlfm_gpu_state_set can do that
-	const long long p0 = sin[s].prev_lpr_index;
-	if (!plain) {
-		int begin, end;
-		deemph_chunk_range(c, n, head, L, begin, end);
-		uint32_t v = (uint32_t)(carried + 32768);
-		bool settled = true;
-		if (begin > 0) {
-			if (begin <= W) {
-				// close to the start of the run: from the carried state itself
-				uint32_t v2 = v;
-				deemph_walk_pair<MAGIC>(r, begin, v, v2, ds);
-			} else {
-				uint32_t lo = 0, hi = 65535;
-				deemph_walk_pair<MAGIC>(r + begin - W, W, lo, hi, ds);
-				settled = lo == hi;
-				v = lo;
+	__shared__ int unsettled[kSpecLprThreads];  // per stream of this workgroup
+	const int nthreads = (int)blockDim.x, tid = (int)threadIdx.x;
+	const int spw = max_chunks >= nthreads ? 1 : nthreads / max_chunks;  // streams per workgroup
+	unsettled[tid] = 0;
+	__syncthreads();
+	const int sl = spw == 1 ? 0 : tid / max_chunks;                    // this lane's stream within the workgroup
+	const size_t s = (size_t)blockIdx.x * spw + sl;
+	const bool live = sl < spw && s < (size_t)nstreams;
+	int n = 0, nc = 0, head = 0, carried = 0;
+	int16_t *r = nullptr;
+	long long p0 = 0;
+	bool plain = false;
+	if (live) {
+		n = cnt ? cnt[s] : T;
+		r = R + s * rstride;
+		head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+		nc = deemph_chunks(n, head, L);
+		carried = sin[s].deemph_avg;
+		plain = (uint32_t)(carried + 32768) > 65535u;  // only rtlfm_gpu_state_set can do that
+		p0 = sin[s].prev_lpr_index;
+	}
+	const int c_first = spw == 1 ? tid : tid - sl * max_chunks, c_step = spw == 1 ? nthreads : max_chunks;
+	if (live && !plain) {
+		for (int c = c_first; c < nc; c += c_step) {
+			int begin, end;
+			deemph_chunk_range(c, n, head, L, begin, end);
+			uint32_t v = (uint32_t)(carried + 32768);
+			bool settled = true;
+			if (begin > 0) {
+				if (begin <= W) {
+					// close to the start of the run: from the carried state itself
+					uint32_t v2 = v;
+					deemph_walk_pair<MAGIC>(r, begin, v, v2, ds);
+				} else {
+					uint32_t lo = 0, hi = 65535;
+					deemph_walk_pair<MAGIC>(r + begin - W, W, lo, hi, ds);
+					settled = lo == hi;
+					v = lo;
+				}
 			}
-		}
-		if (settled) {
+			if (!settled) { unsettled[sl] = 1; continue; }
 			const long long idx0 = p0 + (long long)begin * slow;
 			const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
 			LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
@@ -1095,14 +1099,14 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 			sink.finish();
 			lc[s * max_chunks + c] = sink.out;
 			if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
-		} else {
-			__hip_atomic_store(flag + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
-	if (!tail_last_ticket(ticket + s, (uint32_t)nc)) return;
+	__threadfence_block();  // the chunk records and outputs of this workgroup's lanes, for its finishing lanes
+	__syncthreads();
+	if (!live || c_first != 0) return;
 	int E, phase;
 	lpr_totals(p0, n, slow, fast, E, phase);
-	if (plain || __hip_atomic_load(flag + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+	if (plain || unsettled[sl]) {
 		// the reference's loop over the whole run, on this lane
 		const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(p0, fast) : (int)(p0 / fast);
 		LprSink sink(B + s * bstride, m0, (int)(p0 - (long long)m0 * fast), slow, fast, (uint32_t)sin[s].now_lpr, vec != 0);
@@ -1393,7 +1397,6 @@ __device__ __forceinline__ int arb_first_output(int i, int len1, int len2)
 	return (int)(((uint32_t)(i - 1) * (uint32_t)len2) / (uint32_t)len1) + 1;
 }
 
-// (one launch, its own stragglers: see tail_last_ticket above)
 // arbitrary_upsample (src/rtl_fm.c:1114-1135) of buffer b of a stream by one wave: N samples at a -> len2 at bo
 __device__ __forceinline__ void arb_upsample_wave(const int16_t *a, int16_t *bo, int len1, int len2, int lane)
 {
@@ -1411,28 +1414,41 @@ __device__ __forceinline__ void arb_upsample_wave(const int16_t *a, int16_t *bo,
 	}
 }
 
+// One workgroup of `wpw` waves per stream; wave w takes the spans w, w + wpw, ... of its stream, each wave with an
+// LDS region of its own (the span's traffic is wave-private: wave barriers, no workgroup barrier inside the loop).
+constexpr int kSpecArbMaxWaves = 8;
 template <int MAGIC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kSpecArbMaxWaves)
 k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
                   int N, int len2, int nblocks, double rinv, int fast, int16_t *__restrict__ B, size_t bstride,
-                  const state_t *__restrict__ sin, state_t *__restrict__ sout, uint32_t *flag, uint32_t *ticket,
-                  uint32_t epoch, int32_t *__restrict__ cnt_out)
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, size_t lds_per_wave,
+                  int32_t *__restrict__ cnt_out)
 {
 	extern __shared__ uint4 arb_lds[];
-	int16_t *y = reinterpret_cast<int16_t *>(arb_lds);
-	const int lane = (int)threadIdx.x;
-	const size_t s = blockIdx.x / (unsigned)spans;
-	const int sp = (int)(blockIdx.x % (unsigned)spans);
+	__shared__ int wg_unsettled;
+	const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wpw = (int)blockDim.x >> 6;
+	int16_t *y = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(arb_lds) + (size_t)wave * lds_per_wave);
+	const size_t s = blockIdx.x;
 	constexpr int C = kArbChunk, Cp = kArbStride, span = 64 * C;
 	const int pre = W / C;  // chunks before the span
-	const int k0 = sp * span, k1 = min(k0 + span, T);
 	int16_t *r = R + s * rstride;
 	const int carried = sin[s].deemph_avg;
-	if (sp == 0 && lane == 0 && cnt_out) cnt_out[s] = nblocks * len2;
+	if (threadIdx.x == 0) {
+		wg_unsettled = 0;
+		if (cnt_out) cnt_out[s] = nblocks * len2;
+	}
+	__syncthreads();
 	// a carried state outside int16 (only rtlfm_gpu_state_set can do that) has no biased form: the plain loop below
 	const bool plain = (uint32_t)(carried + 32768) > 65535u;
+	auto wave_sync = [&]() {  // LDS traffic of one wave is in order: a wave barrier + the fences the compiler needs
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
+	for (int sp = wave; sp < spans && !plain; sp += wpw) {
+	const int k0 = sp * span, k1 = min(k0 + span, T);
 	bool unsettled = false;
-	if (!plain) {
+	wave_sync();  // the span before is done with this wave's LDS region
 	// samples [k0 - W, k0 + span), zero outside the run
 	for (int g = lane; g < (pre + 64) * (C / 8); g += 64) {
 		const int q = g >> 2, w = g & 3;
@@ -1447,7 +1463,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		}
 		*reinterpret_cast<uint4 *>(y + q * Cp + w * 8) = v;
 	}
-	__syncthreads();
+	wave_sync();
 	// the state at the start of this lane's chunk (chunk pre + lane of the array): from the `pre` chunks before it
 	const int begin = k0 + lane * C, end = min(begin + C, T);
 	uint32_t v = (uint32_t)(carried + 32768);
@@ -1484,7 +1500,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 			v = lo;
 		}
 	}
-	__syncthreads();
+	wave_sync();
 	// the filtered sample before the span (left neighbour of its first sample), then the chunk in place
 	if (lane == 0) y[pre * Cp - (Cp - C) - 1] = (int16_t)(uint16_t)(v ^ 0x8000u);
 	if (begin < T) {
@@ -1510,7 +1526,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		}
 		if (end == T) sout[s].deemph_avg = (int)v - 32768;
 	}
-	__syncthreads();
+	wave_sync();
 	// arbitrary_upsample (src/rtl_fm.c:1114-1135) of the buffers that intersect the span
 	const int poff = pre * C;
 	auto at = [&](int rel) {  // filtered sample k0 + rel, rel >= -1
@@ -1554,21 +1570,18 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 			if (tick > len2) { tick -= len2; i++; }
 		}
 	}
-	}  // !plain
-	// ---- the stream's last workgroup: redo it sequentially if anybody could not settle ------------------
-	if (__any(unsettled) && lane == 0) __hip_atomic_store(flag + s, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	int last = 0;
-	if (lane == 0) last = tail_last_ticket(ticket + s, (uint32_t)spans) ? 1 : 0;
-	last = __shfl(last, 0, 64);
-	if (!last) return;
-	if (!plain && __hip_atomic_load(flag + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) return;
+	if (__any(unsettled) && lane == 0) wg_unsettled = 1;
+	}  // spans of this wave
+	// ---- anybody who could not settle (or a state outside int16): the reference's sequential loop, by wave 0 ------
+	__syncthreads();
+	if (wave != 0 || !(plain || wg_unsettled)) return;
 	if (lane == 0) {
 		// deemph_filter (src/rtl_fm.c:1011-1026) over the run, in place
 		if (plain) sout[s].deemph_avg = deemph_plain(r, T, carried, (int)ds.a);
 		else sout[s].deemph_avg = (int)deemph_walk<MAGIC, true>(r, T, (uint32_t)(carried + 32768), ds) - 32768;
 	}
-	__threadfence();
-	__syncthreads();
+	__threadfence_block();
+	wave_sync();
 	for (int b = 0; b < nblocks; b++)
 		arb_upsample_wave(r + (size_t)b * N, B + s * bstride + (size_t)b * len2, N, len2, lane);
 }

@@ -20,8 +20,12 @@ SEED_BASE = 0x5D2000
 
 def fm_iq_u8(nstreams: int, nsamples: int, fs: float = 2.4e6, dev_hz: float = 75e3,
              amplitude: float = 60.0, noise_lsb: int = 3, seed: int = SEED_BASE,
-             first_stream: int = 0) -> np.ndarray:
-    """uint8 [nstreams, 2*nsamples] interleaved I,Q."""
+             first_stream: int = 0, quiet: tuple | None = None) -> np.ndarray:
+    """uint8 [nstreams, 2*nsamples] interleaved I,Q.
+
+    quiet = (period, on) in samples: the carrier is keyed - samples n with n % period >= on are 127, 127 (no
+    signal, no noise), so that callback buffers come out loud, silent and half of each: what a power squelch
+    (src/rtl_fm.c:1204-1215) has to tell apart."""
     out = np.empty((nstreams, 2 * nsamples), dtype=np.uint8)
     n = np.arange(nsamples, dtype=np.float64)
     for s in range(nstreams):
@@ -39,6 +43,10 @@ def fm_iq_u8(nstreams: int, nsamples: int, fs: float = 2.4e6, dev_hz: float = 75
         q = np.floor(127.5 + amplitude * np.sin(phi) + u[1])
         out[s, 0::2] = np.clip(i, 0, 255).astype(np.uint8)
         out[s, 1::2] = np.clip(q, 0, 255).astype(np.uint8)
+        if quiet is not None:
+            off = (np.arange(nsamples) % int(quiet[0])) >= int(quiet[1])
+            out[s, 0::2][off] = 127
+            out[s, 1::2][off] = 127
     return out
 
 

@@ -63,6 +63,11 @@ CASES = [
     ("box10_deemph_arb_down96000", dict(downsample=10, custom_atan=ATAN_FAST, deemph=1, deemph_a=19, rate_out=240000,
                                         rate_out2=96000, resampler=RESAMPLE_ARBITRARY), WB),
     ("box1000_std_squelch", dict(downsample=1000, rate_out=1000, squelch_level=50), dict(fs=1.0e6, dev_hz=200.0)),
+    # the everyday scanner line, rtl_fm -M fm -s 12k -l 50: the default boxcar (/84) + the power squelch, on a keyed
+    # carrier (loud, silent and half-and-half buffers); and -M raw behind the boxcar
+    ("box84_fm_squelch50", dict(downsample=84, rate_out=12000, squelch_level=50),
+     dict(fs=1.008e6, dev_hz=2.5e3, amplitude=0.8, quiet=(40000, 22000))),
+    ("raw_box10", dict(mode=MODE_RAW, downsample=10, rate_out=240000), WB),
 ]
 
 

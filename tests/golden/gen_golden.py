@@ -30,11 +30,12 @@ from rtlsdr_amd import synth  # noqa: E402
 # (block_len, nblocks) per fixture family
 SHAPES_MAIN = [(16384, 3)]
 SHAPES_SMALL = [(2048, 5)]
-BIG = {"c2_p4_std": [(262144, 2)], "c3_p6_fir9_deemph": [(262144, 2)]}
+BIG = {"c2_p4_std": [(262144, 2)], "c3_p6_fir9_deemph": [(262144, 2)], "box84_fm_squelch50": [(32768, 8)]}
 MAIN = {"box42_dc", "box84_am_dc", "box6_wbfm_dc", "box334_usb", "box42_dc_arb_up32000",
         "box10_deemph_arb_down96000",
         "c1_boxcar10_fast", "c2_p4_std", "c2_p4_fir9_std", "c3_p6_fir9_deemph",
-        "c3_p6_fir9_deemph_up22050", "wbfm_preset", "c2_p4_lut", "c2_p4_fast_a40"}
+        "c3_p6_fir9_deemph_up22050", "wbfm_preset", "c2_p4_lut", "c2_p4_fast_a40",
+        "box84_fm_squelch50", "raw_box10"}
 
 
 def main():

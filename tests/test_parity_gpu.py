@@ -1305,9 +1305,44 @@ def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (splits, s)
 
 
+@pytest.mark.parametrize("ov,sig", [
+    (dict(downsample=84, rate_out=12000, squelch_level=50), dict(fs=1.008e6, dev_hz=2.5e3, amplitude=0.8, quiet=(40000, 22000))),  # rtl_fm -M fm -s 12k -l 50
+    (dict(downsample=84, rate_out=12000, squelch_level=50, custom_atan=1), dict(fs=1.008e6, dev_hz=2.5e3, amplitude=0.8, quiet=(30000, 9000))),
+    (dict(downsample=1000, rate_out=1000, squelch_level=50), dict(fs=1.0e6, dev_hz=200.0)),
+    (dict(downsample=42, rate_out=24000, report_levels=1, deemph=1, deemph_a=2), dict(fs=1.008e6, dev_hz=2.5e3)),
+    (dict(downsample=7, rate_out=48000, squelch_level=300, rate_out2=11025, resampler=capi.RESAMPLE_LOW_PASS_REAL),
+     dict(fs=1.008e6, dev_hz=2.5e3, amplitude=30.0, quiet=(50000, 30000))),
+    (dict(mode=capi.MODE_RAW, downsample=10, rate_out=240000), dict(fs=2.4e6, dev_hz=75e3)),
+    (dict(mode=capi.MODE_RAW, downsample=3, rate_out=800000, squelch_level=5000), dict(fs=2.4e6, dev_hz=75e3, quiet=(20000, 12000))),
+    (dict(mode=capi.MODE_AM, downsample=84, rate_out=12000, output_scale=3, squelch_level=40), dict(fs=1.008e6, dev_hz=2.5e3, amplitude=0.8, quiet=(40000, 22000))),
+    (dict(mode=capi.MODE_USB, downsample=334, rate_out=3000, report_levels=1), dict(fs=1.002e6, dev_hz=1e3)),
+])
+@pytest.mark.parametrize("L,nb,ns", [(16384, 7, 5), (32768, 4, 33), (262144, 2, 3)])
+def test_boxcar_front_end_emit_mode(oracle_lib, ov, sig, L, nb, ns):
+    """The default decimator (low_pass, no -F) with the power squelch, -L levels or -M raw behind it: the one-launch
+    boxcar kernel stores the decimated IQ (k_boxcar_scan<3>) and the squelch / demodulator kernels finish on 1 / D of
+    the data - last_path == 2, where rounds 1-3 fell back to the staged kernels.  Keyed carriers (loud, silent and
+    half-and-half buffers: the squelch opens and closes, squelch_hits counts), every stream another delay; against the
+    oracle and the staged path, one run and split runs."""
+    cfg = make_cfg(ov, L, nb)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=6100, **sig)
+    for s in range(ns):  # shift the keying per stream, so that streams mute different buffers
+        iq[s] = np.roll(iq[s], 2 * 3111 * s)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for path, splits in ((0, None), (0, [(0, 1), (1, nb)]), (1, None)):
+        outs, sts, used = gpu_run(cfg, iq, path=path, splits=splits)
+        assert used == (1 if path == 1 else 2), (ov, path, used)
+        for s in range(ns):
+            assert len(outs[s]) == want_len[s], (ov, L, path, splits, s)
+            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{ov} L={L} path={path} splits={splits} [{s}]")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
+
+
 @pytest.mark.parametrize("ov", [dict(downsample=16, downsample_passes=4, report_levels=1),
                                 dict(downsample=16, downsample_passes=4, squelch_level=900),
                                 dict(downsample=42, rate_out=24000, report_levels=1, dc_block_raw=1),
+                                dict(downsample=42, rate_out=24000, report_levels=1),   # the boxcar front end's emit mode
+                                dict(downsample=10, rate_out=240000, squelch_level=700),
                                 dict(downsample=128, downsample_passes=7, comp_fir_size=9, report_levels=1)])
 def test_per_buffer_levels(oracle_lib, ov):
     """rtlfm_gpu_levels: `sr` of full_demod() (src/rtl_fm.c:1204-1237) — rms() of the decimated IQ of
