@@ -358,7 +358,7 @@ def cpu_baseline_power(cfg, sample, seconds, gate=None):
                       f"x {reps} reps ({samples / 1e6:.0f} Msamples in {dt:.1f} s)"}
 
 
-def e2e_leg(a, job, local_rank, seconds=3.0):
+def e2e_leg(a, job, local_rank, seconds=3.0, quick=False):
     """PCIe-inclusive rate through the callback boundary: host buffers -> rtlfm_gpu_push
     (memcpy into the pinned ring, 16 pushing threads as 16 dongle threads would) -> rtlfm_gpu_run (async
     H2D + kernels) -> rtlfm_gpu_fetch_all (one D2H), pipelined: the callbacks of run k + 1 fill the other
@@ -413,6 +413,8 @@ def e2e_leg(a, job, local_rank, seconds=3.0):
                            f"native threads rtlfm_gpu_push (pageable -> pinned ring) | rtlfm_gpu_run (async H2D + kernels) | "
                            f"rtlfm_gpu_fetch_all_prev (two runs in flight: run k + 1 is started before the audio of run k is "
                            f"collected, so the H2D copies follow each other on the link); bounded by PCIe, not by the kernels"}
+            if quick:  # the per-rank leg of an N > 1 run: the push loop and the H2D rate only
+                return out
             za = run_native(cfg, S, "acquire", seconds)
             if za:
                 out["zero_copy"] = {"GB/s_in": za["GB/s_in"], "value": za["Msamples/s"], "frac_of_pinned_h2d": round(za["GB/s_in"] / h2d, 3),
@@ -953,16 +955,38 @@ def main():
     e2e = None
     if a.e2e and rank == 0 and world == 1 and a.tail != "power" and not a.pmc_child:
         e2e = e2e_leg(a, job, local_rank)
+    # N > 1: at eight GPUs the curve is the HOST side (8 x ~56 GB/s of pinned H2D through one box's memory), so every
+    # rank times its own PCIe-inclusive loop at the same moment (all ranks between two barriers) and reports it with
+    # its pinned-H2D rate and whether its output got its placement
+    e2e_rank = None
+    if a.e2e and world > 1 and a.tail != "power" and not a.pmc_child:
+        dist.barrier()
+        try:
+            r_ = e2e_leg(a, job, local_rank, seconds=2.0, quick=True)
+            e2e_rank = (float(r_["GB/s_in"]), float(r_["pinned_h2d_GB/s"]))
+        except Exception as ex:  # noqa: BLE001 - the leg is a report, not the benchmark
+            print(f"bench.py: rank {rank}: e2e leg failed: {ex!r}", file=sys.stderr)
+            e2e_rank = (0.0, 0.0)
+        dist.barrier()
 
     n_devices, scatter, per_rank = 1, None, None
     if dist:
         cdev = dev if dist.get_backend() == "nccl" else "cpu"
         # every rank's own clock and front-end launch time, so that host-side contention shows
-        mine = torch.tensor([elapsed / a.steps * 1e3, front_ms / max(launches, 1)], dtype=torch.float64, device=cdev)
+        mine = torch.tensor([elapsed / a.steps * 1e3, front_ms / max(launches, 1),
+                             1.0 if getattr(job, "output_apart", False) else 0.0,
+                             e2e_rank[0] if e2e_rank else -1.0, e2e_rank[1] if e2e_rank else -1.0], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {"ms_per_step": [round(float(x[0]), 4) for x in allr], "launch_ms": [round(float(x[1]), 4) for x in allr],
+                    "output_apart": [bool(x[2] > 0.5) for x in allr],
                     "backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if e2e_rank:
+            per_rank["e2e_GB/s_in"] = [round(float(x[3]), 2) for x in allr]
+            per_rank["pinned_h2d_GB/s"] = [round(float(x[4]), 1) for x in allr]
+            per_rank["e2e_GB/s_in_sum"] = round(sum(float(x[3]) for x in allr), 1)
+            per_rank["e2e_what"] = ("every rank's own push / run / fetch loop (rtlfm_gpu_push from 8 native threads pinned to its device's NUMA "
+                                    "node, 1024 streams x 1 buffer per run), all ranks at the same time: PCIe- and host-memory-bound")
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

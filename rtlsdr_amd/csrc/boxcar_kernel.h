@@ -2,9 +2,13 @@
 //   u8 IQ -> (-127, rotate16_neg90) -> low_pass boxcar sum of D samples -> fm_demod -> int16 PCM
 // (src/rtl_fm.c:1326-1338, :461-481, :932-959), the path of `rtl_fm` without -F, of config 1
 // and of the `-M wbfm` preset.  Same work decomposition as fused_kernel.h: one wave walks a
-// run of whole callback buffers of one stream in 8 KiB tiles (4096 complex samples), a wave
-// that starts mid-stream runs one warm-up tile, the next tile's loads are in flight while a
-// tile is processed, no workgroup barriers.
+// run of one stream in 8 KiB tiles (4096 complex samples), a wave that starts mid-stream runs one
+// warm-up tile, the next tile's loads are in flight while a tile is processed, no workgroup barriers.
+// Callback buffers need not be whole tiles (-W n: any 512 n bytes, src/rtl_fm.c:1869-1873): low_pass carries
+// its sum and count across buffers, and rotate16_neg90's phase restarts every buffer but buffers are
+// multiples of four samples - so the run is ONE continuous sample stream here, whose last tile may be
+// partial (its missing bytes read as 127 = sample 0: the sums do not move); a buffer boundary only
+// matters to fm_demod, whose first output of every buffer is polar_discriminant whatever -A says.
 //
 // low_pass keeps a running sum (now_r, now_j) and a count prev_index across buffers, so with
 // p0 samples already accumulated at the start of the run, output k covers run samples
@@ -52,6 +56,7 @@ struct Params {
 	// the input of the squelch / -L level / -M raw kernels (rtlfm_hip.hip, run_boxfused_emit)
 	uint32_t *emit_iq;
 	size_t emit_iq_stride;      // dwords between streams
+	const int2 *rdc_avg;        // RDC kernels: [stream][nblocks] (avgI, avgQ) of dc_block_raw_filter (k_rdc_sums_wide / k_rdc_smooth)
 };
 
 // Per 8 KiB tile (round 1 walked every window: O(D/2) LDS gathers and dot products per output and
@@ -154,7 +159,13 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fu
 // choices inside the output loop they cost ~40 scalar instructions per output), 0 = everything else
 // (-A lut, AM / USB / LSB), chosen at run time; 3 = emit mode: no demodulator, the decimated IQ is stored
 // (the power squelch, -L and -M raw work on it: src/rtl_fm.c:1204-1237, 1006-1009)
-template <int V>
+// RDC: dc_block_raw_filter (-E rdc, src/rtl_fm.c:1043-1065) in front of the boxcar.  It subtracts one (aI, aQ) per
+// buffer before the rotation, and the rotated constant sums to zero over every four samples: with c = aI + j aQ,
+// sum_{m<n} (-j)^m c = c G(n & 3), G = 0, 1, 1 - j, -j.  So P~(n) = P(n) - c G(n & 3) is the prefix sum of the filtered
+// samples, a tile (4096 samples of ONE buffer: whole-tile buffers only) starts and ends with a correction of zero, and
+// the only change is one subtraction where a prefix is looked up.  The averages come from a pre-pass over the input
+// (k_rdc_sums_wide, k_rdc_smooth), as for the fifth_order front end.  Rotating chains only (no offset tuning).
+template <int V, bool RDC = false>
 __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_scan(const Params p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -163,8 +174,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	const int seg = wave / p.nstreams;
 	const int s = wave - seg * p.nstreams;
 	if (seg >= p.segs) return;
-	const int tpb = (int)(p.block_len / kTileBytes);
-	const int total_tiles = p.nblocks * tpb;
+	const long long run_bytes = (long long)p.nblocks * p.block_len;
+	const int total_tiles = (int)((run_bytes + kTileBytes - 1) / kTileBytes);
+	const int N0 = (int)(p.block_len / 2);  // samples per buffer
 	int t0, t1;
 	fused::segment_bounds(p, seg, total_tiles, t0, t1);
 	if (t0 >= t1) return;
@@ -211,11 +223,26 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	int16_t *out_base = EMIT ? nullptr : p.out + (size_t)s * p.out_stride;
 	uint32_t *emit_base = EMIT ? p.emit_iq + (size_t)s * p.emit_iq_stride : nullptr;
 	uint4 cur[8];
-	auto load_from = [&](const uint8_t *tb) {
+	// The tile's eight 1 KiB rows.  Only the run's last tile can be partial (a multiple of 512 bytes): whole
+	// rows behind its end come from the dummy tile (a scalar select per row), and the row its end cuts in
+	// two is read 512 bytes early, so that no byte outside the run is touched - stage() puts it right.
+	auto load_tile = [&](int tile) {
+		const bool real = tile < gt_end;
+		const uint8_t *tb = real ? stream_base + (size_t)tile * kTileBytes : p.dummy_tile;
+		const long long left = real ? run_bytes - (long long)tile * kTileBytes : (long long)kTileBytes;
+		const int valid = left < kTileBytes ? (int)left : kTileBytes;  // wave-uniform
 #pragma unroll
-		for (int k = 0; k < 8; k++) cur[k] = fused::load_stream16(tb + k * 1024 + lane * 16);
+		for (int k = 0; k < 8; k++) {
+			const uint8_t *row = tb + k * 1024;
+			if (k * 1024 >= valid) row = p.dummy_tile + k * 1024;
+			else if (k * 1024 + 512 == valid) {
+				if (tile > 0 || k > 0) row -= 512;
+				else row = lane < 32 ? row : p.dummy_tile;  // a run of 512 bytes in all: nothing before it to read early
+			}
+			cur[k] = fused::load_stream16(row + lane * 16);
+		}
 	};
-	load_from(stream_base + (size_t)gt_begin * kTileBytes);
+	load_tile(gt_begin);
 
 	// The PCM of a tile waits in LDS at index ((al + kb) & 7) + e, al = the row's element offset
 	// inside its 16-byte line: LDS group j of eight then is one aligned 16-byte piece of d_out and
@@ -251,12 +278,30 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	};
 
 	for (int gt = gt_begin; gt < gt_end; gt++) {
-		const bool more = gt + 1 < gt_end;
-		const bool bs = (gt % tpb) == 0;
 		const bool emit = gt >= gt_first;
-		const int wrap = (ph + p.r4096 >= D) ? 1 : 0;
-		const int Et = p.q4096 + wrap;
-		const int ph_next = ph + p.r4096 - (wrap ? D : 0);
+		const long long left = run_bytes - (long long)gt * kTileBytes;
+		const bool partial = left < kTileBytes;               // the run's last tile, cut short
+		const int vs = partial ? (int)(left / 2) : kTileSamples;  // samples in this tile
+		int Et, ph_next;
+		if (!partial) {
+			const int wrap = (ph + p.r4096 >= D) ? 1 : 0;
+			Et = p.q4096 + wrap;
+			ph_next = ph + p.r4096 - (wrap ? D : 0);
+		} else {
+			Et = __builtin_amdgcn_readfirstlane((ph + vs) / D);
+			ph_next = ph + vs - Et * D;
+		}
+		uint32_t dc1 = 0, dc2 = 0, dc3 = 0;  // c G(1), c G(2), c G(3) as packed int16 pairs
+		int dcI = 0, dcQ = 0;
+		if constexpr (RDC) {
+			const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + (int)(((long long)gt * kTileSamples) / N0));
+			const int2 a = p.rdc_avg[idx];  // a scalar load: a vector one would share the in-order vmcnt with the tile prefetch
+			dcI = __builtin_amdgcn_readfirstlane(a.x); dcQ = __builtin_amdgcn_readfirstlane(a.y);
+			dc1 = pack_iq((int16_t)dcI, (int16_t)dcQ);
+			dc2 = pack_iq((int16_t)(dcI + dcQ), (int16_t)(dcQ - dcI));
+			dc3 = pack_iq((int16_t)dcQ, (int16_t)-dcI);
+			if (gt + 1 == gt_end && writes_state && lane == 0) { sout->dc_avgI = dcI; sout->dc_avgQ = dcQ; }  // src/rtl_fm.c:1062-1063
+		}
 
 		// ---- 1. stage S: chunk c = 64k + lane -> row c >> 3, 16-byte slot c & 7
 #pragma unroll
@@ -267,8 +312,21 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			*reinterpret_cast<uint4 *>(lds + ScanLds::rows + row_at(4 * c)) = v;
 		}
 		__builtin_amdgcn_wave_barrier();
+		if (partial) {
+			// the row the run's end cuts in two was read 512 bytes early (load_tile): its second half is the
+			// row's first half, and what follows the end is sample 0 (S = 0), like the dummy rows behind it
+			const int valid = 2 * vs, kh = valid >> 10;
+			if ((valid & 1023) && (gt > 0 || kh > 0)) {
+				const int c = 64 * kh + lane;
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (lane < 32) v = *reinterpret_cast<const uint4 *>(lds + ScanLds::rows + row_at(4 * (c + 32)));
+				__builtin_amdgcn_wave_barrier();
+				*reinterpret_cast<uint4 *>(lds + ScanLds::rows + row_at(4 * c)) = v;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
 		flush();
-		load_from(more ? stream_base + (size_t)(gt + 1) * kTileBytes : p.dummy_tile);  // unconditional (fused_kernel.h)
+		load_tile(gt + 1);  // unconditional: behind the segment's last tile it reads the dummy tile (fused_kernel.h)
 
 		// ---- 2. the lane's running sum = exclusive prefix before each of its dwords
 		uint32_t pk[32];
@@ -328,6 +386,11 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				fs = plus ? fs : pk_sub16(0u, fs);
 				Pv = (n & 1) ? pk_add16(Pv, fs) : Pv;
 			}
+			if constexpr (RDC) {
+				const int k = n & 3;
+				const uint32_t corr = k == 0 ? 0u : (k == 1 ? dc1 : (k == 2 ? dc2 : dc3));
+				Pv = pk_sub16(Pv, corr);
+			}
 			return Pv;
 		};
 		const int R = p.R;
@@ -369,16 +432,27 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			prevP = curP; b = z; curP = nxtP;
 		}
-		if (V != 1 && !EMIT && bs && (V != 0 || p.mode == RTLFM_MODE_FM) && Et > 0) {
+		if (V != 1 && !EMIT && (V != 0 || p.mode == RTLFM_MODE_FM) && Et > 0) {
 			// fm_demod's first sample of a buffer is always polar_discriminant, whatever -A says
-			// (src/rtl_fm.c:935-937): redone here, once per buffer, instead of as a second discriminator
-			// under a per-lane condition inside the output loop (where it cost every output of a -A fast
-			// run the std path's instructions as well)
-			const uint32_t z0 = pk_sub16(P_at(0), edgeP), b0 = last_out;
-			const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
-			const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
-			const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
-			if (lane == 0) pcm[(al + kb) & 7] = (uint16_t)(int16_t)v0;
+			// (src/rtl_fm.c:935-937): redone here, behind the loop, instead of as a second discriminator under a
+			// per-lane condition inside it (where it cost every output of a -A fast run the std path's
+			// instructions as well).  Buffer b starts at run sample b N0 and its first output is output
+			// (p0 + b N0) / D of the run: lane c looks at the c-th buffer that can have it in this tile.
+			const long long s_lo = (long long)gt * kTileSamples - D, s_hi = (long long)gt * kTileSamples + vs - 1;
+			const int b_a = s_lo <= 0 ? 0 : (int)(s_lo / N0), b_b = (int)(s_hi / N0);
+			__builtin_amdgcn_wave_barrier();
+			for (int bb = b_a + lane; bb <= b_b; bb += 64) {
+				const long long K = ((long long)p0 + (long long)bb * N0) / D;
+				const long long e64 = K - kb;
+				if (bb >= p.nblocks || e64 < 0 || e64 >= Et) continue;
+				const int e = (int)e64;
+				const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
+				const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
+				const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
+				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
+				const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
+				pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v0;
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 		const uint32_t Plast = lds[ScanLds::scratch];
@@ -420,8 +494,13 @@ __global__ void __launch_bounds__(64) k_boxcar_partial32(const Params p)
 	int ar = 0, aj = 0;
 	if (first < 0) { ar = p.sin[s].now_r; aj = p.sin[s].now_j; first = 0; }
 	const uint8_t *src = p.iq + (size_t)s * p.stream_stride;
+	const long long n0 = p.block_len / 2;
 	for (long long i = first; i < total; i++) {
-		const int a = (int)src[2 * i] - 127, b = (int)src[2 * i + 1] - 127;
+		int a = (int)src[2 * i] - 127, b = (int)src[2 * i + 1] - 127;
+		if (p.rdc_avg) {  // dc_block_raw_filter: this buffer's averages off, before the rotation
+			const int2 av = p.rdc_avg[(size_t)s * p.nblocks + (size_t)(i / n0)];
+			a -= av.x; b -= av.y;
+		}
 		// rotate16_neg90 restarts with every buffer, and buffers are multiples of four samples
 		switch (p.rotate ? (int)(i & 3) : 0) {
 		case 0: ar += a; aj += b; break;
@@ -440,9 +519,10 @@ inline bool supported_front(const rtlfm_cfg &c)
 	// at least two outputs per 4096-sample tile: a wave that starts mid-stream takes its first
 	// "previous output" from its warm-up tile
 	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > kMaxD) return false;
-	if (c.comp_fir_size || c.dc_block_raw) return false;
-	if (c.block_len % kTileBytes) return false;
-	return true;
+	if (c.comp_fir_size) return false;
+	// -E rdc: the rotated constant sums to zero over a tile only when buffers are whole tiles and the chain rotates
+	if (c.dc_block_raw && (c.offset_tuning || (c.block_len % kTileBytes))) return false;
+	return true;  // else any buffer length (a multiple of 512 bytes): the run is one continuous sample stream here
 }
 
 // one launch from the bytes to the PCM
@@ -464,10 +544,11 @@ inline bool supported_emit(const rtlfm_cfg &c)
 
 inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, int32_t *d_cnt, const state_t *sin, state_t *sout,
-                  hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0)
+                  hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0, const int2 *rdc_avg = nullptr)
 {
 	Params p{};
 	p.emit_iq = emit_iq; p.emit_iq_stride = emit_iq_stride;
+	p.rdc_avg = rdc_avg;
 	if (int r = fused::ensure_dummy_tile(ws)) return r;
 	p.dummy_tile = ws.dummy_tile;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
@@ -478,7 +559,8 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.mode = c.mode; p.output_scale = c.output_scale;
 	p.D = c.downsample; p.q4096 = kTileSamples / p.D; p.r4096 = kTileSamples % p.D;
 	p.out_cap = kTileSamples / p.D + 2;
-	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, nblocks * (int)(c.block_len / kTileBytes));
+	const long long run_bytes = (long long)nblocks * c.block_len;
+	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, (int)((run_bytes + kTileBytes - 1) / kTileBytes));
 	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
 	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;
@@ -487,7 +569,12 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.R = (p.q4096 + 1 + 63) / 64;
 	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0, emit_iq != nullptr) * 4;
 	const bool fast_fm = c.custom_atan == RTLFM_ATAN_FAST && c.mode == RTLFM_MODE_FM;
-	if (emit_iq) hipLaunchKernelGGL((k_boxcar_scan<3>), dim3(waves), dim3(64), lds_bytes, q, p);
+	if (rdc_avg) {
+		if (emit_iq) hipLaunchKernelGGL((k_boxcar_scan<3, true>), dim3(waves), dim3(64), lds_bytes, q, p);
+		else if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1, true>), dim3(waves), dim3(64), lds_bytes, q, p);
+		else if (fast_fm) hipLaunchKernelGGL((k_boxcar_scan<2, true>), dim3(waves), dim3(64), lds_bytes, q, p);
+		else hipLaunchKernelGGL((k_boxcar_scan<0, true>), dim3(waves), dim3(64), lds_bytes, q, p);
+	} else if (emit_iq) hipLaunchKernelGGL((k_boxcar_scan<3>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else if (fast_fm) hipLaunchKernelGGL((k_boxcar_scan<2>), dim3(waves), dim3(64), lds_bytes, q, p);
 	else hipLaunchKernelGGL((k_boxcar_scan<0>), dim3(waves), dim3(64), lds_bytes, q, p);

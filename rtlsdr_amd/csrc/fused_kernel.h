@@ -321,10 +321,11 @@ __device__ __forceinline__ void hand_off(uint32_t *slots, const uint32_t *cr, co
 	for (int k = 0; k < W; k++) prev[k] = rp[k];
 	__builtin_amdgcn_wave_barrier();
 }
+// `last_lane`: the lane that holds the tile's last samples - 63, or (partial tiles) the last active one
 template <int W>
-__device__ __forceinline__ void leave_carry(uint32_t *cr, const uint32_t (&carry)[W], int lane)
+__device__ __forceinline__ void leave_carry(uint32_t *cr, const uint32_t (&carry)[W], int lane, int last_lane = 63)
 {
-	if (lane == 63) {
+	if (lane == last_lane) {
 #pragma unroll
 		for (int k = 0; k < W; k++) cr[k] = carry[k];
 	}
@@ -337,15 +338,15 @@ __device__ __forceinline__ void leave_carry(uint32_t *cr, const uint32_t (&carry
 // src/rtl_fm.c:800-805 never holds the newest input).
 template <int C>
 __device__ __forceinline__ void fifth_history(uint32_t *slots, uint32_t *cr, const uint32_t (&Y)[C], uint32_t (&h)[5],
-                                              int lane, bool drop_newest_next)
+                                              int lane, bool drop_newest_next, int last_lane = 63)
 {
 	uint32_t mine[5] = {Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2], Y[C - 1]};
 	hand_off<5>(slots, cr, mine, h, lane);
 	if (drop_newest_next) {
 		uint32_t carry[5] = {Y[C - 6], Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2]};
-		leave_carry<5>(cr, carry, lane);
+		leave_carry<5>(cr, carry, lane, last_lane);
 	} else {
-		leave_carry<5>(cr, mine, lane);
+		leave_carry<5>(cr, mine, lane, last_lane);
 	}
 }
 
@@ -356,9 +357,11 @@ __device__ __forceinline__ void fifth_history(uint32_t *slots, uint32_t *cr, con
 // QUIRK: at a buffer start the entries that lie before the buffer are read one
 // position further back (see fifth_history); with fewer than five values per
 // lane that reaches lanes 1 and 2 as well, so it is applied per position.
+// nlanes < 64 (a partial tile): the ring's new prefix is the last kPre entries of (old prefix ++ the nlanes * C
+// valid entries), copied inside LDS instead of left by the last lanes' registers.
 template <int C, int H, bool QUIRK>
 __device__ __forceinline__ void ring_exchange(uint32_t *lds, int prefix, int body, const uint32_t (&mine)[C], uint32_t (&hist)[H],
-                                              int lane, bool buffer_start)
+                                              int lane, bool buffer_start, int nlanes = 64)
 {
 	static_assert(kPre % C == 0 && H + 1 <= kPre, "the prefix holds whole lanes and reaches back far enough");
 	// the kept prefix goes in front of the transient body, so that every lane reads its history at
@@ -378,9 +381,16 @@ __device__ __forceinline__ void ring_exchange(uint32_t *lds, int prefix, int bod
 		hist[k] = ring[kPre + pos];
 	}
 	__builtin_amdgcn_wave_barrier();
-	if (lane >= 64 - kPre / C) {
+	if (nlanes == 64) {
+		if (lane >= 64 - kPre / C) {
 #pragma unroll
-		for (int k = 0; k < C; k++) lds[prefix + (lane - (64 - kPre / C)) * C + k] = mine[k];
+			for (int k = 0; k < C; k++) lds[prefix + (lane - (64 - kPre / C)) * C + k] = mine[k];
+		}
+	} else {
+		uint32_t keep = 0;
+		if (lane < kPre) keep = ring[nlanes * C + lane];
+		__builtin_amdgcn_wave_barrier();
+		if (lane < kPre) lds[prefix + lane] = keep;
 	}
 	__builtin_amdgcn_wave_barrier();
 }
@@ -452,10 +462,20 @@ struct AtanNodesLds {
 // C_I = -/+ 4 (aI - aQ), C_Q = -/+ 4 (aI + aQ) for even / odd outputs (32 aI, 32 aQ without the
 // rotation), and -16 C is what the MFMA accumulators start from instead of zero.  No instruction is
 // added to the tile; samples now span +-255, so pass 3 takes the 32-bit form as it does without rotation.
-template <int P, bool FIR9, bool STD, bool MFMA0, bool RDC = false>
+// PT: callback buffers that are not whole tiles (-W n: any 512 n bytes, src/rtl_fm.c:1869-1873).  A buffer is then
+// ceil(block_len / 8192) tiles whose last one is PARTIAL - 256 k samples, lanes 0 .. 4k - 1 active, the others
+// compute on stale data that nobody reads: the buffer-boundary rules (rotation phase, the fifth_order quirk,
+// fm_demod's first sample) keep falling on tile starts.  What changes for such a tile: its rows behind the
+// buffer's end are not loaded (load rows are chosen per row, the one the end cuts in two is read 512 bytes early
+// and put right in LDS), "the tile's last lane" is lane 4k - 1 instead of 63 wherever a carry is left for the next
+// tile or the state is archived, a ring's new prefix is copied inside LDS, and a wave that starts mid-stream
+// warms up on as many tiles as hold 1024 samples (every carried quantity depends on fewer than
+// 15 * 2^P - 5 <= 955 earlier samples).  MFMA engine only; the PT = false kernels are untouched.
+template <int P, bool FIR9, bool STD, bool MFMA0, bool RDC = false, bool PT = false>
 __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
 {
 	static_assert(!RDC || MFMA0, "the raw DC block rides on the MFMA accumulators");
+	static_assert(!PT || (MFMA0 && !RDC), "partial tiles: MFMA engine, no raw DC block");
 	using L = Lds<P, FIR9, MFMA0>;
 	constexpr int CZ = L::cz;
 	__shared__ __attribute__((aligned(128))) uint32_t lds[L::total];
@@ -464,12 +484,33 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	const int seg = wave / p.nstreams;
 	const int s = wave - seg * p.nstreams;
 	if (seg >= p.segs) return;
-	const int tpb = (int)(p.block_len / kTileBytes);
+	const int tpb = PT ? (int)((p.block_len + kTileBytes - 1) / kTileBytes) : (int)(p.block_len / kTileBytes);
 	const int total_tiles = p.nblocks * tpb;
+	// PT: bytes of a buffer's last tile (a multiple of 512), and what one buffer yields
+	const int last_tile_bytes = PT ? (int)(p.block_len - (uint32_t)(tpb - 1) * kTileBytes) : kTileBytes;
+	const int out_per_buffer = (int)((p.block_len / 2) >> P);
 	int t0, t1;
 	segment_bounds(p, seg, total_tiles, t0, t1);
 	if (t0 >= t1) return;
 	const bool from_state = (t0 == 0);
+	// A segment that starts behind the run's first tile runs the tile before it as a warm-up (outputs
+	// discarded) - the last tile of the previous buffer or an earlier tile of the same buffer alike:
+	// bs / next_bs below follow from the tile's position, so the buffer-boundary rules apply where
+	// they belong whatever the segmentation is.
+	const int gt_first = t0;
+	int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
+	if (PT && !from_state) {
+		// ... or as many as hold 1024 samples, where tiles are short
+		int have = ((gt_begin % tpb) == tpb - 1 ? last_tile_bytes : kTileBytes) / 2;
+		while (gt_begin > 0 && have < 1024) {
+			gt_begin--;
+			have += ((gt_begin % tpb) == tpb - 1 ? last_tile_bytes : kTileBytes) / 2;
+		}
+	}
+	const int gt_end = t1;
+	// PT: a warm-up that reaches back to the run's first tile may be shorter than 1024 samples - it starts from the
+	// carried state, like the stream's first segment (whole tiles: a full warm-up tile needs none)
+	const bool load_state = from_state || (PT && gt_begin == 0);
 	const bool writes_state = (t1 == total_tiles);
 	const state_t *sin = p.sin + s;
 	state_t *sout = p.sout + s;
@@ -490,7 +531,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	for (int k = lane; k < L::total; k += 64) lds[k] = 0;
 	__builtin_amdgcn_wave_barrier();
 	if (lane < 17) reinterpret_cast<double *>(lds + L::atan)[lane] = k_atan_nodes[lane];
-	if (from_state && lane == 0) {
+	if (load_state && lane == 0) {
 		for (int j = 0; j < 6; j++) lds[L::xh + j] = pack_iq(sin->lp_i_hist[0][j], sin->lp_q_hist[0][j]);
 		auto put_slots = [&](int off, int pass) {  // e[-5..-1] = hist[1..5]
 			for (int k = 0; k < 5; k++) lds[off + k] = pack_iq(sin->lp_i_hist[pass][k + 1], sin->lp_q_hist[pass][k + 1]);
@@ -514,13 +555,6 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	__builtin_amdgcn_wave_barrier();
 	const AtanNodesLds nodes{reinterpret_cast<const double *>(lds + L::atan)};
 
-	// A segment that starts behind the run's first tile runs the tile before it as a warm-up (outputs
-	// discarded) - the last tile of the previous buffer or an earlier tile of the same buffer alike:
-	// bs / next_bs below follow from the tile's position, so the buffer-boundary rules apply where
-	// they belong whatever the segmentation is.
-	const int gt_first = t0;
-	const int gt_begin = from_state ? gt_first : gt_first - 1;  // one warm-up tile
-	const int gt_end = t1;
 	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
 	const int out_per_tile = 64 * CZ;
 	int16_t *out_base = p.out + (size_t)s * p.out_stride;
@@ -537,7 +571,28 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			else cur[k] = *reinterpret_cast<const uint4 *>(tb + lane * 128 + k * 16);
 		}
 	};
-	auto load_tile = [&](int tile) { load_from(stream_base + (size_t)tile * kTileBytes); };
+	// PT: tile `tile` = tile tib of buffer b; rows behind the buffer's end come from the dummy tile, the row the
+	// end cuts in two is read 512 bytes early (nothing outside the run is touched; staging puts it right)
+	auto load_tile_pt = [&](int tile) {
+		const bool real = tile < gt_end;
+		const int b = tile / tpb, tib = tile - b * tpb;
+		const uint8_t *tb = real ? stream_base + (size_t)b * p.block_len + (size_t)tib * kTileBytes : p.dummy_tile;
+		const int valid = real && tib == tpb - 1 ? last_tile_bytes : kTileBytes;  // wave-uniform
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const uint8_t *row = tb + k * 1024;
+			if (k * 1024 >= valid) row = p.dummy_tile + k * 1024;
+			else if (k * 1024 + 512 == valid) {
+				if (tile > 0 || k > 0) row -= 512;
+				else row = lane < 32 ? row : p.dummy_tile;  // a run that begins with a 512-byte buffer: nothing before it
+			}
+			cur[k] = load_stream16(row + lane * 16);
+		}
+	};
+	auto load_tile = [&](int tile) {
+		if constexpr (PT) load_tile_pt(tile);
+		else load_from(stream_base + (size_t)tile * kTileBytes);
+	};
 	load_tile(gt_begin);
 	// The reload is unconditional: were it skipped for the last tile of a segment, the
 	// loop-carried registers would be a merge of "kept" and "loaded" values and the register
@@ -546,8 +601,12 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	// shares and that therefore stays in the caches (re-reading the last tile itself would go
 	// to HBM again, the stream being loaded non-temporally: 1.5 % of the traffic).
 	auto reload = [&](int gt, bool more) {
-		const uint8_t *next = stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes;
-		load_from(more || (p.debug & 4) ? next : p.dummy_tile);
+		if constexpr (PT) {
+			load_tile_pt(gt + 1);  // tile gt_end reads the dummy tile
+		} else {
+			const uint8_t *next = stream_base + (size_t)((p.debug & 4) ? gt_begin : gt + 1) * kTileBytes;
+			load_from(more || (p.debug & 4) ? next : p.dummy_tile);
+		}
 	};
 	typedef int v4i_t __attribute__((ext_vector_type(4)));
 	v4i_t mfma_a = {0, 0, 0, 0};
@@ -595,7 +654,11 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		const bool q0 = bs && lane == 0;
 		const bool emit = gt >= gt_first;
 		const bool last = gt + 1 == gt_end;
-		const bool archive = last && writes_state && lane == 63;
+		// PT: a buffer's last tile holds tile_bytes / 128 active lanes (64 samples = 128 bytes each)
+		const int tile_bytes = PT && next_bs ? last_tile_bytes : kTileBytes;
+		const int nlanes = PT ? tile_bytes >> 7 : 64;
+		const int last_lane = nlanes - 1;
+		const bool archive = last && writes_state && lane == last_lane;
 
 		RTLFM_MARK("tile_begin");
 		if constexpr (RDC) {
@@ -615,7 +678,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			// The first / last raw dwords of the tile are needed by the two rare paths below;
 			// in this layout they sit in lane 0's cur[0] and lane 63's cur[7].
 			uint32_t fix0 = 0, fix1 = 0, fix2 = 0;
-			if (bs) {
+			if (!PT && bs) {
 				uint32_t e[11];
 #pragma unroll
 				for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
@@ -627,7 +690,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				fix2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
 			}
 			__builtin_amdgcn_wave_barrier();
-			if (next_bs) {
+			if (!PT && next_bs) {
 				uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
 				unpack_rot(cur[7].x, 0, rotate, a0, a1, dcI, dcQ);
 				unpack_rot(cur[7].y, 1, rotate, a2, a3, dcI, dcQ);
@@ -654,6 +717,54 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				if (k == 7) last = v;
 			}
 			__builtin_amdgcn_wave_barrier();
+			if constexpr (PT) {
+				const int nv = tile_bytes >> 4;  // valid 16-byte chunks: a multiple of 32
+				if (nv < 512) {
+					// the row the buffer's end cuts in two was read 512 bytes early (load_tile_pt): its second half is
+					// the row's first half; what follows is not part of the buffer (left as sample 0)
+					const int kh = tile_bytes >> 10;
+					if ((tile_bytes & 1023) && (gt > 0 || kh > 0)) {
+						uint4 v = make_uint4(0, 0, 0, 0);
+						if (lane < 32) v = chunks[64 * kh + lane + 32];
+						__builtin_amdgcn_wave_barrier();
+						chunks[64 * kh + lane] = v;
+						__builtin_amdgcn_wave_barrier();
+					}
+				}
+				if (bs) {
+					// the first three outputs of a buffer, from the archived x' of the buffer before and this tile's
+					// first dwords - read back from the staged tile (a row may have been loaded 512 bytes early)
+					const uint4 first = chunks[0];
+					uint32_t e[11];
+#pragma unroll
+					for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
+					unpack_rot(first.x ^ 0x7f7f7f7fu, 0, rotate, e[5], e[6]);
+					unpack_rot(first.y ^ 0x7f7f7f7fu, 1, rotate, e[7], e[8]);
+					unpack_rot(first.z ^ 0x7f7f7f7fu, 0, rotate, e[9], e[10]);
+					fix0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
+					fix1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
+					fix2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
+					__builtin_amdgcn_wave_barrier();  // xh is read before the block below rewrites it
+				}
+				last = chunks[nv - 1];  // the tile's last valid chunk (all lanes read it: a broadcast)
+				if (next_bs) {
+					// archive x'[N-7..N-2] of the buffer that ends here: the last eight samples' raw bytes again
+					uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
+					unpack_rot(last.x ^ 0x7f7f7f7fu, 0, rotate, a0, a1);
+					unpack_rot(last.y ^ 0x7f7f7f7fu, 1, rotate, a2, a3);
+					unpack_rot(last.z ^ 0x7f7f7f7fu, 0, rotate, a4, a5);
+					unpack_rot(last.w ^ 0x7f7f7f7fu, 1, rotate, a6, a7);
+					if (lane == last_lane) {
+						lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
+						lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
+						if (archive) {
+							uint32_t v[6] = {a1, a2, a3, a4, a5, a6};
+							for (int j = 0; j < 6; j++) { iq16 w = unpack_iq(v[j]); sout->lp_i_hist[0][j] = w.i; sout->lp_q_hist[0][j] = w.q; }
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
 			// 16 segments of 128 outputs: lane (n = l&15, q = l>>4) feeds window n's bytes
 			// 16q..16q+15 = chunk 32s + 2n + q - 1 and receives outputs 128s + 8n + 2q + {0,1}
 			const int ln = lane;
@@ -678,7 +789,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 #pragma unroll
 			for (int k = 0; k < 9; k++) bop[k] = rd[32 * k];
 			__builtin_amdgcn_wave_barrier();
-			if (lane == 63) chunks[-1] = last;  // for the next tile; segment 0 has read the old one
+			if (lane == (PT ? 0 : 63)) chunks[-1] = last;  // for the next tile; segment 0 has read the old one (PT: every lane holds it)
 			__builtin_amdgcn_wave_barrier();
 #pragma unroll
 			for (int half = 0; half < 2; half++) {
@@ -831,7 +942,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		} else {
 			uint32_t h5[5];
 			uint32_t Y1[16];
-			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lz, next_bs);
+			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lz, next_bs, last_lane);
 			fifth_lane<32, true>(Y0, h5, Y1);
 			archive_regs(Y0, std::integral_constant<int, 32>(), 1);
 			if (MFMA0 && RTLFM_MFMA_RELOAD_AT == 2) reload(gt, more);
@@ -840,7 +951,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
 			} else {
 				uint32_t Y2[8];
-				fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lz, next_bs);
+				fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lz, next_bs, last_lane);
 				fifth_lane<16, true>(Y1, h5, Y2);
 				archive_regs(Y1, std::integral_constant<int, 16>(), 2);
 				if constexpr (P == 3) {
@@ -848,7 +959,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					for (int k = 0; k < 8; k++) Z[k] = Y2[k];
 				} else {
 					uint32_t Y3[4];
-					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lz, next_bs);
+					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lz, next_bs, last_lane);
 					// with rotation |x| <= 1023 here, so the 16-bit form cannot overflow;
 					// without it an all-255 input reaches exactly 2^15
 					if (rotate && !RDC) fifth_lane<8, true>(Y2, h5, Y3);
@@ -859,14 +970,14 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 						for (int k = 0; k < 4; k++) Z[k] = Y3[k];
 					} else {
 						uint32_t Y4[2];
-						ring_exchange<4, 5, true>(lds, L::y3, L::ring_body, Y3, h5, lz, bs);
+						ring_exchange<4, 5, true>(lds, L::y3, L::ring_body, Y3, h5, lz, bs, nlanes);
 						fifth_lane<4, false>(Y3, h5, Y4);
 						archive_ring(L::y3, 4);
 						if constexpr (P == 5) {
 							Z[0] = Y4[0]; Z[1] = Y4[1];
 						} else {
 							uint32_t Y5[1];
-							ring_exchange<2, 5, true>(lds, L::y4, L::ring_body, Y4, h5, lz, bs);
+							ring_exchange<2, 5, true>(lds, L::y4, L::ring_body, Y4, h5, lz, bs, nlanes);
 							fifth_lane<2, false>(Y4, h5, Y5);
 							archive_ring(L::y4, 5);
 							Z[0] = Y5[0];
@@ -886,13 +997,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 #pragma unroll
 				for (int k = 0; k < 9; k++) mine[k] = Z[CZ - 9 + k];
 				hand_off<9>(lds + L::tr, lds + L::c_fz, mine, h9, lz);
-				leave_carry<9>(lds + L::c_fz, mine, lane);
+				leave_carry<9>(lds + L::c_fz, mine, lane, last_lane);
 				if (archive) {
 #pragma unroll
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(mine[j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
 			} else {
-				ring_exchange<CZ, 9, false>(lds, L::fz, L::ring_body, Z, h9, lz, false);
+				ring_exchange<CZ, 9, false>(lds, L::fz, L::ring_body, Z, h9, lz, false, nlanes);
 				if (archive) {
 					for (int j = 0; j < 9; j++) { iq16 w = unpack_iq(lds[L::fz + kPre - 9 + j]); sout->droop_i_hist[j] = w.i; sout->droop_q_hist[j] = w.q; }
 				}
@@ -918,10 +1029,12 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			// IQ), tile-major and lane-contiguous = time order; used for -M raw and as the input of
 			// the staged kernels that finish 7..10 passes or apply the squelch
 			if (p.emit_iq) {
-				if (emit) {
+				if (emit && (!PT || lane < nlanes)) {
 					// stored right away (no deferral as for the PCM: keeping CZ more registers alive
 					// through the next tile would cost every kernel of this family its occupancy)
-					uint32_t *dst = p.emit_iq + (size_t)s * p.emit_iq_stride + ((size_t)gt * 64 + lane) * CZ;
+					const size_t at = PT ? (size_t)(gt / tpb) * out_per_buffer + (size_t)tib * out_per_tile + (size_t)lane * CZ
+					                     : ((size_t)gt * 64 + lane) * CZ;
+					uint32_t *dst = p.emit_iq + (size_t)s * p.emit_iq_stride + at;
 					if constexpr (CZ >= 4) {
 #pragma unroll
 						for (int k = 0; k < CZ / 4; k++)
@@ -941,7 +1054,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		{
 			uint32_t mine[1] = {V[CZ - 1]}, prev[1];
 			hand_off<1>(lds + L::tr, lds + L::c_zd, mine, prev, lz);
-			leave_carry<1>(lds + L::c_zd, mine, lane);
+			leave_carry<1>(lds + L::c_zd, mine, lane, last_lane);
 			pv = prev[0];
 			if (archive) {
 				iq16 w = unpack_iq(V[CZ - 1]);
@@ -976,8 +1089,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 		(void)q0;
 		RTLFM_MARK("demod_done");
-		if (emit) {
-			held_dst = out_base + (size_t)gt * out_per_tile + lane * CZ;
+		if (emit && (!PT || lane < nlanes)) {
+			held_dst = PT ? out_base + (size_t)(gt / tpb) * out_per_buffer + (size_t)tib * out_per_tile + lane * CZ
+			              : out_base + (size_t)gt * out_per_tile + lane * CZ;
 #pragma unroll
 			for (int k = 0; k < CZ; k++) held[k] = pcm[k];
 		}
@@ -1059,7 +1173,11 @@ inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
 		sp.segs = (total_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
 		return sp;
 	}
-	const int min_tiles = ws.min_tiles > 0 ? ws.min_tiles : 1;
+	int min_tiles = ws.min_tiles > 0 ? ws.min_tiles : 1;
+	// Where the streams alone fill every wave slot, a second wave per stream buys no parallelism and pays its
+	// warm-up tile: segments of sixteen tiles at least (north_star's live shape - 4096 streams x ONE 262144-B
+	// buffer per launch - then runs one wave per stream: 0.2128 against 0.2158 ms, same box, interleaved)
+	if (nstreams >= kWaveSlots && min_tiles < 16 && !ws.tail_follows) min_tiles = 16;
 	const int target = ws.tail_follows ? ws.target_waves_tail : ws.target_waves;
 	int segs = (target + nstreams - 1) / nstreams;
 	int cap = total_tiles / min_tiles;
@@ -1102,10 +1220,12 @@ inline int effective_engine(const Workspace &ws)
 
 // What the front end in emit mode plus staged kernels covers beyond supported(): 7..10 passes,
 // -M raw, and the squelch (rtlfm_hip.hip: run_fused_emit)
+// buffers that are not whole 8 KiB tiles (-W n) take the partial-tile kernels: MFMA engine, no raw DC block
+inline bool needs_partial_tiles(const rtlfm_cfg &c) { return (c.block_len % kTileBytes) != 0; }
+
 inline bool supported_emit(const rtlfm_cfg &c)
 {
 	if (c.downsample_passes < 1 || c.downsample_passes > RTLFM_MAX_PASSES) return false;
-	if (c.block_len % kTileBytes) return false;
 	if (c.dc_block_raw) return false;
 	return c.downsample_passes > kMaxP || c.mode == RTLFM_MODE_RAW || c.squelch_level != 0 || c.report_levels != 0;
 }
@@ -1123,15 +1243,22 @@ inline bool supported(const rtlfm_cfg &c, int nblocks)
 	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
 		return false;
 	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
-	if (c.block_len % kTileBytes) return false;
+	if (needs_partial_tiles(c) && c.dc_block_raw) return false;
 	if (c.squelch_level || c.report_levels) return false;
 	(void)nblocks;
-	return true;  // -E rdc: the RDC instantiations (MFMA pass 0 only; rtlfm_hip.hip checks the engine)
+	// -E rdc: the RDC instantiations; -W n: the PT ones (both MFMA pass 0 only; rtlfm_hip.hip checks the engine)
+	return true;
 }
 
 template <int P, bool FIR9>
 static int launch_one(const Params &p, int waves, hipStream_t q)
 {
+	if (p.block_len % kTileBytes) {
+		if (!p.mfma_taps || p.rdc_avg) return -ENOTSUP;
+		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true, false, true>), dim3(waves), dim3(64), 0, q, p);
+		else hipLaunchKernelGGL((k_fused<P, FIR9, false, true, false, true>), dim3(waves), dim3(64), 0, q, p);
+		return hipGetLastError() == hipSuccess ? 0 : -EIO;
+	}
 	if (p.rdc_avg) {
 		if (!p.mfma_taps) return -ENOTSUP;
 		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true, true>), dim3(waves), dim3(64), 0, q, p);
@@ -1188,7 +1315,8 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	}
 	p.debug = ws.debug;
 	if (ws.want_stamps) p.debug |= 2;
-	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)(c.block_len / kTileBytes));
+	if (needs_partial_tiles(c) && engine != 1) return -ENOTSUP;
+	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)((c.block_len + kTileBytes - 1) / kTileBytes));
 	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
 	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;

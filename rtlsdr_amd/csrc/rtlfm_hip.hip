@@ -1106,6 +1106,20 @@ extern "C" int rtlfm_gpu_clock_read(rtlfm_gpu *h, double *shader_mhz, double *sp
 	return read_clock_stamps(h, shader_mhz, span_ms, nullptr);
 }
 
+// dc_block_raw_filter needs every buffer's mean before its first sample: one more pass over the input (the
+// per-buffer sums), the smoothing recurrence over a stream's buffers; the averages then ride on the front end
+// (fused_kernel.h: the MFMA accumulators' start values; boxcar_kernel.h: a correction of the prefix sums)
+static const int2 *rdc_prepass(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks)
+{
+	const rtlfm_cfg &c = h->cfg;
+	if (!c.dc_block_raw) return nullptr;
+	const int S = h->nstreams;
+	k_rdc_sums_wide<<<(unsigned)((size_t)S * nblocks), 256, 0, h->stream>>>(d_iq, stream_stride, c.block_len, nblocks, h->d_sums);
+	k_rdc_smooth<<<grid_for(S, 64), 64, 0, h->stream>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, h->st[h->st_cur],
+	                                                  h->st[(h->st_cur + 1) % 3], h->d_rdc_avg);
+	return h->d_rdc_avg;
+}
+
 static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
                      size_t out_stride, int32_t *d_out_len)
 {
@@ -1124,15 +1138,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
-	const int2 *rdc = nullptr;
-	if (c.dc_block_raw) {
-		// dc_block_raw_filter needs every buffer's mean before its first sample: one more pass over the
-		// input (the per-buffer sums), the smoothing recurrence over a stream's buffers, and then the
-		// averages ride on the front end's MFMA accumulators (fused_kernel.h, RDC)
-		k_rdc_sums_wide<<<(unsigned)((size_t)S * nblocks), 256, 0, q>>>(d_iq, stream_stride, c.block_len, nblocks, h->d_sums);
-		k_rdc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, sin, sout, h->d_rdc_avg);
-		rdc = h->d_rdc_avg;
-	}
+	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
 	h->fws.tail_follows = tp.any();
 	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q, nullptr, 0, rdc);
 	if (r < 0) return r;
@@ -1239,7 +1245,8 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
 	h->fws.tail_follows = tp.any();
-	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt[h->step & 1], sin, sout, q);
+	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt[h->step & 1], sin, sout, q, nullptr, 0, rdc);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -1273,7 +1280,8 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 	if (r < 0) return r;
 	h->fws.tail_follows = true;  // kernels follow on this stream and, with a tail, on the tail's
 	int32_t *dcnt = h->d_cnt[h->step & 1];
-	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, dcnt, sin, sout, q, h->deepA, h->deep_stride);
+	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, dcnt, sin, sout, q, h->deepA, h->deep_stride, rdc);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -1321,12 +1329,14 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	HIP_TRY(hipSetDevice(h->device));
 	const size_t S = (size_t)h->nstreams;
 	bool can_fuse = fused::supported(h->cfg, nblocks);
-	if (h->cfg.dc_block_raw && fused::effective_engine(h->fws) != 1) can_fuse = false;  // the raw DC block rides on the MFMA pass 0
+	// the raw DC block rides on the MFMA pass 0, and only that engine has the partial-tile kernels (-W n)
+	const bool mfma_only = h->cfg.dc_block_raw || fused::needs_partial_tiles(h->cfg);
+	if (mfma_only && fused::effective_engine(h->fws) != 1) can_fuse = false;
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
 	const bool can_box_emit = boxfused::supported_emit(h->cfg);
-	const bool can_deep = fused::supported_emit(h->cfg);
+	const bool can_deep = fused::supported_emit(h->cfg) && !(fused::needs_partial_tiles(h->cfg) && fused::effective_engine(h->fws) != 1);
 	int r;
 	{
 		// this step reuses the res[] / d_cnt[] set and the state copy the step before last handed to

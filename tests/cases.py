@@ -68,6 +68,7 @@ CASES = [
     ("box84_fm_squelch50", dict(downsample=84, rate_out=12000, squelch_level=50),
      dict(fs=1.008e6, dev_hz=2.5e3, amplitude=0.8, quiet=(40000, 22000))),
     ("raw_box10", dict(mode=MODE_RAW, downsample=10, rate_out=240000), WB),
+    ("box10_rdc_fast", dict(downsample=10, custom_atan=ATAN_FAST, dc_block_raw=1, rate_out=240000), WB),  # rtl_fm -s 240k -A fast -E rdc
 ]
 
 

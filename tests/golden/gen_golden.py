@@ -35,7 +35,7 @@ MAIN = {"box42_dc", "box84_am_dc", "box6_wbfm_dc", "box334_usb", "box42_dc_arb_u
         "box10_deemph_arb_down96000",
         "c1_boxcar10_fast", "c2_p4_std", "c2_p4_fir9_std", "c3_p6_fir9_deemph",
         "c3_p6_fir9_deemph_up22050", "wbfm_preset", "c2_p4_lut", "c2_p4_fast_a40",
-        "box84_fm_squelch50", "raw_box10"}
+        "box84_fm_squelch50", "raw_box10", "box10_rdc_fast"}
 
 
 def main():

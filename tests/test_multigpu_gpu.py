@@ -59,6 +59,11 @@ def test_bench_gpus_2_starts_two_ranks():
     assert d["n_gpus"] == (2 if two else 1)
     assert d["value"] > 0 and d["scaling"] == "weak"
     assert d["scatter"]["bytes_from_root"] > 0
+    # what the 1/2/4/8 curve is read with: every rank's own step and launch time, whether its output got its placement,
+    # and its PCIe-inclusive rate beside its pinned H2D rate (at eight GPUs the host side is the curve)
+    pr = d["per_rank"]
+    assert pr["world_size"] == 2 and len(pr["ms_per_step"]) == 2 and len(pr["output_apart"]) == 2
+    assert len(pr["e2e_GB/s_in"]) == 2 and min(pr["e2e_GB/s_in"]) > 0 and min(pr["pinned_h2d_GB/s"]) > 0
     # whole-job value: both ranks' samples over the max-over-ranks time
     per_step = 2 * 32 * 4 * 262144 // 2
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02

@@ -331,6 +331,38 @@ def test_raw_dc_block_on_the_fused_path(oracle_lib, passes, fir9, atan, offs):
         assert np.array_equal(so[s_], outs[s_])
 
 
+@pytest.mark.parametrize("D,atan,extra", [(6, 1, {}), (10, 0, {}), (10, 1, {}), (10, 2, {}), (42, 0, {}), (7, 0, {}), (300, 0, {}),
+                                          (10, 0, dict(squelch_level=400)), (10, 0, dict(mode=4)), (84, 0, dict(mode=1, output_scale=3))])
+def test_raw_dc_block_in_front_of_the_boxcar(oracle_lib, D, atan, extra):
+    """-E rdc in front of the default decimator (rtl_fm -E rdc without -F) on the one-launch path: the rotated
+    constant sums to zero over every four samples, so the per-buffer averages are one correction c G(n & 3) where a
+    prefix sum is looked up (boxcar_kernel.h, RDC).  Drifting DC offsets per buffer, full-scale bytes, odd and long
+    boxcars (the 32-bit partial sums of D > 256), emit mode behind it, runs split over launches, segments."""
+    ov = dict(downsample=D, downsample_passes=0, custom_atan=atan, dc_block_raw=1, rate_out=int(2.4e6 / D))
+    ov.update(extra)
+    L, nb, ns = 32768, 5, 7
+    cfg = make_cfg(ov, L, nb)
+    amp = max(2.0, min(25.0, 400.0 / D)) if atan == 1 else 50.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=7100 + D, fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    rng = np.random.default_rng(D)
+    for s_ in range(ns - 1):
+        for b in range(nb):
+            off = rng.integers(-30, 31, size=2) if atan == 1 else rng.integers(-60, 61, size=2)
+            blk = iq[s_, b * L:(b + 1) * L].astype(np.int32)
+            blk[0::2] += off[0]; blk[1::2] += off[1]
+            iq[s_, b * L:(b + 1) * L] = np.clip(blk, 0, 255).astype(np.uint8)
+    if atan != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=D)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits, opts in ((None, None), ([(0, 1), (1, 3), (3, 5)], None), (None, dict(fused_waves=1)), (None, dict(fused_tiles_per_seg=3))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        assert used == 2, "the raw DC block in front of the boxcar must not fall back to the staged kernels"
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_]
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"rdc box D={D} {extra} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
+
+
 @pytest.mark.parametrize("L", [24576, 40960, 8192 * 7])
 @pytest.mark.parametrize("front", ["p4", "p4rdc", "p5fir", "box10"])
 def test_buffer_sizes_that_are_not_powers_of_two(oracle_lib, front, L):
@@ -354,6 +386,53 @@ def test_buffer_sizes_that_are_not_powers_of_two(oracle_lib, front, L):
         for s_ in range(ns):
             assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"{front} L={L} {splits} {opts} stream {s_}")
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
+
+
+@pytest.mark.parametrize("L", [512, 1536, 12288, 20480, 512 * 23])
+@pytest.mark.parametrize("front", ["p1", "p2fir", "p3", "p4", "p4fast", "p4lut", "p5fir", "p6", "p6fir", "p7fir", "p4raw", "p4am",
+                                   "box2", "box7fast", "box10", "box10lut", "box42", "box10raw", "box10sq", "p4sq"])
+def test_buffers_of_any_512n_bytes(oracle_lib, front, L):
+    """-W n gives buffers of 512 n bytes for ANY n (src/rtl_fm.c:1869-1873): 512, 1536, 12288 (n = 24), 20480 (n = 40),
+    11776 bytes here - a buffer is then whole 8 KiB tiles plus a partial one (fifth_order front ends: the partial-tile
+    kernels) or the run is one continuous sample stream with a partial last tile (the boxcar) - through the one-launch
+    front ends (`last_path == 2`): every pass count, the FIR, all discriminators, emit mode (-M raw, the squelch,
+    7 passes), runs split over launches, one wave per stream and segments of three tiles that start anywhere (their
+    warm-up then spans several short tiles)."""
+    ov = {}
+    if front.startswith("box"):
+        D = int("".join(ch for ch in front[3:] if ch.isdigit()))
+        ov = dict(downsample=D, downsample_passes=0)
+        if D > L // 2:
+            pytest.skip("a boxcar longer than the buffer: outside the reference's domain")
+    else:
+        passes = int(front[1])
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if "fir" in front else 0)
+        if L % (2 << passes):
+            pytest.skip("fifth_order needs buffers of whole groups of 2^(passes+1) bytes")
+    if "fast" in front: ov["custom_atan"] = 1
+    if "lut" in front: ov["custom_atan"] = 2
+    if "raw" in front: ov["mode"] = capi.MODE_RAW
+    if "am" in front: ov.update(mode=capi.MODE_AM, output_scale=4)
+    if "sq" in front: ov["squelch_level"] = 300
+    nb = 9 if L <= 1536 else 5
+    ns = 5
+    cfg = make_cfg(ov, L, nb)
+    amp = 25.0 if ov.get("custom_atan") == 1 else 50.0
+    if ov.get("custom_atan") == 1 and front.startswith("box"):
+        amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=L + 31 * len(front), fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    if ov.get("custom_atan") != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=L)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    cut = nb // 2
+    for splits, opts in ((None, None), ([(0, 1), (1, cut), (cut, nb)], dict(fused_tiles_per_seg=3)), (None, dict(fused_waves=1)),
+                         (None, dict(fused_tiles_per_seg=1))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        assert used == 2, (front, L)
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_], (front, L, splits, opts, s_)
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"{front} L={L} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, splits, opts, s_)
 
 
 def test_options_by_name():
