@@ -63,8 +63,9 @@ struct rtlfm_gpu {
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
-	double arb_rinv = 0;                  // k_deemph_spec_arb: RN(1 / len2) and whether it reproduces tick / len2
-	int arb_len2 = 0, arb_fast = 0;
+	int32_t *d_arb_i = nullptr;           // k_deemph_spec_arb: (i, frac) of every output of a buffer, [arb_len2]
+	double *d_arb_frac = nullptr;
+	int arb_len2 = 0, arb_len1 = 0;
 	int deemph_chunks = 0;   // capacity of d_deemph_tab / d_deemph_inc, chunks per stream
 	int lpr_chunks_cap = 0;  // ... of d_lpr_chunks
 	uint32_t *deepA = nullptr, *deepB = nullptr;  // /64 IQ work buffers of the 7..10-pass path
@@ -310,8 +311,9 @@ static int create_body(rtlfm_gpu *h)
 		HIP_TRY(hipEventCreateWithFlags(&h->ev_front[k], hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&h->ev_tail[k], hipEventDisableTiming));
 	}
-	// (default priority: with the highest, so that the tail's workgroups are placed first whenever wave slots
-	// come free, the c3 and wbfm steps measured 1 % slower)
+	// (default priority: the highest and the lowest one were both tried - round 3: highest 1 % slower; round 4,
+	// three alternations on one box: c3 0.883 / 0.881 / 0.883 ms, wbfm 1.381 / 1.381 / 1.379 for default / lowest /
+	// highest - the dispatcher does not seem to look at it between two compute queues)
 	HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
 	h->tail_overlap = true;
 	{
@@ -418,7 +420,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -794,16 +796,27 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 			const size_t arb_lds = (size_t)(Ws / kArbChunk + 64) * kArbStride * sizeof(int16_t);
 			int32_t *cnt_dst = d_out_len ? d_out_len : h->d_cnt2;
 			if (spec_arb) {
-				if (h->arb_len2 != arb_l2) {
-					// frac = (double)tick / (double)len2 (src/rtl_fm.c:1122) as two fused multiply-adds with
-					// RN(1 / len2): used only if it is the division's result for every tick of this len2
-					h->arb_rinv = 1.0 / (double)arb_l2;
-					h->arb_fast = 1;
-					for (int t = 0; t <= arb_l2 && h->arb_fast; t++) {
-						const double dt = (double)t, q0 = dt * h->arb_rinv;
-						if (std::fma(std::fma(-q0, (double)arb_l2, dt), h->arb_rinv, q0) != dt / (double)arb_l2) h->arb_fast = 0;
+				if (h->arb_len2 != arb_l2 || h->arb_len1 != Nblk) {
+					// (i, frac) of every output of a buffer, as arbitrary_upsample's loop (src/rtl_fm.c:1114-1135)
+					// has them when it writes buf2[j]: walked once here, shared by every stream and buffer
+					std::vector<int32_t> ti((size_t)arb_l2);
+					std::vector<double> tf((size_t)arb_l2);
+					int i = 1, tick = 0;
+					for (int j = 0; j < arb_l2; j++) {
+						ti[j] = i;
+						tf[j] = (double)tick / (double)arb_l2;
+						tick += Nblk;
+						if (tick > arb_l2) { tick -= arb_l2; i++; }
+						if (i >= Nblk) { i = Nblk - 1; tick = arb_l2; }
 					}
-					h->arb_len2 = arb_l2;
+					HIP_TRY(hipStreamSynchronize(q));  // the tables of another geometry may still be in use
+					if (h->d_arb_i) { HIP_TRY(hipFree(h->d_arb_i)); HIP_TRY(hipFree(h->d_arb_frac)); }
+					h->d_arb_i = nullptr; h->d_arb_frac = nullptr;
+					HIP_TRY(hipMalloc(&h->d_arb_i, ti.size() * sizeof(int32_t)));
+					HIP_TRY(hipMalloc(&h->d_arb_frac, tf.size() * sizeof(double)));
+					HIP_TRY(hipMemcpy(h->d_arb_i, ti.data(), ti.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+					HIP_TRY(hipMemcpy(h->d_arb_frac, tf.data(), tf.size() * sizeof(double), hipMemcpyHostToDevice));
+					h->arb_len2 = arb_l2; h->arb_len1 = Nblk;
 				}
 				int16_t *arb_dst = nullptr; size_t arb_ds = 0;
 				next_dst(&arb_dst, &arb_ds);
@@ -816,7 +829,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				if (wpw > kSpecArbMaxWaves) wpw = kSpecArbMaxWaves;
 				if (wpw < 1) wpw = 1;
 #define RTLFM_SPEC_ARB(MM) k_deemph_spec_arb<MM><<<(unsigned)S, 64 * wpw, arb_lds * wpw, q>>>(cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, \
-				h->arb_rinv, h->arb_fast, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
+				h->d_arb_i, h->d_arb_frac, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
 				if (M == 2) RTLFM_SPEC_ARB(2); else if (M == 1) RTLFM_SPEC_ARB(1); else RTLFM_SPEC_ARB(0);
 #undef RTLFM_SPEC_ARB
 				RTLFM_DBG_SYNC("one pass (arb)");

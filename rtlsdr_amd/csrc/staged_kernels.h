@@ -1043,6 +1043,10 @@ __device__ __forceinline__ void lpr_totals(long long p0, int n, int slow, int fa
 // barrier the lane of chunk 0 finishes its stream: the outputs that straddle chunk boundaries, the carried
 // accumulator, phase and count (what k_lpr_fixup does for the four-pass route) - or, if a chunk could not settle
 // (flag in LDS) or the carried filter state lies outside int16, the reference's own sequential loop over the run.
+// (Not VALU-bound: a form of this kernel with the filter's state in fp32 - six full-rate instructions per sample instead
+// of seven and a quarter-rate multiply-high, exact for every a the host checked - ran the wbfm step in 1.377 ms
+// against 1.378, same box, alternating.  Every lane walks a row of its own, 16 bytes at a time: the kernel waits for
+// its 64 separate lines per load instruction.)
 constexpr int kSpecLprThreads = 256;
 template <int MAGIC>
 __global__ void __launch_bounds__(kSpecLprThreads)
@@ -1077,8 +1081,11 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 		for (int c = c_first; c < nc; c += c_step) {
 			int begin, end;
 			deemph_chunk_range(c, n, head, L, begin, end);
-			uint32_t v = (uint32_t)(carried + 32768);
+			const long long idx0 = p0 + (long long)begin * slow;
+			const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
+			LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
 			bool settled = true;
+			uint32_t v = (uint32_t)(carried + 32768);
 			if (begin > 0) {
 				if (begin <= W) {
 					// close to the start of the run: from the carried state itself
@@ -1092,13 +1099,10 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 				}
 			}
 			if (!settled) { unsettled[sl] = 1; continue; }
-			const long long idx0 = p0 + (long long)begin * slow;
-			const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
-			LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
-			v = deemph_walk_sink<MAGIC>(r + begin, end - begin, v, ds, true, sink);
+			const int v_end = (int)deemph_walk_sink<MAGIC>(r + begin, end - begin, v, ds, true, sink) - 32768;
 			sink.finish();
 			lc[s * max_chunks + c] = sink.out;
-			if (c == nc - 1) sout[s].deemph_avg = (int)v - 32768;
+			if (c == nc - 1) sout[s].deemph_avg = v_end;
 		}
 	}
 	__threadfence_block();  // the chunk records and outputs of this workgroup's lanes, for its finishing lanes
@@ -1420,7 +1424,8 @@ constexpr int kSpecArbMaxWaves = 8;
 template <int MAGIC>
 __global__ void __launch_bounds__(64 * kSpecArbMaxWaves)
 k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
-                  int N, int len2, int nblocks, double rinv, int fast, int16_t *__restrict__ B, size_t bstride,
+                  int N, int len2, int nblocks, const int32_t *__restrict__ tab_i, const double *__restrict__ tab_frac,
+                  int16_t *__restrict__ B, size_t bstride,
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, size_t lds_per_wave,
                   int32_t *__restrict__ cnt_out)
 {
@@ -1533,41 +1538,25 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		const int p = rel + poff;
 		return (int)y[(p >> 5) * Cp + (p & (C - 1))];
 	};
+	// (i, frac) of output j - what the reference's loop holds when it writes buf2[j] - do not depend on the data:
+	// the host walks that loop once per (len1, len2) and leaves them in tab_i / tab_frac (rtlfm_hip.hip), 12 bytes
+	// per output that every stream shares.  Computing them per output (a 32-bit division to start, then a carry
+	// chain and a two-fma quotient for frac) was 18 of the 35 instructions an output cost.
 	const int len1 = N;
-	const double dlen2 = (double)len2;
-	const uint32_t step_i = (64u * (uint32_t)len1) / (uint32_t)len2, step_t = (64u * (uint32_t)len1) % (uint32_t)len2;
 	for (int b = k0 / N; b <= (k1 - 1) / N; b++) {
 		const int base = b * N;
 		const int ia = max(k0, base) - base, ib = min(k1, base + N) - base;
 		const int j0 = arb_first_output(ia, len1, len2), j1 = arb_first_output(ib, len1, len2);
 		int j = j0 + lane;
 		if (j >= j1) continue;
-		int i, tick;
-		if (j == 0) { i = 1; tick = 0; }
-		else {
-			const uint32_t adv = (uint32_t)j * (uint32_t)len1;
-			const uint32_t q = (adv - 1u) / (uint32_t)len2;
-			i = 1 + (int)q;
-			tick = (int)(adv - q * (uint32_t)len2);
-		}
 		int16_t *bo = B + s * bstride + (size_t)b * len2;
 		const int rel0 = base - k0;
-		for (; j < j1; j += 64) {
-			int ii = i, tt = tick;
-			if (ii >= len1) { ii = len1 - 1; tt = len2; }
-			const double dt = (double)tt;
-			double frac;
-			if (fast) {
-				const double q0 = dt * rinv;
-				frac = fma(fma(-q0, dlen2, dt), rinv, q0);
-			} else {
-				frac = dt / dlen2;
-			}
+		const int32_t *ti = tab_i + j;
+		const double *tf = tab_frac + j;
+		for (; j < j1; j += 64, ti += 64, tf += 64) {
+			const int ii = *ti;
+			const double frac = *tf;
 			bo[j] = (int16_t)(at(rel0 + ii - 1) * (1 - frac) + at(rel0 + ii) * frac);
-			// 64 outputs on: j * len1 = (i - 1) * len2 + tick with 0 < tick <= len2 (tick == 0 only at j == 0)
-			if (tick == 0) { i = 0; tick = len2; }
-			i += (int)step_i; tick += (int)step_t;
-			if (tick > len2) { tick -= len2; i++; }
 		}
 	}
 	if (__any(unsettled) && lane == 0) wg_unsettled = 1;
