@@ -482,7 +482,7 @@ class ApartRows:
         self.lib = load()
         self.rows, self.cols = rows, cols
         p, apart, ms, walked = C.c_void_p(), C.c_int(), C.c_double(), C.c_size_t()
-        check(self.lib.rtlfm_gpu_malloc_apart_ex(device, rows * cols * 2, other_ptr, other_bytes, 80 << 30, C.byref(p), C.byref(apart),
+        check(self.lib.rtlfm_gpu_malloc_apart_ex(device, rows * cols * 2, other_ptr, other_bytes, 150 << 30, C.byref(p), C.byref(apart),
                                                  C.byref(ms), C.byref(walked)), "rtlfm_gpu_malloc_apart_ex")
         self.ptr, self.apart = p.value, bool(apart.value)
         self.search_ms, self.walked_mb = round(ms.value, 1), walked.value >> 20  # what finding the placement cost
@@ -575,7 +575,26 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
             cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
             cfg.max_blocks = nb
             self.g = GpuDemod(cfg, S, local_rank)
-            self.o = ApartRows(S, self.g.result_cap(nb), job.iq.data_ptr(), job.iq.numel(), local_rank)
+            cap = self.g.result_cap(nb)
+            have = job.out.rows * job.out.cols if isinstance(job.out, ApartRows) else 0
+            if S * cap <= have:
+                # the default workload's own output buffer, whose placement is known, under this leg's row length
+                outer = job.out
+
+                class View:
+                    ptr, apart = outer.ptr, outer.apart
+
+                    def data_ptr(self):
+                        return self.ptr
+
+                    def stride(self, dim):
+                        return cap if dim == 0 else 1
+
+                    def free(self):
+                        pass
+                self.o = View()
+            else:
+                self.o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
             self.output_apart = self.o.apart
             self.n = torch.zeros(S, dtype=torch.int32, device=dev)
             self.samples = S * nb * L // 2
@@ -703,10 +722,28 @@ class FmJob:
         self.g.set_path(a.path)
         cap = self.g.result_cap(NB) + int(os.environ.get("RTLFM_BENCH_ROW_PAD", "0"))  # experiments: rows off the 128-byte lines
         # the output a quarter of the HBM away from the input (data layout); --colocate 1 = wherever torch puts it
-        self.out = (torch.empty((S, cap), dtype=torch.int16, device=dev) if a.colocate
-                    else ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank))
+        self._parked = []
+        if a.colocate:
+            self.out = torch.empty((S, cap), dtype=torch.int16, device=dev)
+        else:
+            # "apart" is a minority of the memory and where it lies differs from box to box: if the
+            # search comes back empty-handed, the input moves (a second copy somewhere else; the first stays parked so that
+            # the allocator cannot hand the same place out again) and the search runs once more - three tries in all
+            tries = []
+            for attempt in range(3):
+                self.out = ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank)
+                tries.append({"apart": self.out.apart, "search_ms": self.out.search_ms, "walked_mb": self.out.walked_mb})
+                if self.out.apart or attempt == 2 or a.pmc_child:
+                    break
+                self.out.free()
+                moved = torch.empty_like(self.iq)
+                moved.copy_(self.iq)
+                self._parked.append(self.iq)
+                self.iq = moved
         self.output_apart = bool(getattr(self.out, "apart", False))
         self.placement = {"search_ms": getattr(self.out, "search_ms", None), "walked_mb": getattr(self.out, "walked_mb", None)}
+        if not a.colocate:
+            self.placement["tries"] = tries
         self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
         self.local_rank = local_rank
         # u8 I + u8 Q in, int16 PCM out at 1/D (x the resampling ratio)
@@ -754,6 +791,7 @@ class FmJob:
         self.g.close()
         if hasattr(self.out, "free"):
             self.out.free()
+        self._parked = []
 
 
 class PowerJob:

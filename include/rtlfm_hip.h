@@ -275,7 +275,7 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   lpr_scalar_stores    1: the resampler's outputs one by one
  *   lpr_chunk            samples per lane of the one-pass deemph + low_pass_real kernel (default 2720; 256 ... 2^20,
  *                        anything else -EINVAL)
- *   apart_budget_gb      most device memory (GiB, default 80, never more than half of what is free) a placement
+ *   apart_budget_gb      most device memory (GiB, default 150, never more than 60 % of what is free) a placement
  *                        search may hold in temporary allocations; 0 = no search, plain allocations
  * Read-only (rtlfm_gpu_get_option):
  *   ring_apart           1 / 0: the result buffers behind rtlfm_gpu_push() / _run() are / are not a quarter of the HBM
@@ -370,8 +370,8 @@ int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream
  *
  * rtlfm_gpu_malloc_apart: `bytes` of device memory for a write stream that runs beside the read stream
  * of `other` (other_bytes long; only read): candidates are timed against `other` with the bandwidth
- * probe until one lies in another quarter (a few ms each; up to 80 GB of temporary allocations are
- * walked over and freed again).  *apart (may be NULL) = 1 when found; otherwise - buffers too small to
+ * probe until one lies in another quarter (a few ms each; up to 150 GiB of temporary allocations - two
+ * quarters - are walked over and freed again).  *apart (may be NULL) = 1 when found; otherwise - buffers too small to
  * matter (< 256 MiB streamed), no budget, probe failure - ordinary memory is returned with *apart = 0.
  * The library's own result buffers behind rtlfm_gpu_push() / _run() are placed this way.
  * rtlfm_gpu_placement_probe: 1 if existing buffers `in` / `out` are a quarter apart, 0 if not (or too
@@ -381,7 +381,7 @@ int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream
 int rtlfm_gpu_malloc(int device, size_t bytes, void **out);
 int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart);
 /* The same with the search's cost in the open: budget_bytes = most the filler walk may hold (0: no search, plain
- * memory; rtlfm_gpu_malloc_apart uses 80 GiB; never more than half of the free device memory is taken),
+ * memory; rtlfm_gpu_malloc_apart uses 150 GiB; never more than 60 % of the free device memory is taken),
  * *search_ms = wall time of the call, *walked_bytes = most it held at once (either may be NULL). */
 int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
                               void **out, int *apart, double *search_ms, size_t *walked_bytes);

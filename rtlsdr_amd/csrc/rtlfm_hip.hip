@@ -93,7 +93,7 @@ struct rtlfm_gpu {
 	bool no_deemph_scan = false;      // stream-range views (ragged runs) keep to the sequential filter
 	// placement of the write streams (rtlfm_gpu_malloc_apart_ex): what the searches found and what they cost
 	struct Placement {
-		int budget_gb = 80;             // option apart_budget_gb: most the filler walk may hold; 0 = no search
+		int budget_gb = 150;            // option apart_budget_gb: most the filler walk may hold; 0 = no search
 		int ring_apart = -1;            // -1: not allocated yet; 0 / 1: the ring's result buffers (both halves) are a quarter away from d_in
 		int res_apart = -1;             // the same for the audio tail's work buffers against the first run's input
 		double search_ms = 0;           // wall time of all searches of this handle
@@ -2025,7 +2025,9 @@ size_t probe_region(size_t in_bytes, size_t out_bytes)
 }
 
 constexpr float kApartRatio = 1.21f;  // read+write over read-only time: 1.12 apart, 1.31 in the same quarter
-constexpr size_t kApartBudgetDefault = (size_t)80 << 30;
+// (80 GiB until the end of round 4: on one of the pool's boxes two searches in a row walked all of it - 82 GB - and found
+// nothing where others found the boundary after 61 and 70 GB; the walk is ~1 ms per GB)
+constexpr size_t kApartBudgetDefault = (size_t)150 << 30;
 
 }  // namespace
 
@@ -2070,10 +2072,11 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	const size_t step = (size_t)4 << 30;
-	// a quarter is 72 GB: at most that much (the caller's budget) is walked over, and never more than HALF of what
-	// is free - the device may have other tenants, whose next allocation must not fail because of a search
+	// a quarter is 72 GB, and a buffer near the start of its quarter needs nearly all of it walked over: the caller's
+	// budget (the library's default: two quarters), and never more than 60 % of what is free - the device may have other
+	// tenants, whose next allocation must not fail because of a search
 	size_t budget = budget_bytes;
-	if (budget > free_b / 2) budget = free_b / 2;
+	if (budget > free_b / 5 * 3) budget = free_b / 5 * 3;
 	std::vector<void *> keep;       // fillers
 	std::vector<void *> cand;       // candidates that did not pass, with their times
 	std::vector<float> cand_rw;

@@ -64,6 +64,61 @@ def test_cli_output_matches_oracle(oracle_lib, tmp_path, argv, plan, fs):
     assert d.max() <= (0 if exact_needed else 1) and (d != 0).mean() <= 1e-4, (argv, int(d.max()), int((d != 0).sum()))
 
 
+@pytest.mark.parametrize("zero_copy", [True, False])
+def test_cli_on_a_slow_rtl_tcp_source_loses_nothing(oracle_lib, tmp_path, zero_copy):
+    """The dongle / demod hand-off under a source that dribbles (an rtl_tcp server that sends 3000 bytes at a time with
+    pauses, RTLSDR_FILE=tcp://...): with -Z the device layer has a ring slot open nearly all the time and
+    rtlfm_gpu_run() refuses to start while one is - no committed buffer may be left in the ring at the end of the
+    stream, none demodulated twice.  The PCM must be the oracle's for every whole buffer that arrived."""
+    import socket
+    import threading
+    import time
+    _, cli = hipbuild.build_host()
+    ov = dict(rate_out=150000)
+    cfg = RtlfmCfg.default(**ov)
+    cf, cr = C.c_uint32(), C.c_uint32()
+    oracle_lib.oracle().orc_optimal_settings(C.byref(cfg), 100000000, 150000, 1300000, 1, 0, C.byref(cf), C.byref(cr))
+    L, nb = int(cfg.block_len), 23
+    iq = synth.fm_iq_u8(1, L // 2 * nb, fs=2.4e6, dev_hz=5e3, amplitude=60.0, seed=405)[0]
+    payload = iq.tobytes()
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    port = srv.getsockname()[1]
+
+    def serve():
+        c, _ = srv.accept()
+        c.sendall(b"RTL0" + (5).to_bytes(4, "big") + (29).to_bytes(4, "big"))
+        for at in range(0, len(payload), 3000):
+            c.sendall(payload[at:at + 3000])
+            time.sleep(0.002 if (at // 3000) % 7 else 0.02)
+        # the client's tuning commands sit unread in this socket: closing it now would answer with a reset and the
+        # client's kernel would drop what it has not read yet - finish the sending side, then drain until the client leaves
+        c.shutdown(socket.SHUT_WR)
+        c.settimeout(20.0)
+        try:
+            while c.recv(4096):
+                pass
+        except OSError:
+            pass
+        c.close()
+    t = threading.Thread(target=serve, daemon=True)
+    t.start()
+    out = tmp_path / "audio.raw"
+    env = dict(os.environ, RTLSDR_FILE=f"tcp://127.0.0.1:{port}")
+    argv = ["-M", "fm", "-s", "150k", "-m", "1.3M", "-F", "0"] + (["-Z"] if zero_copy else [])
+    r = subprocess.run([cli, "-f", "100M"] + argv + [str(out)], env=env, capture_output=True, text=True, timeout=300)
+    t.join(10)
+    srv.close()
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert f"{nb} buffers in" in r.stderr, r.stderr[-400:]
+    got = np.fromfile(out, dtype=np.int16)
+    want, _ = oracle_lib.run_stream(cfg, iq)
+    assert got.shape == want.shape, (got.shape, want.shape, r.stderr[-300:])
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-4
+
+
 @pytest.mark.parametrize("argv,passes", [
     (["-f", "100M:102.048M:125", "-w", "hamming", "-1"], 4),          # BASELINE config 4's command line
     (["-f", "88M:96M:10k", "-w", "blackman", "-c", "20%", "-1"], 3),  # 3 hops, cropped

@@ -1203,8 +1203,9 @@ def test_caller_stream_orders_the_audio_tail(oracle_lib):
 def test_placement_is_observable_and_bounded():
     """The search that places the write streams a quarter of the HBM away from the read stream
     (rtlfm_gpu_malloc_apart_ex) is a measured walk over temporary allocations: what it found, how long it took and
-    how much it held are readable per handle, the walk is capped (apart_budget_gb), and two handles created back to
-    back on one device both come up - neither search may starve the other of memory."""
+    how much it held are readable per handle, the walk is capped (apart_budget_gb: two 72 GB quarters by default, never
+    more than 60 % of the free memory), and two handles created back to back on one device both come up - neither
+    search may starve the other of memory."""
     from rtlsdr_amd.demod import GpuDemod
     L, ns = 262144, 1024                     # a 256 MiB ring half: large enough for the search to run
     ov = dict(downsample=16, downsample_passes=4)
@@ -1219,7 +1220,7 @@ def test_placement_is_observable_and_bounded():
             for s in range(ns):
                 g.rtlsdr_callback(buf, s)    # the first push builds the ring
             assert g.get_option("ring_apart") in (0, 1)
-            assert g.get_option("placement_walked_mb") < 100 * 1024
+            assert g.get_option("placement_walked_mb") < 160 * 1024
             assert g.get_option("placement_ms") >= 0
             g.full_demod(); g.fetch_all()
         with pytest.raises(Exception):

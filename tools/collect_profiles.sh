@@ -2,12 +2,12 @@
 # tools/collect_profiles.sh — on the GPU box: for every measured workload the bench line, right
 # behind it the rocprofv3 kernel-trace stats of the same workload (the box drifts by a few per cent
 # over minutes at its power cap, so the two that have to agree are taken back to back), and PMC
-# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r03) (copy
+# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r04) (copy
 # what should be judged into profiles/ afterwards; the raw traces are deleted, they are large).
 # One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 top() { # csv title
@@ -25,12 +25,12 @@ PY
 }
 # long enough that the clock ramp of the first launches after idle does not weigh on the averages
 COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0 --ceiling 0 --also 0"
-for spec in "c2:" "ns4096:--workload ns4096" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
+for spec in "ns4096:" "c2:--workload c2" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
   tag=${spec%%:*}; args=${spec#*:}
   if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $tag "; then continue; fi
   cd $ROOT
   case $tag in
-    c2) timeout 400 python bench.py > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
+    ns4096) timeout 600 python bench.py > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
     box*) timeout 300 python bench.py $args --steps 100 --warmup 50 --no-cpu-baseline --e2e 0 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
     *) timeout 400 python bench.py $args --steps 100 --warmup 50 --cpu-seconds 6 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err ;;
   esac
@@ -48,7 +48,7 @@ pmc() { # tag kernels bench-args...
   for k in $kernels; do cp $ROOT/gpurun_out/pmc_${ROUND}_$tag/summary_$k.txt $OUT/pmc_${tag}_$k.txt; done
   rm -rf $ROOT/gpurun_out/pmc_${ROUND}_$tag
 }
-if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " c2 "; then pmc c2 "k_fused"; fi
+if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " ns4096 "; then pmc ns4096 "k_fused"; fi
 if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " c3 "; then pmc c3 "k_fused k_deemph_spec_arb" --workload c3; fi
 if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " wbfm "; then pmc wbfm "k_boxcar_scan k_deemph_spec_lpr" --workload wbfm; fi
 if [ -z "${PMC_ONLY:-}" ] || echo " $PMC_ONLY " | grep -q " box10 "; then pmc box10 "k_boxcar_scan" --boxcar 10; fi
