@@ -371,7 +371,10 @@ int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream
  * rtlfm_gpu_malloc_apart: `bytes` of device memory for a write stream that runs beside the read stream
  * of `other` (other_bytes long; only read): candidates are timed against `other` with the bandwidth
  * probe until one lies in another quarter (a few ms each; up to 150 GiB of temporary allocations - two
- * quarters - are walked over and freed again).  *apart (may be NULL) = 1 when found; otherwise - buffers too small to
+ * quarters - are walked over and freed again).  A candidate is at least 1 GiB and the winner is kept whole
+ * (the driver's allocator serves smaller requests from holes that all sit in one place; from 1 GiB on the
+ * allocations move through the quarters): up to 1 GiB - bytes stay unused behind a placed buffer.
+ * *apart (may be NULL) = 1 when found; otherwise - buffers too small to
  * matter (< 256 MiB streamed), no budget, probe failure - ordinary memory is returned with *apart = 0.
  * The library's own result buffers behind rtlfm_gpu_push() / _run() are placed this way.
  * rtlfm_gpu_placement_probe: 1 if existing buffers `in` / `out` are a quarter apart, 0 if not (or too

@@ -2090,24 +2090,37 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 	// tenants, whose next allocation must not fail because of a search
 	size_t budget = budget_bytes;
 	if (budget > free_b / 5 * 3) budget = free_b / 5 * 3;
+	// Candidates are at least 1 GiB (the winner is kept whole: up to 1 GiB - bytes of it stay unused).  The driver's
+	// allocator serves small requests from whatever holes it has, and those sit in ONE place: a walk with 268 MiB
+	// candidates between 4 GiB fillers kept getting its candidates from the input's own quarter while the fillers
+	// advanced through the others (round 4, tools/placement_sizes.py: twenty 268 MiB blocks in a row all landed in class
+	// A, 1 GiB blocks went B A A B B A B B B B B B C C ..., 4 GiB ones C C C C C C A A ...; one search walked 152 GB that
+	// way and found nothing).  From 1 GiB on an allocation goes where the big free ranges are and the classes rotate.
+	const size_t cand_bytes = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
 	std::vector<void *> keep;       // fillers
 	std::vector<void *> cand;       // candidates that did not pass, with their times
 	std::vector<float> cand_rw;
 	void *win = nullptr;
 	size_t walked = 0;
-	for (;;) {
+	for (int tries = 0;; tries++) {
 		void *p = nullptr;
-		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+		if (hipMalloc(&p, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
 		float rw = 0;
 		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 6, &rw) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
 		if (rw < kApartRatio * rd) { win = p; break; }
 		cand.push_back(p); cand_rw.push_back(rw);
-		if (walked + step + bytes > budget) break;
-		void *f = nullptr;
-		if (hipMalloc(&f, step) != hipSuccess) { (void)hipGetLastError(); break; }
-		keep.push_back(f);
-		walked += step + bytes;
+		walked += cand_bytes;
 		clk.peak = walked;
+		// a long run of one class (40 GB and more were seen): from the sixth try on, 4 GiB of filler per try as well
+		const size_t push = tries >= 5 ? step : 0;
+		if (walked + push + cand_bytes > budget) break;
+		if (push) {
+			void *f = nullptr;
+			if (hipMalloc(&f, push) != hipSuccess) { (void)hipGetLastError(); break; }
+			keep.push_back(f);
+			walked += push;
+			clk.peak = walked;
+		}
 	}
 	for (void *k : keep) hipFree(k);
 	// no candidate under the threshold (a noisy box, or the walk ran out of budget): the one that measured
@@ -2124,7 +2137,7 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 	}
 	for (void *c : cand)
 		if (c) hipFree(c);
-	if (!win) HIP_TRY(hipMalloc(&win, bytes));
+	if (!win) HIP_TRY(hipMalloc(&win, bytes));  // (nothing could be allocated at candidate size)
 	*out = win;
 	return 0;
 }

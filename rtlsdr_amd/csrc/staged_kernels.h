@@ -1107,11 +1107,12 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 	}
 	__threadfence_block();  // the chunk records and outputs of this workgroup's lanes, for its finishing lanes
 	__syncthreads();
-	if (!live || c_first != 0) return;
-	int E, phase;
-	lpr_totals(p0, n, slow, fast, E, phase);
+	if (!live) return;
 	if (plain || unsettled[sl]) {
-		// the reference's loop over the whole run, on this lane
+		if (c_first != 0) return;
+		// the reference's loop over the whole run, on the stream's first lane
+		int E, phase;
+		lpr_totals(p0, n, slow, fast, E, phase);
 		const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(p0, fast) : (int)(p0 / fast);
 		LprSink sink(B + s * bstride, m0, (int)(p0 - (long long)m0 * fast), slow, fast, (uint32_t)sin[s].now_lpr, vec != 0);
 		if (plain) {
@@ -1122,24 +1123,37 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 		}
 		sink.finish();
 		sout[s].now_lpr = (int)sink.out.tail;
-	} else {
-		// the one output per chunk boundary that began in the chunks before, and what the run leaves in the accumulator
-		const LprChunk *l0 = lc + s * max_chunks;
-		const int div = fast / slow;
-		uint32_t carry = 0;  // what the chunks so far have left in the accumulator since their last emission
-		for (int j = 0; j < nc; j++) {
-			const LprChunk k = l0[j];
-			if (k.mfirst >= 0) {
-				if (j > 0) B[s * bstride + k.mfirst] = (int16_t)((int)(k.head + carry) / div);
-				carry = k.tail;
-			} else {
-				carry += k.tail;
-			}
-		}
-		sout[s].now_lpr = (int)carry;
+		sout[s].prev_lpr_index = phase;
+		if (cnt_out) cnt_out[s] = E;
+		return;
 	}
-	sout[s].prev_lpr_index = phase;
-	if (cnt_out) cnt_out[s] = E;
+	// Every lane finishes its own chunks (as k_lpr_fixup does for the four-pass route): the one output that began in
+	// the chunks before - its value needs what they left in the accumulator since their last emission, normally the
+	// direct predecessor's tail -, and the run's last chunk leaves the carried accumulator, phase and count.  (One lane
+	// walking all chunk records of its stream here kept the other 255 lanes of the workgroup waiting for ~130 dependent
+	// trips to L2: a quarter of the kernel's time at the wbfm shape.)
+	const LprChunk *l0 = lc + s * max_chunks;
+	const int div = fast / slow;
+	auto left_by = [&](int upto) {
+		uint32_t sum = 0;
+		for (int j = upto; j >= 0; j--) {
+			const LprChunk k = l0[j];
+			sum += k.tail;
+			if (k.mfirst >= 0) break;
+		}
+		return sum;
+	};
+	for (int c = c_first; c < nc; c += c_step) {
+		const LprChunk k = l0[c];
+		if (c > 0 && k.mfirst >= 0) B[s * bstride + k.mfirst] = (int16_t)((int)(k.head + left_by(c - 1)) / div);
+		if (c == nc - 1) {
+			int E, phase;
+			lpr_totals(p0, n, slow, fast, E, phase);
+			sout[s].now_lpr = (int)left_by(c);
+			sout[s].prev_lpr_index = phase;
+			if (cnt_out) cnt_out[s] = E;
+		}
+	}
 }
 
 // the outputs that straddle chunk boundaries, the carried accumulator and the output count

@@ -124,6 +124,8 @@ def test_cli_on_a_slow_rtl_tcp_source_loses_nothing(oracle_lib, tmp_path, zero_c
     (["-f", "88M:96M:10k", "-w", "blackman", "-c", "20%", "-1"], 3),  # 3 hops, cropped
     (["-f", "433M:434M:1k", "-F", "9", "-1"], 2),                      # one hop, fifth_order /2 + FIR9
     (["-f", "24M:34M:1M", "-1"], 2),                                   # giant bins: rms_power per hop
+    (["-f", "100M:102M:50", "-w", "hamming", "-1"], 2),                # fine bins: 2^16 per hop, the transform over HBM
+    (["-f", "144M:146.4M:10", "-c", "10%", "-1"], 2),                  # 2^18 bins
 ])
 def test_rtl_power_cli_matches_oracle(oracle_lib, tmp_path, argv, passes):
     from rtlsdr_amd import capi
@@ -153,7 +155,7 @@ def test_rtl_power_cli_matches_oracle(oracle_lib, tmp_path, argv, passes):
     reads = iq.reshape(passes, T, L)
     for i in range(T):
         avg, n = oracle_lib.power_scan_batch(cfg, np.ascontiguousarray(reads[:, i, :]).reshape(1, -1))
-        buf = C.create_string_buffer(1 << 20)
+        buf = C.create_string_buffer(8 << 20)
         a = avg[0].copy()
         assert lib.rtlpower_csv_dbm(C.byref(plan), i, a.ctypes.data, int(n[0]), buf, len(buf)) > 0
         got = lines[i].split(", ", 2)[2]  # drop "date, time, "
