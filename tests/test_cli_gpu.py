@@ -125,7 +125,7 @@ def test_cli_on_a_slow_rtl_tcp_source_loses_nothing(oracle_lib, tmp_path, zero_c
     (["-f", "433M:434M:1k", "-F", "9", "-1"], 2),                      # one hop, fifth_order /2 + FIR9
     (["-f", "24M:34M:1M", "-1"], 2),                                   # giant bins: rms_power per hop
     (["-f", "100M:102M:50", "-w", "hamming", "-1"], 2),                # fine bins: 2^16 per hop, the transform over HBM
-    (["-f", "144M:146.4M:10", "-c", "10%", "-1"], 2),                  # 2^18 bins
+    (["-f", "144M:146.4M:10", "-c", "20%", "-1"], 2),                  # two hops of 2^18 bins, cropped
 ])
 def test_rtl_power_cli_matches_oracle(oracle_lib, tmp_path, argv, passes):
     from rtlsdr_amd import capi
