@@ -582,6 +582,54 @@ __global__ void __launch_bounds__(256) k_power_place(const StagedParams p)
 	}
 }
 
+// The same placement for bin_e >= 12 without the scattered 4-byte stores (every store of k_power_place lands in a line of
+// its own: the bit reversal of consecutive j): the index is cut into j = a << (E - 6) | m << 6 | c, and a workgroup takes
+// the 64 x 64 tile (a, c) of one m - 64 rows of 64 CONSECUTIVE samples (128 input bytes each) -, turns it over in LDS and
+// writes 64 rows of 64 consecutive points: rev(j) = rev6(c) << (E - 6) | rev(m) << 6 | rev6(a), so for a fixed c the
+// 64 values of a fill one 256-byte piece of the frame.  Both sides move whole lines.
+__global__ void __launch_bounds__(256) k_power_place_tiled(const StagedParams p)
+{
+	__shared__ uint32_t tile[64][65];
+	const int E = p.bin_e, N = 1 << E;
+	const int mbits = E - 12;                      // >= 0
+	const size_t M = (size_t)p.chunks * N;
+	const size_t tiles_per_frame = (size_t)1 << mbits;
+	const size_t total = (size_t)p.nstreams * p.nreads * p.chunks * tiles_per_frame;
+	const int t = threadIdx.x, c = t & 63, a0 = t >> 6;  // 4 rows per sweep
+	for (size_t g = blockIdx.x; g < total; g += gridDim.x) {
+		const size_t m = g & (tiles_per_frame - 1);
+		const size_t fr = g >> mbits;                // (stream, read, chunk)
+		const int ch = (int)(fr % p.chunks);
+		const size_t sr = fr / p.chunks;
+		const size_t s = sr / p.nreads;
+		const int r = (int)(sr % p.nreads);
+		const uint8_t *raw = p.iq8 ? p.iq8 + s * p.stride8 + (size_t)r * p.buf_len : nullptr;
+		const int16_t *dec = p.dec ? p.dec + s * p.dec_stream_stride + (size_t)r * p.dec_read_stride : nullptr;
+		const int2 av = p.ave[sr];
+		__syncthreads();
+		for (int a = a0; a < 64; a += 4) {
+			const int j = (a << (E - 6)) | ((int)m << 6) | c;
+			const int pnt = (ch << E) + j;           // point of the read (remove_dc and the data's end go by it)
+			int vi = staged_element(p, raw, dec, 2 * pnt), vq = staged_element(p, raw, dec, 2 * pnt + 1);
+			if (2 * pnt < p.len_dec) vi = (int16_t)(vi - av.x);
+			if (2 * pnt + 1 < p.len_dec) vq = (int16_t)(vq - av.y);
+			const int w = p.window[j];
+			vi = (int16_t)(vi * w);
+			vq = (int16_t)(vq * w);
+			tile[a][c] = pack_iq(vi, vq);
+		}
+		__syncthreads();
+		// output row c' = t >> 6 (+ 4 k): the points rev(j) for that c, a = rev6(t & 63) so that consecutive threads write consecutive points
+		const int ar = (int)(__brev((unsigned)(t & 63)) >> 26);
+		const unsigned mr = mbits ? (__brev((unsigned)m) >> (32 - mbits)) : 0u;
+		for (int cc = a0; cc < 64; cc += 4) {
+			const unsigned cr = __brev((unsigned)cc) >> 26;
+			const size_t rj = ((size_t)cr << (E - 6)) | ((size_t)mr << 6) | (size_t)(t & 63);
+			p.work[sr * M + ((size_t)ch << E) + rj] = tile[ar][cc];
+		}
+	}
+}
+
 // stages 0 .. eb - 1 (eb = min(bin_e, 14)) of one block of 2^eb points per workgroup
 __global__ void __launch_bounds__(kThreads) k_power_fft_lds(uint32_t *work, const uint32_t *twg, int eb, size_t nblocks_total)
 {

@@ -533,7 +533,8 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 			sp.ave = h->d_ave; sp.work = h->d_work; sp.avg = h->d_avg; sp.samples = h->d_samples; sp.nstreams = S;
 			const size_t frames = (size_t)S * nb * h->chunks;
 			k_power_dc<<<(unsigned)((size_t)S * nb), 256, 0, q>>>(sp);
-			k_power_place<<<grid_for((size_t)S * nb * M, 256, 256 * 64), 256, 0, q>>>(sp);
+			if (c.bin_e >= 12) k_power_place_tiled<<<grid_for(frames << (c.bin_e - 12), 1, 256 * 64), 256, 0, q>>>(sp);
+			else k_power_place<<<grid_for((size_t)S * nb * M, 256, 256 * 64), 256, 0, q>>>(sp);
 			const size_t nblk = frames << (c.bin_e - eb);
 			hipLaunchKernelGGL(k_power_fft_lds, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(kThreads), lds, q, h->d_work, h->d_tw, eb, nblk);
 			for (int st = 14; st < c.bin_e;) {
