@@ -219,3 +219,31 @@ def test_planner_random_against_live_reference(oracle_lib):
             assert got == want, (arg, crop, boxcar)
     finally:
         ref.close()
+
+
+def test_every_plan_of_the_planner_is_accepted():
+    """What frequency_range() can plan, rtlpower_gpu_create() takes: bins from 2^1 to 2^21 (src/rtl_power.c:483-486),
+    boxcar or fifth_order in front, any crop - rtlpower_cfg_validate (no GPU needed) must accept the configuration of
+    every plan (rounds 1-3 answered -ENOTSUP above 2^14 bins)."""
+    from rtlsdr_amd import capi
+    from rtlsdr_amd import build as hipbuild
+    hipbuild.build()
+    lib = capi.load()
+    rng = np.random.default_rng(78)
+    seen = set()
+    for k in range(600):
+        lo = int(rng.integers(24_000_000, 1_600_000_000))
+        width = int(rng.choice([rng.integers(20_000, 900_000), rng.integers(900_000, 3_000_000), rng.integers(3_000_000, 40_000_000)]))
+        step = int(rng.choice([rng.integers(1, 50), rng.integers(50, 2000), rng.integers(2000, 900_000)]))
+        crop = float(rng.choice([0.0, 0.1, 0.25]))
+        boxcar = int(rng.integers(0, 2))
+        plan = capi.RtlpowerPlan()
+        if lib.rtlpower_frequency_range(lo, lo + width, step, crop, boxcar, C.byref(plan)) != 0 or plan.tune_count == 0:
+            continue
+        cfg = capi.RtlpowerCfg()
+        lib.rtlpower_plan_cfg(C.byref(plan), int(rng.integers(0, 8)), boxcar, int(rng.choice([0, 9])), 0, C.byref(cfg))
+        assert lib.rtlpower_cfg_validate(C.byref(cfg)) == 0, (lo, width, step, crop, boxcar, plan.bin_e, plan.downsample, plan.buf_len)
+        seen.add(plan.bin_e)
+    assert max(seen) == 21 and min(seen) <= 8, sorted(seen)
+    bad = capi.RtlpowerCfg.default(bin_e=22, buf_len=1 << 24)
+    assert lib.rtlpower_cfg_validate(C.byref(bad)) < 0
