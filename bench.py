@@ -86,6 +86,7 @@ def parse():
                     help="D > 0: the reference's default low_pass boxcar /D instead of fifth_order passes")
     ap.add_argument("--fir9", type=int, default=None)
     ap.add_argument("--rdc", type=int, default=0, help="1: -E rdc (dc_block_raw_filter) in front of the chain")
+    ap.add_argument("--squelch", type=int, default=0, help="-l N: the power squelch behind the decimator (the front end's emit mode + squelch kernels)")
     ap.add_argument("--atan", choices=["std", "fast", "lut"], default=None)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 staged, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +167,8 @@ def pmc_counters(a, counters):
             "--warmup", "2", "--sustain", "0", "--no-cpu-baseline", "--check", "0", "--workload", a.workload,
             "--streams", str(a.streams), "--blocks", str(a.blocks), "--block-len", str(a.block_len),
             "--path", str(a.path), "--atan", a.atan, "--colocate", "1", "--ceiling", "0", "--also", "0", "--e2e", "0"]
-    base += ["--boxcar", str(a.boxcar)] if a.boxcar else ["--passes", str(a.passes), "--fir9", str(a.fir9), "--rdc", str(a.rdc)]
+    base += ["--boxcar", str(a.boxcar)] if a.boxcar else ["--passes", str(a.passes), "--fir9", str(a.fir9)]
+    base += ["--rdc", str(a.rdc), "--squelch", str(getattr(a, "squelch", 0))]
     out = {}
     tmp = tempfile.mkdtemp(prefix="rtlfm_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -698,7 +700,8 @@ class FmJob:
         self.D = D
         rate_out = int(a.fs / D)
         kw = dict(downsample=D, downsample_passes=a.passes, comp_fir_size=9 if a.fir9 else 0, custom_atan=atan,
-                  rate_out=rate_out, block_len=a.block_len, max_blocks=a.blocks, dc_block_raw=1 if a.rdc else 0)
+                  rate_out=rate_out, block_len=a.block_len, max_blocks=a.blocks, dc_block_raw=1 if a.rdc else 0,
+                  squelch_level=int(getattr(a, "squelch", 0)))
         self.out_ratio = 1.0
         if a.tail == "c3":
             kw.update(rate_out=16000, deemph=1, deemph_a=lib.rtlfm_deemph_a(16000, 75), rate_out2=22050,
@@ -783,7 +786,7 @@ class FmJob:
         a, D = self.a, self.D
         front = f"low_pass boxcar /{D}" if a.boxcar else f"{a.passes}x fifth_order (/{D})" + (" + FIR9" if a.fir9 else "")
         tail = {"c3": " + deemph + arbitrary_resample 16k -> 22050", "wbfm": " + deemph + low_pass_real 170k -> 32k"}.get(a.tail, "")
-        front = ("dc_block_raw_filter + " if a.rdc else "") + front
+        front = ("dc_block_raw_filter + " if a.rdc else "") + front + (f" + squelch {a.squelch}" if getattr(a, "squelch", 0) else "")
         return (f"rtl_fm -A {a.atan}: {a.streams} streams/GPU x {a.blocks} buffers x {a.block_len} B u8 IQ @{a.fs / 1e6:g} MS/s, "
                 f"{front} + polar discriminant{tail} -> int16 PCM")
 

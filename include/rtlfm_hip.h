@@ -263,7 +263,8 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   fused_waves          waves a front-end launch aims for (default 8192 = twice the GPU's wave slots);
  *                        a stream's run is cut into that many segments / nstreams.  Sets fused_waves_tail too.
  *   fused_waves_tail     the same for configurations with an audio tail behind the front end (deemph, DC block,
- *                        resamplers; default 20480: shorter segments let the tail's waves in sooner)
+ *                        resamplers; default 20480 behind the boxcar, 12288 behind fifth_order passes: shorter
+ *                        segments let the tail's waves in sooner)
  *   fused_min_tiles      shortest segment in 8 KiB tiles (default 8: each segment but a stream's first
  *                        re-runs one warm-up tile); not applied while the launch cannot fill the GPU
  *   fused_tiles_per_seg  > 0: exactly this segment length (tests)

@@ -1130,6 +1130,10 @@ struct Workspace {
 	// Same-box sweep of 8192 .. 32768: c3 step 0.907-0.926 -> 0.872-0.876 ms, wbfm
 	// 1.418 -> 1.309-1.315 ms at 20480; without a tail the launch time is flat from 8192 to 24576.
 	int target_waves_tail = 20480;
+	// ... for the fifth_order front ends 12288 since the tail is ONE kernel (round 4, same box, two alternations: c3 step
+	// 0.879 / 0.876 / 0.873 / 0.884 ms at 20480 / 16384 / 12288 / 24576; the boxcar front end of -M wbfm still wants
+	// 20480: 1.392 / 1.408 / 1.424 / 1.392).  0 = as target_waves_tail (set together with it by fused_waves).
+	int target_waves_tail_fifth = 12288;
 	bool tail_follows = false;                    // set by the host per run (rtlfm_hip.hip: plan_tail)
 	int min_tiles = 8;                            // a segment pays one warm-up tile: at most 1/8 on top
 	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
@@ -1164,7 +1168,7 @@ struct SegPlan {
 	int segs = 1, tiles_per_seg = 0, nlist = 0;
 	int start[kMaxSegList + 1];
 };
-inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
+inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles, bool fifth_order = false)
 {
 	SegPlan sp;
 	sp.tiles_per_seg = total_tiles;
@@ -1178,7 +1182,8 @@ inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles)
 	// warm-up tile: segments of sixteen tiles at least (north_star's live shape - 4096 streams x ONE 262144-B
 	// buffer per launch - then runs one wave per stream: 0.2128 against 0.2158 ms, same box, interleaved)
 	if (nstreams >= kWaveSlots && min_tiles < 16 && !ws.tail_follows) min_tiles = 16;
-	const int target = ws.tail_follows ? ws.target_waves_tail : ws.target_waves;
+	const int target = !ws.tail_follows ? ws.target_waves
+	                   : (fifth_order && ws.target_waves_tail_fifth > 0 ? ws.target_waves_tail_fifth : ws.target_waves_tail);
 	int segs = (target + nstreams - 1) / nstreams;
 	int cap = total_tiles / min_tiles;
 	if (cap < 1) cap = 1;
@@ -1316,7 +1321,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	p.debug = ws.debug;
 	if (ws.want_stamps) p.debug |= 2;
 	if (needs_partial_tiles(c) && engine != 1) return -ENOTSUP;
-	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)((c.block_len + kTileBytes - 1) / kTileBytes));
+	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)((c.block_len + kTileBytes - 1) / kTileBytes), true);
 	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
 	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;

@@ -550,6 +550,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if (!slot) return -ENOENT;
 	if ((!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) && value < 1) return -EINVAL;
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
+	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
 	if (!strcmp(name, "pass0_engine") && (value < -1 || value > 1)) return -EINVAL;
 	if ((!strcmp(name, "fused_min_tiles") || !strcmp(name, "fused_tiles_per_seg")) && value < 0) return -EINVAL;
 	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
@@ -1056,7 +1057,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 		                                         c.dc_block_raw, h->d_mute, h->d_levels);
 	if (c.squelch_level) {
 		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
-		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, Nblk, D, nblocks, S, T, sin,
+		k_squelch_zero<<<S * nblocks, 256, 0, q>>>(cur, h->xstride, Nblk, D, nblocks, S, T, sin,
 		                                                     h->d_mute);
 	}
 	// --- mode_demod (src/rtl_fm.c:1256-1259)
@@ -1069,8 +1070,8 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	tail_route(h, tp, d_out, out_stride, &dd, &dds);
 	const int32_t *cnt = varcnt ? h->d_cnt[h->step & 1] : nullptr;
 	if (c.mode == RTLFM_MODE_FM)
-		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, dd, dds, T, S, Nblk, D,
-		                                                 c.custom_atan, h->d_lut, cnt, sin, sout);
+		k_fm_demod<<<S * nblocks, 256, 0, q>>>(cur, h->xstride, dd, dds, T, S, Nblk, D, nblocks,
+		                                         c.custom_atan, h->d_lut, cnt, sin, sout);
 	else
 		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->xstride, dd, dds, T, S, c.mode,
 		                                                     c.output_scale, cnt);
@@ -1232,14 +1233,14 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 		                                         c.dc_block_raw, h->d_mute, h->d_levels);
 	if (c.squelch_level) {
 		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
-		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, Nblk, 1, nblocks, S, T, sin,
+		k_squelch_zero<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, Nblk, 1, nblocks, S, T, sin,
 		                                                     h->d_mute);
 	}
 	int16_t *dd; size_t dds;
 	tail_route(h, tp, d_out, out_stride, &dd, &dds);
 	if (c.mode == RTLFM_MODE_FM)
-		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, Nblk, 1, c.custom_atan,
-		                                                 h->d_lut, nullptr, sin, sout);
+		k_fm_demod<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, Nblk, 1, nblocks, c.custom_atan,
+		                                         h->d_lut, nullptr, sin, sout);
 	else
 		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, c.mode,
 		                                                     c.output_scale, nullptr);
@@ -1321,14 +1322,14 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 		                                         h->d_mute, h->d_levels);
 	if (c.squelch_level) {
 		k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
-		k_squelch_zero<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, N0, D, nblocks, S, T, sin, h->d_mute);
+		k_squelch_zero<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, N0, D, nblocks, S, T, sin, h->d_mute);
 	}
 	int16_t *dd; size_t dds;
 	tail_route(h, tp, d_out, out_stride, &dd, &dds);
 	const int32_t *cnt = varcnt ? dcnt : nullptr;
 	if (c.mode == RTLFM_MODE_FM)
-		k_fm_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, N0, D, c.custom_atan, h->d_lut, cnt,
-		                                                 sin, sout);
+		k_fm_demod<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, N0, D, nblocks, c.custom_atan, h->d_lut, cnt,
+		                                         sin, sout);
 	else
 		k_simple_demod<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, h->deep_stride, dd, dds, T, S, c.mode, c.output_scale, cnt);
 	if (c.mode == RTLFM_MODE_RAW) {

@@ -340,6 +340,18 @@ k_squelch_rms(const uint32_t *__restrict__ X, size_t xstride, int N, int D, int 
 	while (len > step * 32768) ++step;
 	uint32_t p = 0;
 	int32_t t = 0;
+	if (step == 1) {
+		// both sums are taken modulo 2^32 (the reference's uint32 p wraps, :1093-1098), so their order is free: a packed
+		// (I, Q) pair per lane, v_dot2 for the squares and for I + Q
+		const uint32_t *z = X + s * xstride + t0;
+		typedef short s2_t __attribute__((ext_vector_type(2)));
+		const s2_t ones = {(short)1, (short)1};
+		for (int i = threadIdx.x; i < t1 - t0; i += blockDim.x) {
+			const s2_t v = __builtin_bit_cast(s2_t, z[i]);
+			p = (uint32_t)__builtin_amdgcn_sdot2(v, v, (int)p, false);
+			t = __builtin_amdgcn_sdot2(v, ones, t, false);
+		}
+	} else
 	for (int i = threadIdx.x * step; i < len; i += blockDim.x * step) {
 		int v = lp[i];
 		t += v;
@@ -391,49 +403,54 @@ __global__ void k_squelch_hits(const int32_t *__restrict__ mute, int nblocks, in
 	}
 }
 
+// a workgroup per (stream, block): nothing but a look at the flag for the blocks that stay
 __global__ void __launch_bounds__(256)
 k_squelch_zero(uint32_t *__restrict__ X, size_t xstride, int N, int D, int nblocks, int nstreams, int T,
                const state_t *__restrict__ sin, const int32_t *__restrict__ mute)
 {
-	const size_t total = (size_t)nstreams * T;
-	RTLFM_GRID_STRIDE(g, total) {
-		int t = (int)(g % T);
-		size_t s = g / T;
-		const int p0 = D > 1 ? sin[s].prev_index : 0;
-		int b = dec_block_of(t, N, D, p0);
-		if (b < nblocks && mute[s * nblocks + b] == 1)
-			X[s * xstride + t] = 0;
-	}
+	const int sb = blockIdx.x;
+	if (mute[sb] != 1) return;
+	const int b = sb % nblocks;
+	const size_t s = sb / nblocks;
+	const int p0 = D > 1 ? sin[s].prev_index : 0;
+	const int t0 = dec_block_begin(b, N, D, p0), t1 = dec_block_begin(b + 1, N, D, p0);
+	uint32_t *x = X + s * xstride;
+	for (int t = t0 + (int)threadIdx.x; t < t1 && t < T; t += 256) x[t] = 0;
 }
 
 // ------------------------------------------------------------------ demods ----
 // fm_demod (src/rtl_fm.c:932-959): output t pairs sample t with t-1 (or with
 // the carried pre_r/pre_j); the FIRST output of every block always uses
 // polar_discriminant.  cnt == nullptr: every stream has T samples.
+// A workgroup per (stream, block): the block's extent costs two divisions per workgroup instead of four 64-bit ones per
+// sample (the per-sample form was 1.24 ms for the 214 M decimated samples of a /10 run of 4 GiB - more than the
+// decimator in front of it).
 __global__ void __launch_bounds__(256)
 k_fm_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restrict__ R, size_t rstride,
-           int T, int nstreams, int N, int D, int variant, const int32_t *__restrict__ lut,
+           int T, int nstreams, int N, int D, int nblocks, int variant, const int32_t *__restrict__ lut,
            const int32_t *__restrict__ cnt, const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
-	const size_t total = (size_t)nstreams * T;
-	RTLFM_GRID_STRIDE(g, total) {
-		int t = (int)(g % T);
-		size_t s = g / T;
-		const int Ts = cnt ? cnt[s] : T;
-		if (t >= Ts) continue;
-		const uint32_t *Xs = X + s * xstride;
-		iq16 cur = unpack_iq(Xs[t]);
+	const int sb = blockIdx.x;
+	const int b = sb % nblocks;
+	const size_t s = sb / nblocks;
+	const int Ts = cnt ? cnt[s] : T;
+	const int p0 = D > 1 ? sin[s].prev_index : 0;
+	const int t0 = dec_block_begin(b, N, D, p0);
+	int t1 = dec_block_begin(b + 1, N, D, p0);
+	if (t1 > Ts) t1 = Ts;
+	const uint32_t *Xs = X + s * xstride;
+	int16_t *Rs = R + s * rstride;
+	for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) {
+		const iq16 cur = unpack_iq(Xs[t]);
 		int br, bj;
 		if (t > 0) {
-			iq16 pv = unpack_iq(Xs[t - 1]);
+			const iq16 pv = unpack_iq(Xs[t - 1]);
 			br = pv.i; bj = pv.q;
 		} else {
 			br = sin[s].pre_r; bj = sin[s].pre_j;
 		}
-		const int p0 = D > 1 ? sin[s].prev_index : 0;
-		int v = dec_block_first(t, N, D, p0) ? disc_std(cur.i, cur.q, br, bj)
-		                                     : discriminate(variant, cur.i, cur.q, br, bj, lut);
-		R[s * rstride + t] = (int16_t)v;
+		const int v = t == t0 ? disc_std(cur.i, cur.q, br, bj) : discriminate(variant, cur.i, cur.q, br, bj, lut);
+		Rs[t] = (int16_t)v;
 		if (t == Ts - 1) {
 			sout[s].pre_r = cur.i;
 			sout[s].pre_j = cur.q;
