@@ -369,8 +369,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		// P(n_{-1}) = -(carried partial sum), so that out[0] = carry + P(n_0); z_{-1} = the last output
 		// of the previous tile.
 		const uint32_t edgeP = pk_sub16(0u, pack_iq((int16_t)carry_r, (int16_t)carry_j));
-		auto P_at = [&](int e) -> uint32_t {  // P(n_e) for e >= 0
-			int n = (e + 1) * D - ph;
+		auto P_n = [&](int n) -> uint32_t {  // P(n): the prefix sum of the tile's first n samples
 			if (n > kTileSamples) n = kTileSamples;  // outputs past Et
 			const int d = n >> 1;
 			uint32_t Pv = lds[ScanLds::rows + row_at(d)];
@@ -393,6 +392,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			return Pv;
 		};
+		auto P_at = [&](int e) -> uint32_t { return P_n((e + 1) * D - ph); };  // P(n_e) for e >= 0
 		const int R = p.R;
 		const int e0 = lane * R;
 		uint32_t prevP, b;
@@ -402,11 +402,13 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			b = e0 > 0 ? pk_sub16(a1, e0 > 1 ? a2 : edgeP) : last_out;
 		}
 		uint32_t curP = P_at(e0);
+		int n_next = (e0 + 2) * D - ph;  // n of output e + 1: D further per round (a 32-bit multiply per look-up issues at quarter rate)
 		// (The per-lane `if`s below are cheaper than they look: a branch-free form - outputs past Et computed
 		// and dumped, the last output's boundary kept in registers - measured 8-13 % SLOWER.)
 		for (int r = 0; r < R; r++) {
 			const int e = e0 + r;
-			const uint32_t nxtP = P_at(e + 1);
+			const uint32_t nxtP = P_n(n_next);
+			n_next += D;
 			const uint32_t z = pk_sub16(curP, prevP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
 			if (EMIT) {
 				if (e < Et) {

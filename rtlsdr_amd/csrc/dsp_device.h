@@ -53,15 +53,18 @@ __device__ __forceinline__ int fifth_tap(int a, int b, int c, int d, int e, int 
 
 // generic_fir's sum over the nine samples before the current one
 // (src/rtl_fm.c:815-821), 32-bit wrap, >> 15.
+// The samples are int16 and the taps below 2^17 in magnitude: every factor fits 24 bits, and the low 32 bits of the
+// 48-bit product are the reference's wrapping 32-bit product - v_mul_i32_i24 / v_mad_i32_i24 issue at full rate where
+// the 32-bit multiply takes four times as long (said explicitly here; where the samples visibly come out of 16-bit
+// halves the compiler finds the 24-bit forms by itself).
 __device__ __forceinline__ int fir9_tap(const int h[9], const int32_t *t)
 {
-	uint32_t acc = 0;
-	acc += (uint32_t)(h[0] + h[8]) * (uint32_t)t[0];
-	acc += (uint32_t)(h[1] + h[7]) * (uint32_t)t[1];
-	acc += (uint32_t)(h[2] + h[6]) * (uint32_t)t[2];
-	acc += (uint32_t)(h[3] + h[5]) * (uint32_t)t[3];
-	acc += (uint32_t)h[4] * (uint32_t)t[4];
-	return (int32_t)acc >> 15;
+	int acc = __mul24(h[0] + h[8], t[0]);
+	acc = (int)((uint32_t)acc + (uint32_t)__mul24(h[1] + h[7], t[1]));
+	acc = (int)((uint32_t)acc + (uint32_t)__mul24(h[2] + h[6], t[2]));
+	acc = (int)((uint32_t)acc + (uint32_t)__mul24(h[3] + h[5], t[3]));
+	acc = (int)((uint32_t)acc + (uint32_t)__mul24(h[4], t[4]));
+	return acc >> 15;
 }
 
 // multiply(ar, aj, br, -bj) (src/rtl_fm.c:836-840, called at :846, :877, :898)

@@ -356,10 +356,13 @@ __device__ __forceinline__ void fifth_history(uint32_t *slots, uint32_t *cr, con
 // them in the prefix, straight from their registers.  Two barriers.
 // QUIRK: at a buffer start the entries that lie before the buffer are read one
 // position further back (see fifth_history); with fewer than five values per
-// lane that reaches lanes 1 and 2 as well, so it is applied per position.
+// lane that reaches lanes 1 and 2 as well.  SHIFT (whole-tile kernels): the kept prefix is then copied in front of
+// the body one slot LATER (its newest entry, the x[N-1] the reference never saves, falls off), so that every lane still
+// reads at one base address + constants; without it (partial tiles, whose next prefix needs that entry) the
+// position is chosen per read - a compare and a select per history entry.
 // nlanes < 64 (a partial tile): the ring's new prefix is the last kPre entries of (old prefix ++ the nlanes * C
 // valid entries), copied inside LDS instead of left by the last lanes' registers.
-template <int C, int H, bool QUIRK>
+template <int C, int H, bool QUIRK, bool SHIFT = false>
 __device__ __forceinline__ void ring_exchange(uint32_t *lds, int prefix, int body, const uint32_t (&mine)[C], uint32_t (&hist)[H],
                                               int lane, bool buffer_start, int nlanes = 64)
 {
@@ -372,12 +375,13 @@ __device__ __forceinline__ void ring_exchange(uint32_t *lds, int prefix, int bod
 	if (lane < kPre) carried = lds[prefix + lane];
 #pragma unroll
 	for (int k = 0; k < C; k++) ring[kPre + lane * C + k] = mine[k];
-	if (lane < kPre) ring[lane] = carried;
+	const int sh = (QUIRK && SHIFT && buffer_start) ? 1 : 0;  // wave-uniform
+	if (lane < kPre - sh) ring[lane + sh] = carried;
 	__builtin_amdgcn_wave_barrier();
 #pragma unroll
 	for (int k = 0; k < H; k++) {
 		int pos = lane * C - H + k;
-		if (QUIRK && buffer_start && pos < 0) pos -= 1;
+		if (QUIRK && !SHIFT && buffer_start && pos < 0) pos -= 1;
 		hist[k] = ring[kPre + pos];
 	}
 	__builtin_amdgcn_wave_barrier();
@@ -970,14 +974,14 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 						for (int k = 0; k < 4; k++) Z[k] = Y3[k];
 					} else {
 						uint32_t Y4[2];
-						ring_exchange<4, 5, true>(lds, L::y3, L::ring_body, Y3, h5, lz, bs, nlanes);
+						ring_exchange<4, 5, true, !PT>(lds, L::y3, L::ring_body, Y3, h5, lz, bs, nlanes);
 						fifth_lane<4, false>(Y3, h5, Y4);
 						archive_ring(L::y3, 4);
 						if constexpr (P == 5) {
 							Z[0] = Y4[0]; Z[1] = Y4[1];
 						} else {
 							uint32_t Y5[1];
-							ring_exchange<2, 5, true>(lds, L::y4, L::ring_body, Y4, h5, lz, bs, nlanes);
+							ring_exchange<2, 5, true, !PT>(lds, L::y4, L::ring_body, Y4, h5, lz, bs, nlanes);
 							fifth_lane<2, false>(Y4, h5, Y5);
 							archive_ring(L::y4, 5);
 							Z[0] = Y5[0];

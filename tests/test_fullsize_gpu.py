@@ -195,3 +195,95 @@ def test_wbfm_shape_full_size(oracle_lib):
     assert torch.equal(torch.cat([o[0, :int(l[0])] for o, l in zip(po_, pl_)]), fo[0][0, :tot])
     for s in fst:
         assert gu.state_dict(pst[s], False) == gu.state_dict(fst[s], False)
+
+
+def test_scanner_line_full_size(oracle_lib):
+    """The everyday scanner line at configs[1]'s size: rtl_fm -M fm -s 12k -l 50 (boxcar /84 + power squelch) on 256
+    streams x 64 buffers x 262144 B of keyed carriers - the boxcar front end in emit mode + the squelch / demod kernels
+    (`last_path == 2`) against the staged kernels on every sample and the oracle on sampled streams, split runs."""
+    S, NB, L = 256, 64, 262144
+    cfg = RtlfmCfg.default(downsample=84, rate_out=12000, squelch_level=50, block_len=L, max_blocks=NB)
+    dev = torch.device("cuda", 0)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=1.008e6, dev_hz=2.5e3, amplitude=0.8)
+    # key the carriers: every stream silent for its own stretch of whole and half buffers
+    for s in range(0, S, 3):
+        a = ((s * 7919) % (NB - 6)) * L + (L // 2 if s % 2 else 0)
+        iq[s, a:a + 5 * L // 2] = 127
+    fo, fl, fst, used = _run(cfg, iq, 2)
+    assert used == 2
+    so, sl, sst, used1 = _run(cfg, iq, 1)
+    assert used1 == 1 and torch.equal(fl[0], sl[0])
+    n = int(fl[0].max())
+    mask = torch.arange(n, device=dev)[None, :] < fl[0][:, None]
+    assert torch.equal(fo[0][:, :n][mask], so[0][:, :n][mask]), "emit-mode front end != staged at full size"
+    del so
+    for s in (0, 3, 129, 255):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        got = fo[0][s, :int(fl[0][s])].cpu().numpy()
+        assert got.shape == want.shape
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()))
+        if s in fst:
+            assert gu.state_dict(fst[s], False) == gu.state_dict(st, False)
+    po_, pl_, pst, _ = _run(cfg, iq, 2, splits=[(0, 7), (7, 8), (8, 64)])
+    tot = sum(int(l[0]) for l in pl_)
+    assert tot == int(fl[0][0])
+    assert torch.equal(torch.cat([o[0, :int(l[0])] for o, l in zip(po_, pl_)]), fo[0][0, :tot])
+    for s in fst:
+        assert gu.state_dict(pst[s], False) == gu.state_dict(fst[s], False)
+
+
+@pytest.mark.parametrize("front", ["p4", "box10"])
+def test_odd_buffer_length_full_size(oracle_lib, front):
+    """-W 40 (20480-byte buffers: two whole tiles and half a tile each) at scale: 1024 streams x 200 buffers = 4 GB of IQ
+    through the partial-tile fifth_order kernels / the boxcar's continuous run, against the staged kernels on every
+    sample, the oracle on sampled streams, and itself under run splitting."""
+    S, NB, L = 1024, 200, 20480
+    ov = dict(downsample=16, downsample_passes=4) if front == "p4" else dict(downsample=10, downsample_passes=0)
+    cfg = RtlfmCfg.default(rate_out=150000, block_len=L, max_blocks=NB, **ov)
+    iq = synth.fm_iq_u8_torch(S, NB * L // 2, torch.device("cuda", 0))
+    fo, fl, fst, used = _run(cfg, iq, 2)
+    assert used == 2
+    so, sl, sst, used1 = _run(cfg, iq, 1)
+    assert used1 == 1 and torch.equal(fl[0], sl[0])
+    n = int(fl[0].max())
+    mask = torch.arange(n, device=iq.device)[None, :] < fl[0][:, None]
+    assert torch.equal(fo[0][:, :n][mask], so[0][:, :n][mask]), "one-launch front end != staged at full size"
+    del so
+    for s in (0, 512, 1023):
+        want, st = oracle_lib.run_stream(cfg, iq[s].cpu().numpy())
+        got = fo[0][s, :int(fl[0][s])].cpu().numpy()
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert got.shape == want.shape and d.max() <= 1 and (d != 0).mean() <= 1e-4, (s, int(d.max()))
+        assert gu.state_dict(fst[s], False) == gu.state_dict(st, False)
+    po_, pl_, pst, _ = _run(cfg, iq, 2, splits=[(0, 33), (33, 34), (34, 200)])
+    tot = sum(int(l[0]) for l in pl_)
+    assert tot == int(fl[0][0])
+    assert torch.equal(torch.cat([o[0, :int(l[0])] for o, l in zip(po_, pl_)]), fo[0][0, :tot])
+
+
+def test_rtl_power_fine_bins_full_size(oracle_lib):
+    """frequency_range()'s fine-bin plans at scale: 2^17 bins, 64 tuning states x 16 reads x 262144 B (256 MiB of IQ per
+    launch) through the transform over HBM - every accumulator equal to the oracle's on sampled states, reads split
+    over two launches equal to one launch, and Parseval-like sanity: a state fed zeros-around-127 accumulates nothing
+    but the window's DC leakage."""
+    from rtlsdr_amd.capi import RtlpowerCfg
+    from rtlsdr_amd.power import GpuPower
+    S, NR, bin_e = 64, 16, 17
+    L = 2 << bin_e
+    cfg = RtlpowerCfg.default(bin_e=bin_e, window=1, buf_len=L)
+    dev = torch.device("cuda", 0)
+    iq = synth.fm_iq_u8_torch(S, NR * L // 2, dev, fs=2.048e6, dev_hz=50e3)
+    iq[S - 1] = 127
+    with GpuPower(cfg, S, 0) as g:
+        g.scan_torch(iq); g.sync()
+        one = [g.fetch(s) for s in (0, 31, S - 1)]
+        full = torch.from_numpy(np.stack([g.fetch(s)[0] for s in range(S)]))
+    with GpuPower(cfg, S, 0) as g:
+        g.scan_torch(iq[:, :5 * L].contiguous()); g.scan_torch(iq[:, 5 * L:].contiguous()); g.sync()
+        split = torch.from_numpy(np.stack([g.fetch(s)[0] for s in range(S)]))
+    assert torch.equal(full, split)
+    for (avg, n), s in zip(one, (0, 31, S - 1)):
+        want, wn = oracle_lib.power_scan_batch(cfg, iq[s:s + 1].cpu().numpy(), nthreads=1)
+        assert n == wn[0] == NR and np.array_equal(avg, want[0]), s
+    assert int(one[2][0].sum()) == 0  # 127 is sample 0: nothing but zeros goes into the transform
