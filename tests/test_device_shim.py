@@ -89,6 +89,39 @@ def test_async_reads_into_consumer_memory(shim, tmp_path, monkeypatch):
     lib.rtlsdr_close(h)
 
 
+def test_a_slot_that_is_too_small_is_given_back(shim, tmp_path, monkeypatch):
+    """A buffer source may offer less room than a transfer needs: the device layer must hand that slot back (the callback
+    sees the slot's pointer with 0 bytes, the owner commits nothing) before it reads into a buffer of its own - round 3
+    left the slot open, and a ring whose slot stays open never runs again."""
+    lib, _ = shim
+    data = np.random.default_rng(3).integers(0, 256, size=16384 * 3, dtype=np.uint8)
+    f = tmp_path / "iq.bin"
+    data.tofile(f)
+    monkeypatch.setenv("RTLSDR_FILE", str(f))
+    h = C.c_void_p()
+    assert lib.rtlsdr_open(C.byref(h), 0) == 0
+    small = np.zeros(4096, dtype=np.uint8)
+    seen = []
+    SRC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
+
+    def source(ctx, buf, cap):
+        buf[0] = small.ctypes.data
+        cap[0] = 4096          # a transfer is 16384 bytes
+        return 0
+
+    def cb(buf, n, ctx):
+        seen.append((C.cast(buf, C.c_void_p).value, n, bytes(C.string_at(buf, n))))
+    src_fn, cb_fn = SRC(source), CB(cb)
+    lib.rtlamd_file_set_buffer_source.argtypes = [C.c_void_p, SRC, C.c_void_p]
+    assert lib.rtlamd_file_set_buffer_source(h, src_fn, None) == 0
+    assert lib.rtlsdr_read_async(h, cb_fn, None, 0, 16384) == 0
+    given_back = [x for x in seen if x[0] == small.ctypes.data]
+    own = [x for x in seen if x[0] != small.ctypes.data]
+    assert len(given_back) >= 3 and all(n == 0 for _, n, _ in given_back)
+    assert b"".join(b for _, _, b in own) == data.tobytes()
+    lib.rtlsdr_close(h)
+
+
 def test_no_file_means_no_device(shim, monkeypatch):
     lib, _ = shim
     monkeypatch.delenv("RTLSDR_FILE", raising=False)

@@ -1236,6 +1236,27 @@ def test_placement_is_observable_and_bounded():
             g.close()
 
 
+def test_push_and_acquire_do_not_mix_on_one_stream():
+    """One producer per stream: while a slot is out between rtlfm_gpu_acquire and _commit, rtlfm_gpu_push for that stream
+    is refused (-EBUSY; it would land in that very slot), a second acquire too, and rtlfm_gpu_run says -EAGAIN."""
+    import errno
+    from rtlsdr_amd.demod import GpuDemod
+    cfg = make_cfg(dict(downsample=16, downsample_passes=4), 16384, 2)
+    buf = np.full(16384, 127, dtype=np.uint8)
+    with GpuDemod(cfg, 2, 0) as g:
+        p, cap = C.c_void_p(), C.c_uint32()
+        assert g.lib.rtlfm_gpu_acquire(g._h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == 16384
+        assert g.lib.rtlfm_gpu_push(g._h, 0, buf.ctypes.data, 16384) == -errno.EBUSY
+        assert g.lib.rtlfm_gpu_acquire(g._h, 0, C.byref(p), C.byref(cap)) == -errno.EBUSY
+        assert g.lib.rtlfm_gpu_push(g._h, 1, buf.ctypes.data, 16384) == 0      # another stream is free to push
+        assert g.lib.rtlfm_gpu_run(g._h) == -errno.EAGAIN
+        C.memmove(p, buf.ctypes.data, 16384)
+        assert g.lib.rtlfm_gpu_commit(g._h, 0, 16384) == 0
+        assert g.lib.rtlfm_gpu_run(g._h) == 0
+        o, n = g.fetch_all()
+        assert n[0] == n[1] == 512
+
+
 def test_ingest_overlaps_callbacks_with_runs(oracle_lib):
     """The staging ring has two halves: callbacks keep pushing (from several threads) while the
     previous run's transfer and kernels are in flight, results are fetched one run late, nothing is
