@@ -1123,6 +1123,9 @@ struct Workspace {
 	unsigned long long *stamps = nullptr;
 	int stamp_waves = 0;                          // capacity of stamps[]
 	int stamp_last = 0;                           // waves of the last launch that stamped
+	unsigned stamp_seq = 0;                       // stamped launches so far: they alternate between the two halves of stamps[]
+	// the half the last (back = 0) or the one before the last (back = 1) stamped launch wrote
+	const unsigned long long *stamp_half(int back) const { return stamps + (size_t)((stamp_seq + 1 + back) & 1) * stamp_waves * 4; }
 	uint32_t *mfma_taps[2] = {nullptr, nullptr};  // [rotate]
 	uint8_t *dummy_tile = nullptr;
 	int pass0_engine = -1;                        // 0 = v_dot4 (VALU), 1 = int8 MFMA; -1 = the compiled default (see launch)
@@ -1330,8 +1333,9 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;
 	if (p.debug & 2) {
-		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; ws.stamp_waves = 0; if (hipMalloc(&ws.stamps, (size_t)waves * 32) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
-		p.stamps = ws.stamps;
+		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; ws.stamp_waves = 0; if (hipMalloc(&ws.stamps, (size_t)waves * 32 * 2) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
+		p.stamps = ws.stamps + (size_t)(ws.stamp_seq & 1) * ws.stamp_waves * 4;
+		ws.stamp_seq++;
 		ws.stamp_last = waves;
 	}
 	if (emit_iq) p.variant = RTLFM_ATAN_FAST;  // the emit path lives in the run-time-discriminator kernels

@@ -55,6 +55,10 @@ struct ScanParams {
 	int32_t *samples;        // [stream]
 	int groups;              // workgroups per stream: group g takes reads [g, g + 1) * nreads / groups
 	unsigned long long *stamps;  // rtlpower_gpu_clock_probe: [workgroups][4] shader clock first / last, 100 MHz counter first / last
+	// k_power_scan_big<14, true> (frames of 2^(14 + comb_c) points, see "transforms that do not fit" below): iq8 = the
+	// frames' bytes comb by comb, window16 = the window likewise, ave = remove_dc's averages per frame, work = where
+	// the blocks go after stage 13
+	int comb_c; size_t comb_blocks; const int2 *ave; uint32_t *work;
 };
 
 // FIX_MPY, src/rtl_power.c:263-269
@@ -332,9 +336,17 @@ __global__ void __launch_bounds__(kThreads) k_power_scan(const ScanParams p)
 //  * with the lane index in the top bits of j the bit-reversed LDS address has the
 //    lane in its LOW bits: phase B's scattered stores are bank-conflict free (they were
 //    32-way conflicted with the natural mapping).
-template <int E>
+//
+// COMB (E = 14, frames of 2^(14 + c) points): after the bit reversal over all 14 + c bits, block rev_c(b) of a frame
+// holds the points j = k << c | b (the comb b of the frame) in the bit-reversed order of k - exactly what this
+// kernel's phase B builds in LDS for a read of 16384 points -, and stages 0 .. 13 stay inside the block.  So a
+// "read" is one comb (its bytes contiguous: k_power_comb_bytes has gathered them, the window likewise), the averages
+// come from k_power_dc_part / _fin (remove_dc runs over the whole frame), and the final pass stores the block into
+// the work buffer for the stages beyond 13 instead of accumulating |X|^2.
+template <int E, bool COMB = false>
 __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams p)
 {
+	static_assert(!COMB || E == 14, "a comb is one 16384-point block");
 	constexpr int N = 1 << E;
 	constexpr int P = N / kThreads;  // points per thread: 8 or 16
 	constexpr int V = P / 8;         // uint4 loads per thread
@@ -343,9 +355,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 	uint32_t *tw = sm + skewed_size(N);       // [N]
 	__shared__ int red[2][kThreads / 64];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const size_t s = blockIdx.x / p.groups;
-	const int grp = (int)(blockIdx.x % p.groups);
-	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
+	// COMB: the "reads" are this workgroup's share of all blocks, in order (the combs of a frame follow each other)
+	const size_t s = COMB ? 0 : blockIdx.x / p.groups;
+	const int grp = COMB ? 0 : (int)(blockIdx.x % p.groups);
+	using idx_t = std::conditional_t<COMB, long long, int>;  // (the accumulating kernel has no register to spare for 64-bit counters)
+	const idx_t r_begin = COMB ? (idx_t)((unsigned long long)blockIdx.x * p.comb_blocks / gridDim.x)
+	                           : (idx_t)((long long)grp * p.nreads / p.groups);
+	const idx_t r_end = COMB ? (idx_t)((unsigned long long)(blockIdx.x + 1) * p.comb_blocks / gridDim.x)
+	                         : (idx_t)((long long)(grp + 1) * p.nreads / p.groups);
 	if (r_begin >= r_end) return;
 	unsigned long long st_clk = 0, st_rt = 0;
 	if (p.stamps) { st_clk = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
@@ -358,15 +375,16 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 	const int j0 = (lane_r << (E - 6)) | (wave << (E - 10));
 	// the window coefficients as 16-bit halves (only the low 16 bits of a product survive the reference's
 	// int16 stores), two to a register
-	const uint4 *wp = reinterpret_cast<const uint4 *>(p.window16 + j0);
+	const uint4 *wp = reinterpret_cast<const uint4 *>(p.window16 + j0 + (COMB ? (size_t)(r_begin & ((1 << p.comb_c) - 1)) << E : 0));
 	const int scatter0 = skew((int)(__brev((unsigned)j0) >> (32 - E)));
-	long long acc[16];
+	long long acc[COMB ? 1 : 16];
 #pragma unroll
-	for (int k = 0; k < 16; k++) acc[k] = 0;
-	const uint8_t *base = p.iq8 + s * p.stride8 + 2 * (size_t)j0;
+	for (int k = 0; k < (COMB ? 1 : 16); k++) acc[k] = 0;
+	const uint8_t *base = p.iq8 + (COMB ? 0 : s * p.stride8) + 2 * (size_t)j0;
+	const size_t read_bytes = COMB ? (size_t)2 * N : (size_t)p.buf_len;
 	uint4 cur[V], nxt[V];
 #pragma unroll
-	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base + (size_t)r_begin * p.buf_len)[v];
+	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base + (size_t)r_begin * read_bytes)[v];
 
 	// ---- A: remove_dc sums (all 2N elements are below len_dec here), one read AHEAD ----------------------
 	// at most N * 128 = 2^21 in magnitude: 32-bit sums, one v_dot4 per dword and component, the wave's total
@@ -411,12 +429,16 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 		for (int k = 0; k < P / 8; k++) { const uint4 v = wq[k]; w2[4 * k] = v.x; w2[4 * k + 1] = v.y; w2[4 * k + 2] = v.z; w2[4 * k + 3] = v.w; }
 	};
 	load_window();
-	int ai, aq;
-	dc_partial(cur);
+	int ai = 0, aq = 0;
+	if (!COMB) dc_partial(cur);
 	__syncthreads();  // also: the twiddle table is in place
-	dc_average(ai, aq);
+	if (!COMB) dc_average(ai, aq);
 
-	for (int r = r_begin; r < r_end; r++) {
+	for (idx_t r = r_begin; r < r_end; r++) {
+		if (COMB) {
+			const int2 a = p.ave[r >> p.comb_c];  // remove_dc's averages of the comb's frame
+			ai = a.x; aq = a.y;
+		}
 		// ---- B: convert, DC, window, bit-reversed placement (conflict-free) ---------
 		// on packed pairs: v_perm lifts (I, Q) out of the dword as two zero-extended 16-bit halves, one
 		// v_pk_sub takes 127 + average off both, one v_pk_mul_lo_u16 applies the window coefficient (only
@@ -439,7 +461,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 		const bool more = r + 1 < r_end;
 		if (more) {
 #pragma unroll
-			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
+			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * read_bytes)[v];
 		}
 		__syncthreads();
 		// ---- C: E = 13: four radix-8 passes and a radix-2 one; E = 14: four and a radix-4 one ----------
@@ -451,7 +473,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 			fft_group<3, 3>(pts, tw, 3, g); wave_sync();
 			fft_group<3, 6>(pts, tw, 6, g);
 		}
-		if (more) dc_partial(nxt);
+		if (more && !COMB) dc_partial(nxt);
 		__syncthreads();
 		fft_pass<3, 9>(pts, tw, N, 9, t);
 		__syncthreads();
@@ -459,9 +481,19 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 		// g + 4096 k - the thread's own accumulators a = it + 4 k: |X|^2 goes from the butterfly's registers
 		// into them, the spectrum is never written back to LDS.  One |X|^2 is at most 2^31: the peak-hold
 		// maximum lives in 32 bits, the sum takes one 64-bit add.
-		if (more) load_window();
+		if (more) {
+			if (COMB) wp = reinterpret_cast<const uint4 *>(p.window16 + j0 + ((size_t)((r + 1) & ((1 << p.comb_c) - 1)) << E));
+			load_window();
+		}
 		{
 			constexpr int R = E - 12, G = 1 << R;
+			// COMB: comb b of frame f is block rev_c(b) of the frame
+			uint32_t *sink = nullptr;
+			if (COMB) {
+				const unsigned b = (unsigned)(r & ((1 << p.comb_c) - 1));
+				const unsigned br = p.comb_c ? __brev(b) >> (32 - p.comb_c) : 0u;
+				sink = p.work + ((size_t)(r >> p.comb_c) << (E + p.comb_c)) + ((size_t)br << E);
+			}
 			// the LDS addresses of the four rounds are loop-invariant; hoisted out of the read loop they are
 			// spilled and reloaded - two integer operations each, recomputed here, are cheaper
 			int tl = t;
@@ -471,31 +503,39 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 				uint32_t x[G];
 				if (it) __builtin_amdgcn_sched_barrier(0);  // one round's operands at a time: all four at once spill
 				fft_group_regs<R, 12>(pts, tw, tl + it * kThreads, x);
+				if constexpr (COMB) {
+					// group g of the final pass holds the block's points g + 4096 k
 #pragma unroll
-				for (int k = 0; k < G; k++) {
-					const int a = it + 4 * k;
-					if (p.peak_hold) {
-						const uint32_t pw = (uint32_t)power_of(x[k]);
-						const uint32_t m = (uint32_t)acc[a];
-						acc[a] = (long long)(pw > m ? pw : m);
-					} else {
-						acc[a] += power_of(x[k]);
+					for (int k = 0; k < G; k++) sink[tl + it * kThreads + (k << 12)] = x[k];
+				} else {
+#pragma unroll
+					for (int k = 0; k < G; k++) {
+						const int a = it + 4 * k;
+						if (p.peak_hold) {
+							const uint32_t pw = (uint32_t)power_of(x[k]);
+							const uint32_t m = (uint32_t)acc[a];
+							acc[a] = (long long)(pw > m ? pw : m);
+						} else {
+							acc[a] += power_of(x[k]);
+						}
 					}
 				}
 			}
 		}
-		if (more) dc_average(ai, aq);  // red[] was written before the barrier behind stage 8
+		if (more && !COMB) dc_average(ai, aq);  // red[] was written before the barrier behind stage 8
 		__syncthreads();               // the final pass is done reading pts: the next read may be placed
 #pragma unroll
 		for (int v = 0; v < V; v++) cur[v] = nxt[v];
 	}
+	if constexpr (!COMB) {
 #pragma unroll
-	for (int a = 0; a < P; a++) {
-		const int bin = t + kThreads * a;
-		if (p.peak_hold) atomicMax(p.avg + s * N + bin, acc[a]);
-		else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + bin), (unsigned long long)acc[a]);
+		for (int a = 0; a < P; a++) {
+			const int bin = t + kThreads * a;
+			if (p.peak_hold) atomicMax(p.avg + s * N + bin, acc[a]);
+			else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + bin), (unsigned long long)acc[a]);
+		}
+		if (t == 0) atomicAdd(p.samples + s, p.ds * (int)(r_end - r_begin));
 	}
-	if (t == 0) atomicAdd(p.samples + s, p.ds * (r_end - r_begin));
 	if (p.stamps && t == 0) {
 		unsigned long long *o = p.stamps + (size_t)blockIdx.x * 4;
 		o[0] = st_clk; o[1] = __builtin_amdgcn_s_memtime(); o[2] = st_rt; o[3] = __builtin_amdgcn_s_memrealtime();
@@ -704,6 +744,147 @@ __global__ void __launch_bounds__(256) k_power_accum(const StagedParams p)
 			}
 		p.avg[g] = a;
 		if (bin == 0) p.samples[s] += p.ds * p.chunks * p.nreads;  // :717, once per frame
+	}
+}
+
+// ---- the same path for undecimated reads of exactly one frame (rtl_power's fine-bin scans), round 4 ----
+// k_power_dc_part / _fin: the averages with 16-byte loads, a read cut into 64 KiB slices (one workgroup per
+// (stream, read) left 2^21-point reads to 256 threads each); k_power_comb_bytes: the frame's BYTES comb by comb, so
+// that k_power_scan_big<14, true> takes a comb as it takes a 16384-point read; k_power_fft_gl_acc: the last pass over
+// HBM accumulates |X|^2 from its registers - the spectrum is never written, k_power_accum never reads it.
+constexpr int kDcSlice = 65536;  // bytes
+__global__ void __launch_bounds__(256) k_power_dc_part(const uint8_t *iq8, size_t stride8, int nreads, int buf_len, int2 *part)
+{
+	const int slices = buf_len / kDcSlice;
+	const size_t sr = blockIdx.x / slices;
+	const int sl = (int)(blockIdx.x % slices);
+	const size_t s = sr / nreads;
+	const int r = (int)(sr % nreads);
+	const uint4 *src = reinterpret_cast<const uint4 *>(iq8 + s * stride8 + (size_t)r * buf_len + (size_t)sl * kDcSlice);
+	int si = -127 * (kDcSlice / 2 / 256), sq = si;
+	uint4 d[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++) d[i] = src[i * 256 + threadIdx.x];
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		const uint32_t w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			si = (int)__builtin_amdgcn_udot4(w[q], 0x00010001u, (uint32_t)si, false);
+			sq = (int)__builtin_amdgcn_udot4(w[q], 0x01000100u, (uint32_t)sq, false);
+		}
+	}
+	si = wave_total(si);
+	sq = wave_total(sq);
+	__shared__ int red[2][4];
+	if ((threadIdx.x & 63) == 63) { red[0][threadIdx.x >> 6] = si; red[1][threadIdx.x >> 6] = sq; }
+	__syncthreads();
+	if (threadIdx.x == 0) part[blockIdx.x] = make_int2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+}
+__global__ void __launch_bounds__(64) k_power_dc_fin(const int2 *part, int slices, int len_dec, size_t nsr, int2 *ave)
+{
+	const size_t sr = (size_t)blockIdx.x * 64 + threadIdx.x;
+	if (sr >= nsr) return;
+	long long si = 0, sq = 0;
+	for (int k = 0; k < slices; k++) { const int2 v = part[sr * slices + k]; si += v.x; sq += v.y; }
+	// as k_power_dc: the sum over N/2 values divided by N (and N - 1)
+	ave[sr] = make_int2((int)(int16_t)(si / (long long)len_dec), (int)(int16_t)(sq / (long long)(len_dec - 1)));
+}
+
+// out[frame][b][k] = in[frame][k << c | b] (2-byte points): tiles of 8192 consecutive points, K = 8192 >> c values of k
+// for every comb; 16-byte loads, 16-byte stores in runs of K points (c <= 7: at least 128 bytes)
+__global__ void __launch_bounds__(256) k_power_comb_bytes(const uint8_t *iq8, size_t stride8, int nreads, int buf_len, int bin_e,
+                                                          size_t tiles_total, uint8_t *out)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t tile[8192];
+	const int c = bin_e - 14, C = 1 << c, kshift = 13 - c, K = 1 << kshift;
+	const int tpf = 1 << (bin_e - 13);  // tiles per frame
+	const int t = threadIdx.x;
+	for (size_t g = blockIdx.x; g < tiles_total; g += gridDim.x) {
+		const size_t sr = g >> (bin_e - 13);
+		const int T = (int)(g & (size_t)(tpf - 1));
+		const size_t s = sr / nreads;
+		const int r = (int)(sr % nreads);
+		const uint4 *src = reinterpret_cast<const uint4 *>(iq8 + s * stride8 + (size_t)r * buf_len + (size_t)T * 16384);
+		uint4 d[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) d[i] = src[i * 256 + t];
+		__syncthreads();  // the previous tile has been read out
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int q0 = (i * 256 + t) * 8;
+			const uint32_t w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+			for (int e = 0; e < 8; e++) {
+				const int q = q0 + e;
+				tile[((q & (C - 1)) << kshift) | (q >> c)] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+			}
+		}
+		__syncthreads();
+		uint8_t *dst = out + (sr << (bin_e + 1)) + (size_t)T * K * 2;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int u = (i * 256 + t) * 8;  // first of eight points of one comb
+			const int b = u >> kshift, kl = u & (K - 1);
+			*reinterpret_cast<uint4 *>(dst + ((size_t)b << 15) + (size_t)kl * 2) = *reinterpret_cast<const uint4 *>(tile + u);
+		}
+	}
+}
+
+// stages st .. st + R - 1 = the LAST ones (st + R == bin_e), and phase D with them: one thread per (stream, group of
+// 2^R points at stride 2^st) walks the batch's frames of its stream in order (the next frame's points in flight), the
+// group's twiddles stay in registers, |X|^2 goes from the butterflies' registers into the thread's own accumulators
+// (one owner per bin: no atomics).  src/rtl_power.c:309-321, 708-717
+template <int R>
+__global__ void __launch_bounds__(256) k_power_fft_gl_acc(const StagedParams p, int st)
+{
+	constexpr int G = 1 << R;
+	const int E = p.bin_e;
+	const size_t per_frame = (size_t)1 << (E - R);
+	const size_t total = (size_t)p.nstreams * per_frame;
+	const int h = 1 << st;
+	const size_t nfr = (size_t)p.nreads * p.chunks;
+	for (size_t g0 = (size_t)blockIdx.x * 256 + threadIdx.x; g0 < total; g0 += (size_t)gridDim.x * 256) {
+		const size_t s = g0 >> (E - R);
+		const int g = (int)(g0 & (per_frame - 1));
+		const int glo = g & (h - 1), ghi = g >> st;
+		const size_t pos = ((size_t)ghi << (st + R)) | (size_t)glo;
+		uint32_t w[G];  // w[(1 << r) - 1 + kk]
+#pragma unroll
+		for (int r = 0; r < R; r++)
+#pragma unroll
+			for (int kk = 0; kk < (1 << r); kk++) w[(1 << r) - 1 + kk] = p.tw[(((size_t)1 << (st + r)) - 1) + glo + (size_t)kk * h];
+		long long *av = p.avg + (s << E) + pos;
+		long long acc[G];
+#pragma unroll
+		for (int k = 0; k < G; k++) acc[k] = av[(size_t)k << st];
+		const uint32_t *base = p.work + ((s * nfr) << E) + pos;
+		uint32_t x[G], nx[G];
+#pragma unroll
+		for (int k = 0; k < G; k++) x[k] = base[(size_t)k << st];
+		for (size_t f = 0; f < nfr; f++) {
+			if (f + 1 < nfr) {
+#pragma unroll
+				for (int k = 0; k < G; k++) nx[k] = base[((f + 1) << E) + ((size_t)k << st)];
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+#pragma unroll
+				for (int k = 0; k < G; k++) {
+					if (k & (1 << r)) continue;
+					butterfly<0>(x[k], x[k + (1 << r)], w[(1 << r) - 1 + (k & ((1 << r) - 1))]);
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < G; k++) {
+				const long long pw = power_of(x[k]);
+				acc[k] = p.peak_hold ? (pw > acc[k] ? pw : acc[k]) : acc[k] + pw;
+				x[k] = nx[k];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < G; k++) av[(size_t)k << st] = acc[k];
+		if (g == 0) p.samples[s] += p.ds * p.chunks * p.nreads;  // :717, once per frame
 	}
 }
 

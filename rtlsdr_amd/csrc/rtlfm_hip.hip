@@ -1097,7 +1097,7 @@ static int read_clock_stamps(rtlfm_gpu *h, double *mhz, double *span_ms, int *wa
 	HIP_TRY(sync_all(h));
 	if (!h->fws.stamps || h->fws.stamp_last <= 0) return -ENODATA;
 	std::vector<unsigned long long> st((size_t)h->fws.stamp_last * 4);
-	HIP_TRY(hipMemcpy(st.data(), h->fws.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(st.data(), h->fws.stamp_half(0), st.size() * 8, hipMemcpyDeviceToHost));
 	double sum = 0; int n = 0; unsigned long long t0 = ~0ull, t1 = 0;
 	for (int w = 0; w < h->fws.stamp_last; w++) {
 		double dc = (double)(st[w * 4 + 1] - st[w * 4]), dr = (double)(st[w * 4 + 3] - st[w * 4 + 2]);
@@ -2266,7 +2266,9 @@ extern "C" int rtlfm_gpu_clock_stamps(rtlfm_gpu *h, uint64_t *out, int cap_waves
 	*waves = h->fws.stamp_last;
 	if (!out) return 0;
 	if (cap_waves < h->fws.stamp_last) return -ENOBUFS;
-	HIP_TRY(hipMemcpy(out, h->fws.stamps, (size_t)h->fws.stamp_last * 32, hipMemcpyDeviceToHost));
+	// fused_debug bit 64: the launch BEFORE the last one (the two alternate between the halves of the buffer), so that
+	// a tool can see the gap between two launches that followed each other (tools/launch_gap.py)
+	HIP_TRY(hipMemcpy(out, h->fws.stamp_half((h->fws.debug & 64) ? 1 : 0), (size_t)h->fws.stamp_last * 32, hipMemcpyDeviceToHost));
 	return 0;
 }
 

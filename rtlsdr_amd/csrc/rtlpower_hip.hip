@@ -45,6 +45,9 @@ struct rtlpower_gpu {
 	int groups = 0;  // option "groups": workgroups per stream of the FFT kernel (0 = automatic)
 	bool staged = false;                   // bin_e 15 .. 21 or more points per read than a workgroup's LDS holds: transform in HBM
 	uint32_t *d_work = nullptr; int2 *d_ave = nullptr;
+	// one undecimated frame per read, bin_e > 14: the window comb by comb, the batch's bytes likewise, the averages' partial sums
+	uint16_t *d_window16T = nullptr; uint8_t *d_tbuf = nullptr; int2 *d_part = nullptr; bool attr_comb = false;
+	int staged_fast = 1;  // option "staged_fast": 0 = the general kernels also where the fast ones apply (A/B, tests)
 	size_t work_reads = 0;                 // reads the work buffer holds per stream
 	bool attr_lds = false;
 	bool want_stamps = false;              // rtlpower_gpu_clock_probe
@@ -283,6 +286,14 @@ static int power_create_body(rtlpower_gpu *h)
 		for (size_t i = 0; i < w.size(); i++) w16[i] = (uint16_t)(uint32_t)w[i];
 		HIP_TRY(hipMalloc(&h->d_window16, w16.size() * sizeof(uint16_t)));
 		HIP_TRY(hipMemcpy(h->d_window16, w16.data(), w16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+		if (cfg->bin_e > 14) {
+			// comb b of the frame = the points k << c | b: k_power_scan_big<14, true> reads its coefficients as it reads a read's
+			const int cc = cfg->bin_e - 14;
+			std::vector<uint16_t> wt(w16.size());
+			for (size_t j = 0; j < w16.size(); j++) wt[((j & (((size_t)1 << cc) - 1)) << 14) | (j >> cc)] = w16[j];
+			HIP_TRY(hipMalloc(&h->d_window16T, wt.size() * sizeof(uint16_t)));
+			HIP_TRY(hipMemcpy(h->d_window16T, wt.data(), wt.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+		}
 		// sine_table(), src/rtl_power.c:247-261, regrouped per FFT stage: stage s uses
 		// wr = Sinewave[j + N/4] >> 1, wi = -Sinewave[j] >> 1 at j = m << (log2N - 1 - s)
 		// for m < 2^s (:303-308); entry (1 << s) - 1 + m holds them DOUBLED and packed, (2 wr, 2 wi) - the
@@ -316,7 +327,7 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 		if (e) (void)hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one, h->d_stamps, h->d_work, h->d_ave};
+	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one, h->d_stamps, h->d_work, h->d_ave, h->d_window16T, h->d_tbuf, h->d_part};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -378,6 +389,10 @@ extern "C" int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long v
 	if (!strcmp(name, "groups")) {
 		if (value < 0) return -EINVAL;
 		h->groups = (int)value;
+		return 0;
+	}
+	if (!strcmp(name, "staged_fast")) {
+		h->staged_fast = value != 0;
 		return 0;
 	}
 	return -ENOENT;
@@ -505,10 +520,23 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		if (h->work_reads < batch) {
 			HIP_TRY(hipStreamSynchronize(q));
 			if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_ave); h->d_work = nullptr; h->d_ave = nullptr; }
+			if (h->d_tbuf) { (void)hipFree(h->d_tbuf); (void)hipFree(h->d_part); h->d_tbuf = nullptr; h->d_part = nullptr; }
 			h->work_reads = 0;
 			HIP_TRY(hipMalloc(&h->d_work, (size_t)S * batch * M * sizeof(uint32_t)));
 			HIP_TRY(hipMalloc(&h->d_ave, (size_t)S * batch * sizeof(int2)));
+			if (c.bin_e > 14 && !dec && h->chunks == 1) {
+				HIP_TRY(hipMalloc(&h->d_tbuf, (size_t)S * batch * M * 2));
+				HIP_TRY(hipMalloc(&h->d_part, (size_t)S * batch * (c.buf_len / kDcSlice + 1) * sizeof(int2)));
+			}
 			h->work_reads = batch;
+		}
+		// rtl_power's own fine-bin shape - an undecimated read is exactly one frame - takes the kernels written for it
+		const bool fast = h->staged_fast && h->d_tbuf && c.bin_e > 14 && !dec && h->chunks == 1 && h->len_dec == 2 * h->N &&
+		                  c.buf_len == (uint32_t)(2 * h->N) && !(stream_stride & 15) && !((uintptr_t)d_iq & 15);
+		if (fast && !h->attr_comb) {
+			HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_big<14, true>),
+			                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+			h->attr_comb = true;
 		}
 		const int eb = c.bin_e < 14 ? c.bin_e : 14;
 		const size_t lds = ((size_t)skewed_size(1 << eb) + ((size_t)1 << eb)) * 4;
@@ -532,20 +560,41 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 			sp.ds = c.downsample; sp.peak_hold = c.peak_hold; sp.window = h->d_window; sp.tw = h->d_tw;
 			sp.ave = h->d_ave; sp.work = h->d_work; sp.avg = h->d_avg; sp.samples = h->d_samples; sp.nstreams = S;
 			const size_t frames = (size_t)S * nb * h->chunks;
-			k_power_dc<<<(unsigned)((size_t)S * nb), 256, 0, q>>>(sp);
-			if (c.bin_e >= 12) k_power_place_tiled<<<grid_for(frames << (c.bin_e - 12), 1, 256 * 64), 256, 0, q>>>(sp);
-			else k_power_place<<<grid_for((size_t)S * nb * M, 256, 256 * 64), 256, 0, q>>>(sp);
-			const size_t nblk = frames << (c.bin_e - eb);
-			hipLaunchKernelGGL(k_power_fft_lds, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(kThreads), lds, q, h->d_work, h->d_tw, eb, nblk);
+			if (fast) {
+				const int slices = (int)(c.buf_len / kDcSlice);
+				const uint8_t *src = d_iq + (size_t)r0 * c.buf_len;
+				k_power_dc_part<<<(unsigned)(frames * slices), 256, 0, q>>>(src, stream_stride, nb, (int)c.buf_len, h->d_part);
+				k_power_dc_fin<<<grid_for(frames, 64), 64, 0, q>>>(h->d_part, slices, h->len_dec, frames, h->d_ave);
+				const size_t tiles = frames << (c.bin_e - 13);
+				k_power_comb_bytes<<<grid_for(tiles, 1, 256 * 32), 256, 0, q>>>(src, stream_stride, nb, (int)c.buf_len, c.bin_e, tiles, h->d_tbuf);
+				ScanParams cp{};
+				cp.iq8 = h->d_tbuf; cp.window16 = h->d_window16T; cp.tw = h->d_tw; cp.ave = h->d_ave; cp.work = h->d_work;
+				cp.comb_c = c.bin_e - 14; cp.comb_blocks = frames << cp.comb_c;
+				const size_t lds_big = ((size_t)skewed_size(16384) + 16384) * 4;
+				const unsigned wgs = (unsigned)(cp.comb_blocks < 256 ? cp.comb_blocks : 256);
+				hipLaunchKernelGGL((k_power_scan_big<14, true>), dim3(wgs), dim3(kThreads), lds_big, q, cp);
+			} else {
+				k_power_dc<<<(unsigned)((size_t)S * nb), 256, 0, q>>>(sp);
+				if (c.bin_e >= 12) k_power_place_tiled<<<grid_for(frames << (c.bin_e - 12), 1, 256 * 64), 256, 0, q>>>(sp);
+				else k_power_place<<<grid_for((size_t)S * nb * M, 256, 256 * 64), 256, 0, q>>>(sp);
+				const size_t nblk = frames << (c.bin_e - eb);
+				hipLaunchKernelGGL(k_power_fft_lds, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(kThreads), lds, q, h->d_work, h->d_tw, eb, nblk);
+			}
+			// stages 14 .. bin_e - 1 over HBM, three per pass; the last pass accumulates (k_power_fft_gl_acc)
 			for (int st = 14; st < c.bin_e;) {
 				const int R = c.bin_e - st >= 3 ? 3 : c.bin_e - st;
-				const int g = grid_for(frames << (c.bin_e - R), 256, 256 * 64);
-				if (R == 3) k_power_fft_gl<3><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
-				else if (R == 2) k_power_fft_gl<2><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
-				else k_power_fft_gl<1><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
+				if (st + R == c.bin_e) {
+					const int g = grid_for((size_t)S << (c.bin_e - R), 256, 256 * 64);
+					if (R == 3) k_power_fft_gl_acc<3><<<g, 256, 0, q>>>(sp, st);
+					else if (R == 2) k_power_fft_gl_acc<2><<<g, 256, 0, q>>>(sp, st);
+					else k_power_fft_gl_acc<1><<<g, 256, 0, q>>>(sp, st);
+				} else {
+					const int g = grid_for(frames << (c.bin_e - R), 256, 256 * 64);
+					k_power_fft_gl<3><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
+				}
 				st += R;
 			}
-			k_power_accum<<<grid_for((size_t)S * h->N, 256, 256 * 64), 256, 0, q>>>(sp);
+			if (c.bin_e <= 14) k_power_accum<<<grid_for((size_t)S * h->N, 256, 256 * 64), 256, 0, q>>>(sp);
 		}
 		HIP_TRY(hipGetLastError());
 		if (h->timing) {
@@ -630,11 +679,13 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	view.d_samples = h->d_samples + stream;
 	view.d_decA = view.d_decB = nullptr; view.dec_cap_reads = 0;
 	view.d_work = nullptr; view.d_ave = nullptr; view.work_reads = 0;
+	view.d_tbuf = nullptr; view.d_part = nullptr;
 	view.ev_pending.clear(); view.ev_free.clear(); view.timing = false;
 	int r = rtlpower_gpu_scan_device(&view, h->d_one, h->cfg.buf_len, 1);
 	const hipError_t e = hipStreamSynchronize(h->stream);
 	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }  // also when the sync failed
 	if (view.d_work) { (void)hipFree(view.d_work); (void)hipFree(view.d_ave); }
+	if (view.d_tbuf) { (void)hipFree(view.d_tbuf); (void)hipFree(view.d_part); }
 	if (e != hipSuccess) return -EIO;
 	return r;
 }

@@ -13,11 +13,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def gpu_scan(cfg, iq2d, split=None):
+def gpu_scan(cfg, iq2d, split=None, options=None):
     from rtlsdr_amd.power import GpuPower
     ns = iq2d.shape[0]
     L = int(cfg.buf_len)
     with GpuPower(cfg, ns, 0) as g:
+        for k, v in (options or {}).items():
+            g.set_option(k, v)
         d = torch.from_numpy(np.ascontiguousarray(iq2d)).cuda()
         if split:
             nr = iq2d.shape[1] // L
@@ -153,11 +155,40 @@ def test_power_fine_bins_random(oracle_lib, seed):
     iq = np.concatenate([synth.fm_iq_u8(ns, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=300 + seed),
                          synth.random_u8(1, L * nr, seed=400 + seed)])
     want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=3)
-    for split in (None, 1):
-        res = gpu_scan(cfg, iq, split=split)
+    # staged_fast = 0: the general kernels also where the ones written for "one undecimated frame per read" apply
+    for split, fast in ((None, 1), (1, 1), (None, 0)):
+        res = gpu_scan(cfg, iq, split=split, options=dict(staged_fast=fast))
         for s in range(ns + 1):
-            assert res[s][1] == wn[s], (kw, s, split)
-            assert np.array_equal(res[s][0], want[s]), (kw, s, split)
+            assert res[s][1] == wn[s], (kw, s, split, fast)
+            assert np.array_equal(res[s][0], want[s]), (kw, s, split, fast)
+
+
+@pytest.mark.parametrize("bin_e", [15, 16, 17, 18, 19, 20, 21])
+def test_power_one_frame_per_read_every_size(oracle_lib, bin_e):
+    """rtl_power's own fine-bin shape (an undecimated read = one frame of 2^bin_e points, src/rtl_power.c:483-501) on the
+    kernels written for it - averages in slices, the bytes comb by comb, k_power_scan_big<14, true>, the last pass over
+    HBM accumulating - and on the general ones, against the oracle; a stream stride that is not a multiple of 16 bytes
+    takes the general kernels by itself."""
+    cfg = RtlpowerCfg.default(bin_e=bin_e, window=int(bin_e % 7) + 1, buf_len=2 << bin_e, peak_hold=int(bin_e == 16))
+    L, nr, ns = int(cfg.buf_len), 3, 2
+    iq = np.concatenate([synth.fm_iq_u8(1, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=700 + bin_e),
+                         synth.random_u8(1, L * nr, seed=800 + bin_e)])
+    want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=2)
+    for fast in (1, 0):
+        res = gpu_scan(cfg, iq, split=1 if fast else None, options=dict(staged_fast=fast))
+        for s in range(ns):
+            assert res[s][1] == wn[s], (bin_e, s, fast)
+            assert np.array_equal(res[s][0], want[s]), (bin_e, s, fast)
+    if bin_e <= 17:
+        from rtlsdr_amd.power import GpuPower
+        wide = torch.zeros((ns, L * nr + 8), dtype=torch.uint8, device="cuda")
+        wide[:, :L * nr] = torch.from_numpy(iq).cuda()
+        with GpuPower(cfg, ns, 0) as g:
+            g.scan_device(wide.data_ptr(), wide.stride(0), nr)
+            g.sync()
+            for s in range(ns):
+                avg, n = g.fetch(s)
+                assert n == wn[s] and np.array_equal(avg, want[s]), (bin_e, s, "stride")
 
 
 def test_power_clock_probe():

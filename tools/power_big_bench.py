@@ -15,7 +15,10 @@ from rtlsdr_amd.power import GpuPower  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     total = 1 << 30  # bytes per launch
-    for bin_e, streams in ((14, 1024), (15, 512), (17, 128), (19, 32), (21, 8), (17, 1), (21, 1)):
+    shapes = ((14, 1024), (15, 512), (17, 128), (19, 32), (20, 16), (21, 8), (17, 1), (21, 1))
+    if len(sys.argv) > 1:  # only these bin sizes (for a short rocprofv3 --kernel-trace --stats run)
+        shapes = tuple(x for x in shapes if str(x[0]) in sys.argv[1:] and x[1] > 1)
+    for bin_e, streams in shapes:
         L = 2 << bin_e
         nreads = max(1, total // (streams * L)) if streams > 1 else 16
         cfg = RtlpowerCfg.default(bin_e=bin_e, window=1, buf_len=L)
