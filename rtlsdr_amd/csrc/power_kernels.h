@@ -748,39 +748,11 @@ __global__ void __launch_bounds__(256) k_power_accum(const StagedParams p)
 }
 
 // ---- the same path for undecimated reads of exactly one frame (rtl_power's fine-bin scans), round 4 ----
-// k_power_dc_part / _fin: the averages with 16-byte loads, a read cut into 64 KiB slices (one workgroup per
-// (stream, read) left 2^21-point reads to 256 threads each); k_power_comb_bytes: the frame's BYTES comb by comb, so
-// that k_power_scan_big<14, true> takes a comb as it takes a 16384-point read; k_power_fft_gl_acc: the last pass over
-// HBM accumulates |X|^2 from its registers - the spectrum is never written, k_power_accum never reads it.
-constexpr int kDcSlice = 65536;  // bytes
-__global__ void __launch_bounds__(256) k_power_dc_part(const uint8_t *iq8, size_t stride8, int nreads, int buf_len, int2 *part)
-{
-	const int slices = buf_len / kDcSlice;
-	const size_t sr = blockIdx.x / slices;
-	const int sl = (int)(blockIdx.x % slices);
-	const size_t s = sr / nreads;
-	const int r = (int)(sr % nreads);
-	const uint4 *src = reinterpret_cast<const uint4 *>(iq8 + s * stride8 + (size_t)r * buf_len + (size_t)sl * kDcSlice);
-	int si = -127 * (kDcSlice / 2 / 256), sq = si;
-	uint4 d[16];
-#pragma unroll
-	for (int i = 0; i < 16; i++) d[i] = src[i * 256 + threadIdx.x];
-#pragma unroll
-	for (int i = 0; i < 16; i++) {
-		const uint32_t w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			si = (int)__builtin_amdgcn_udot4(w[q], 0x00010001u, (uint32_t)si, false);
-			sq = (int)__builtin_amdgcn_udot4(w[q], 0x01000100u, (uint32_t)sq, false);
-		}
-	}
-	si = wave_total(si);
-	sq = wave_total(sq);
-	__shared__ int red[2][4];
-	if ((threadIdx.x & 63) == 63) { red[0][threadIdx.x >> 6] = si; red[1][threadIdx.x >> 6] = sq; }
-	__syncthreads();
-	if (threadIdx.x == 0) part[blockIdx.x] = make_int2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-}
+// k_power_comb_bytes: the frame's BYTES comb by comb, so that k_power_scan_big<14, true> takes a comb as it takes a
+// 16384-point read - and, from the same registers, the sums of its 16 KiB tile for remove_dc (k_power_dc_fin adds a
+// frame's tiles up; one workgroup per (stream, read) left 2^21-point reads to 256 threads each); k_power_fft_gl_acc:
+// the last pass over HBM accumulates |X|^2 from its registers - the spectrum is never written, k_power_accum never
+// reads it.
 __global__ void __launch_bounds__(64) k_power_dc_fin(const int2 *part, int slices, int len_dec, size_t nsr, int2 *ave)
 {
 	const size_t sr = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -794,9 +766,10 @@ __global__ void __launch_bounds__(64) k_power_dc_fin(const int2 *part, int slice
 // out[frame][b][k] = in[frame][k << c | b] (2-byte points): tiles of 8192 consecutive points, K = 8192 >> c values of k
 // for every comb; 16-byte loads, 16-byte stores in runs of K points (c <= 7: at least 128 bytes)
 __global__ void __launch_bounds__(256) k_power_comb_bytes(const uint8_t *iq8, size_t stride8, int nreads, int buf_len, int bin_e,
-                                                          size_t tiles_total, uint8_t *out)
+                                                          size_t tiles_total, uint8_t *out, int2 *part)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t tile[8192];
+	__shared__ int red[2][4];
 	const int c = bin_e - 14, C = 1 << c, kshift = 13 - c, K = 1 << kshift;
 	const int tpf = 1 << (bin_e - 13);  // tiles per frame
 	const int t = threadIdx.x;
@@ -809,7 +782,21 @@ __global__ void __launch_bounds__(256) k_power_comb_bytes(const uint8_t *iq8, si
 		uint4 d[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++) d[i] = src[i * 256 + t];
+		// remove_dc's sums of this tile (src/rtl_power.c:581-596): at most 8192 * 128 in magnitude
+		int si = -127 * 32, sq = si;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const uint32_t w[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				si = (int)__builtin_amdgcn_udot4(w[q], 0x00010001u, (uint32_t)si, false);
+				sq = (int)__builtin_amdgcn_udot4(w[q], 0x01000100u, (uint32_t)sq, false);
+			}
+		}
+		si = wave_total(si);
+		sq = wave_total(sq);
 		__syncthreads();  // the previous tile has been read out
+		if ((t & 63) == 63) { red[0][t >> 6] = si; red[1][t >> 6] = sq; }
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 			const int q0 = (i * 256 + t) * 8;
@@ -821,6 +808,7 @@ __global__ void __launch_bounds__(256) k_power_comb_bytes(const uint8_t *iq8, si
 			}
 		}
 		__syncthreads();
+		if (t == 0) part[g] = make_int2(red[0][0] + red[0][1] + red[0][2] + red[0][3], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
 		uint8_t *dst = out + (sr << (bin_e + 1)) + (size_t)T * K * 2;
 #pragma unroll
 		for (int i = 0; i < 4; i++) {

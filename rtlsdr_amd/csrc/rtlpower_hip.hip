@@ -526,7 +526,7 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 			HIP_TRY(hipMalloc(&h->d_ave, (size_t)S * batch * sizeof(int2)));
 			if (c.bin_e > 14 && !dec && h->chunks == 1) {
 				HIP_TRY(hipMalloc(&h->d_tbuf, (size_t)S * batch * M * 2));
-				HIP_TRY(hipMalloc(&h->d_part, (size_t)S * batch * (c.buf_len / kDcSlice + 1) * sizeof(int2)));
+				HIP_TRY(hipMalloc(&h->d_part, (size_t)S * batch * (M / 8192) * sizeof(int2)));
 			}
 			h->work_reads = batch;
 		}
@@ -561,12 +561,10 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 			sp.ave = h->d_ave; sp.work = h->d_work; sp.avg = h->d_avg; sp.samples = h->d_samples; sp.nstreams = S;
 			const size_t frames = (size_t)S * nb * h->chunks;
 			if (fast) {
-				const int slices = (int)(c.buf_len / kDcSlice);
 				const uint8_t *src = d_iq + (size_t)r0 * c.buf_len;
-				k_power_dc_part<<<(unsigned)(frames * slices), 256, 0, q>>>(src, stream_stride, nb, (int)c.buf_len, h->d_part);
-				k_power_dc_fin<<<grid_for(frames, 64), 64, 0, q>>>(h->d_part, slices, h->len_dec, frames, h->d_ave);
 				const size_t tiles = frames << (c.bin_e - 13);
-				k_power_comb_bytes<<<grid_for(tiles, 1, 256 * 32), 256, 0, q>>>(src, stream_stride, nb, (int)c.buf_len, c.bin_e, tiles, h->d_tbuf);
+				k_power_comb_bytes<<<grid_for(tiles, 1, 256 * 32), 256, 0, q>>>(src, stream_stride, nb, (int)c.buf_len, c.bin_e, tiles, h->d_tbuf, h->d_part);
+				k_power_dc_fin<<<grid_for(frames, 64), 64, 0, q>>>(h->d_part, 1 << (c.bin_e - 13), h->len_dec, frames, h->d_ave);
 				ScanParams cp{};
 				cp.iq8 = h->d_tbuf; cp.window16 = h->d_window16T; cp.tw = h->d_tw; cp.ave = h->d_ave; cp.work = h->d_work;
 				cp.comb_c = c.bin_e - 14; cp.comb_blocks = frames << cp.comb_c;
