@@ -1246,7 +1246,12 @@ inline int ensure_dummy_tile(Workspace &ws)
 {
 	if (ws.dummy_tile) return 0;
 	if (hipMalloc(&ws.dummy_tile, kTileBytes) != hipSuccess) return -ENOMEM;
+	// hipMemset of device memory returns before the fill has run (it is a kernel on the null stream), and the handle's
+	// own stream is non-blocking: without the wait a first launch could read the tile before it is filled - the
+	// boxcar front end's partial last tile (-W n) then summed garbage behind the run's end into (now_r, now_j).
+	// Found by the extended sweep with four test processes sharing the GPU, where the fill was late often enough.
 	if (hipMemset(ws.dummy_tile, 0x7f, kTileBytes) != hipSuccess) return -EIO;
+	if (hipStreamSynchronize(nullptr) != hipSuccess) return -EIO;
 	return 0;
 }
 

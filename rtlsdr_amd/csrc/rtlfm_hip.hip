@@ -2196,7 +2196,7 @@ extern "C" int rtlfm_gpu_bw_probe(int device, size_t bytes, int write_div, int r
 		// input and the co-located output in ONE allocation: the same quarter by construction
 		if (hipMalloc(&d_in, total + wbytes) != hipSuccess) { rc = -ENOMEM; break; }
 		d_near = d_in + total;
-		if (hipMemset(d_in, 0x5a, total) != hipSuccess) { rc = -EIO; break; }
+		if (hipMemset(d_in, 0x5a, total) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { rc = -EIO; break; }
 		int apart = 0;
 		if ((rc = rtlfm_gpu_malloc_apart(device, wbytes, d_in, total, &d_far, &apart)) < 0) break;
 		float ms[3] = {0, 0, 0};

@@ -693,6 +693,37 @@ def test_random_configurations_vs_oracle(oracle_lib, seed):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_W", "24"))))
+def test_random_configurations_any_buffer_size(oracle_lib, seed):
+    """The same sweep with -W n buffers (any 512 n bytes, src/rtl_fm.c:1869-1873): the partial tiles of the fifth_order
+    front end (fused_kernel.h, PT), the continuous run of the boxcar one, the staged kernels and the tails behind them."""
+    from rtlsdr_amd.demod import GpuDemod
+    rng = np.random.default_rng(19000 + seed)
+    ov = _random_cfg(rng)
+    L = 512 * int(rng.integers(1, 80))
+    nb = int(rng.integers(2, 7))
+    ns = int(rng.choice([1, 3, 9]))
+    cfg = make_cfg(ov, L, nb)
+    try:
+        GpuDemod(cfg, ns, 0).close()
+    except capi.RtlfmError as e:
+        _skip_only_outside_reference_domain(oracle_lib, cfg, L, e)
+    amp = 25.0 if ov["custom_atan"] == 1 and ov["mode"] == capi.MODE_FM else 55.0
+    if ov["custom_atan"] == 1 and ov["downsample_passes"] == 0:
+        amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=17000 + seed, fs=1.024e6, dev_hz=20e3, amplitude=amp)
+    if seed % 3 == 0:
+        iq[-1] = synth.random_u8(1, L * nb, seed=18000 + seed)[0]  # full-scale bytes: the int16 wraps
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=2)
+    cut = int(rng.integers(1, nb))
+    for path, splits in ((0, None), (0, [(0, cut), (cut, nb)])):
+        outs, sts, _ = gpu_run(cfg, iq, path=path, splits=splits)
+        for s in range(ns):
+            assert len(outs[s]) == want_len[s], (ov, L, nb, path, splits, s)
+            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{ov} L={L} nb={nb} path={path} splits={splits} [{s}]")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
+
+
 @pytest.mark.parametrize("passes,fir9,atan,mode", [
     (7, 0, 0, 0), (7, 1, 0, 0), (7, 1, 2, 0), (8, 0, 0, 0), (8, 1, 1, 0), (9, 1, 0, 0), (10, 0, 0, 0), (10, 1, 2, 0),
     (7, 0, 0, 1), (8, 1, 0, 2), (9, 0, 0, 3),
