@@ -285,6 +285,10 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        0 also on a caller-owned stream, where no search is made)
  *   placement_ms         wall time the placement searches of this handle took, in all
  *   placement_walked_mb  most a search held in temporary allocations (MiB)
+ *   poison               1 when RTLFM_POISON=1 was in the environment at the library's first allocation: every device
+ *                        allocation of both libraries is filled with 0xA5 and every run / scan first leaves 0xA5 in all of
+ *                        every CU's LDS, so that nothing read before it is written goes unnoticed (debug_poison.h;
+ *                        tests/test_poison_gpu.py runs the parity suites that way)
  *   tail_sync            1: synchronise and report after every tail kernel (debugging)
  *   fused_debug          clock-stamp experiments (2 / 18 / 4, see fused_kernel.h)
  * Returns -ENOENT for an unknown name, -EINVAL for a value out of range.

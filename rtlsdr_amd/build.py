@@ -26,9 +26,9 @@ def _hipcc() -> str:
 OBJDIR = os.path.join(CSRC, "build")
 # which headers a translation unit sees (a header change recompiles only the units that include it)
 UNIT_HEADERS = {
-    "rtlfm_hip.hip": ["dsp_device.h", "staged_kernels.h", "fused_kernel.h", "boxcar_kernel.h", "bw_probe_kernel.h",
+    "rtlfm_hip.hip": ["debug_poison.h", "dsp_device.h", "staged_kernels.h", "fused_kernel.h", "boxcar_kernel.h", "bw_probe_kernel.h",
                       os.path.join("..", "..", "include", "rtlfm_hip.h")],
-    "rtlpower_hip.hip": ["dsp_device.h", "power_kernels.h", os.path.join("..", "..", "include", "rtlpower_hip.h"),
+    "rtlpower_hip.hip": ["debug_poison.h", "dsp_device.h", "power_kernels.h", os.path.join("..", "..", "include", "rtlpower_hip.h"),
                          os.path.join("..", "..", "include", "rtlfm_hip.h")],
 }
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",

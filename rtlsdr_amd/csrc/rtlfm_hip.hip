@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rtlfm_hip.h"
+#include "debug_poison.h"
 #include "staged_kernels.h"
 #include "fused_kernel.h"
 #include "boxcar_kernel.h"
@@ -566,6 +567,7 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 	if (!strcmp(name, "tail_serial")) { *value = h->tail_overlap ? 0 : 1; return 0; }
 	// read-only: where the write streams' buffers ended up (rtlfm_gpu_malloc_apart_ex) and what finding out cost
 	if (!strcmp(name, "ring_apart")) { *value = h->place.ring_apart; return 0; }
+	if (!strcmp(name, "poison")) { *value = rtl_debug::poison_on() ? 1 : 0; return 0; }  // RTLFM_POISON=1 (debug_poison.h)
 	if (!strcmp(name, "res_apart")) { *value = h->place.res_apart; return 0; }
 	if (!strcmp(name, "placement_ms")) { *value = (long)(h->place.search_ms + 0.5); return 0; }
 	if (!strcmp(name, "placement_walked_mb")) { *value = (long)(h->place.walked_peak >> 20); return 0; }
@@ -1354,6 +1356,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	if (((uintptr_t)d_iq & 15) || (stream_stride & 15) || ((uintptr_t)d_out & 3) || (out_stride & 1)) return -EINVAL;
 	if (stream_stride < (size_t)nblocks * h->cfg.block_len) return -EINVAL;
 	HIP_TRY(hipSetDevice(h->device));
+	rtl_debug::poison_lds(h->stream);  // RTLFM_POISON=1 only
 	const size_t S = (size_t)h->nstreams;
 	bool can_fuse = fused::supported(h->cfg, nblocks);
 	// the raw DC block rides on the MFMA pass 0, and only that engine has the partial-tile kernels (-W n)

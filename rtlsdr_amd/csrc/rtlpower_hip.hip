@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/rtlpower_hip.h"
+#include "debug_poison.h"
 #include "power_kernels.h"
 
 using namespace rtlpower;
@@ -472,6 +473,7 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 	const rtlpower_cfg &c = h->cfg;
 	const int S = h->nstreams;
 	hipStream_t q = h->stream;
+	rtl_debug::poison_lds(q);  // RTLFM_POISON=1 only
 	if (c.bin_e == 0) {
 		k_power_rms<<<S, 256, 0, q>>>(d_iq, stream_stride, nreads, (int)c.buf_len, c.peak_hold, h->d_avg, h->d_samples);
 		HIP_TRY(hipGetLastError());

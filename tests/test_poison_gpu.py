@@ -1,0 +1,31 @@
+"""Nothing the library reads may depend on what fresh memory happens to hold: hipMalloc hands out zero pages in a fresh
+process, and a workgroup's LDS usually still holds what the same kernel left there one launch earlier - so a buffer or an
+LDS word that is read before it is written passes every ordinary test.  With RTLFM_POISON=1 (rtlsdr_amd/csrc/
+debug_poison.h) every device allocation of the library is filled with 0xA5 and every run / scan entry point first leaves
+0xA5 in all of every CU's LDS; the golden fixtures and a short random sweep of both tools must not notice.  (Round 4:
+the boxcar front end read its dummy tile - what lies behind a partial last tile - before the null-stream memset that
+fills it had run; it showed only with several test processes on one GPU.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parity_suites_under_poison():
+    env = dict(os.environ, RTLFM_POISON="1", RTLFM_SWEEP="24", RTLFM_SWEEP_W="24", RTLFM_SWEEP_POWER="16",
+               RTLFM_SWEEP_POWER_BIG="4", RTLFM_SWEEP_CB="4")
+    probe = ("import sys; sys.path.insert(0, %r); from rtlsdr_amd.capi import RtlfmCfg; from rtlsdr_amd.demod import GpuDemod\n"
+             "g = GpuDemod(RtlfmCfg.default(downsample=16, downsample_passes=4, block_len=16384, max_blocks=2), 1, 0)\n"
+             "print('poison', g.get_option('poison'))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=300)
+    assert "poison 1" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_parity_gpu.py"), os.path.join(ROOT, "tests", "test_power_gpu.py"),
+                        "-k", "golden or random or any_512n or one_frame_per_read"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
