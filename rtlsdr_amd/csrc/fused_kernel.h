@@ -1143,6 +1143,7 @@ struct Workspace {
 	int target_waves_tail_fifth = 12288;
 	bool tail_follows = false;                    // set by the host per run (rtlfm_hip.hip: plan_tail)
 	int min_tiles = 8;                            // a segment pays one warm-up tile: at most 1/8 on top
+	bool plan_by_caller = false;                  // fused_waves / fused_min_tiles were set: the planner's own rules of thumb stand back
 	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
 	int gss_x10 = 0;                              // guided segment lengths: remaining / (gss R) per round, x10 (0 = equal segments)
 	int debug = 0;                                // fused_debug: 2 = clock stamps per launch (+16: only on timing_read), 4 = reload a cached tile, 32 = stamp HW_ID / XCC_ID instead of the shader clock
@@ -1186,9 +1187,13 @@ inline SegPlan plan_segments(const Workspace &ws, int nstreams, int total_tiles,
 	}
 	int min_tiles = ws.min_tiles > 0 ? ws.min_tiles : 1;
 	// Where the streams alone fill every wave slot, a second wave per stream buys no parallelism and pays its
-	// warm-up tile: segments of sixteen tiles at least (north_star's live shape - 4096 streams x ONE 262144-B
-	// buffer per launch - then runs one wave per stream: 0.2128 against 0.2158 ms, same box, interleaved)
-	if (nstreams >= kWaveSlots && min_tiles < 16 && !ws.tail_follows) min_tiles = 16;
+	// warm-up tile: north_star's live shape - 4096 streams x ONE 262144-B buffer per launch, 32 tiles per stream -
+	// runs one wave per stream (0.2050 against 0.2086 ms, 0.2128 against 0.2158 on another box, interleaved:
+	// tools/launch_gap.py, gpurun_out/r04d/x1_waves.txt); from four buffers per launch on, two waves per stream win
+	// again (0.8283 against 0.8383 ms): the longer the waves, the more the SIMD's preference for its oldest wave
+	// spreads their ends (4.2a).  (Until the end of round 4 this rule said "segments of sixteen tiles at least", which
+	// at 32 tiles per stream still cut two - bench.py's also.ns4096x1.waves_per_stream said so all along.)
+	if (nstreams >= kWaveSlots && !ws.tail_follows && !ws.plan_by_caller) min_tiles = total_tiles <= 48 ? total_tiles : 16;
 	const int target = !ws.tail_follows ? ws.target_waves
 	                   : (fifth_order && ws.target_waves_tail_fifth > 0 ? ws.target_waves_tail_fifth : ws.target_waves_tail);
 	int segs = (target + nstreams - 1) / nstreams;

@@ -552,6 +552,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if ((!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) && value < 1) return -EINVAL;
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
 	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
+	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_min_tiles")) h->fws.plan_by_caller = true;       // ... and so do these
 	if (!strcmp(name, "pass0_engine") && (value < -1 || value > 1)) return -EINVAL;
 	if ((!strcmp(name, "fused_min_tiles") || !strcmp(name, "fused_tiles_per_seg")) && value < 0) return -EINVAL;
 	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
