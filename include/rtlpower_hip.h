@@ -122,7 +122,8 @@ int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream);
 /* Tunables by name, as rtlfm_gpu_set_option: "groups" = workgroups per stream of the FFT kernel
  * (0 = automatic: enough to fill the 256 CUs); "staged_fast" = 0: transforms beyond 16384 bins take the general
  * kernels also where the ones written for rtl_power's own shape (an undecimated read = one frame) apply - A/B and
- * tests, the results are the same integers.  -ENOENT for an unknown name. */
+ * tests, the results are the same integers; "scan_frames" = 0 likewise for reads that hold several frames (the general
+ * in-LDS kernel instead of k_power_scan_frames).  -ENOENT for an unknown name. */
 int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long value);
 /* HIP-event timing of the FFT kernel, as rtlfm_gpu_timing_*. */
 int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on);

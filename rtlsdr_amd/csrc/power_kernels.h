@@ -542,6 +542,152 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 	}
 }
 
+// rtl_power's everyday shape: SEVERAL frames per read.  The planner never reads less than 16384 bytes
+// (src/rtl_power.c:501-504), so every scan below 8192 bins - "-f 88M:108M:125k" is 32 of them - hands over reads of
+// M = 2^E = 8192 points (or 16384) that hold chunks = M >> bin_e frames.  Stage s < bin_e pairs points inside a
+// frame only, so the stages run over all M points at once exactly as k_power_scan_big's do - same thread-owned
+// 16-byte loads with the next read in flight, same packed phases A and B (the bit reversal is over bin_e bits inside
+// the frame, the window index is j mod N), stages 0 .. bin_e - 1 with the stage a run-time value -, and phase D folds
+// the M points onto the N bins: point pos is bin pos mod N, a thread's eight or sixteen points keep their own 64-bit
+// sums over the reads, and at the end the workgroup adds them up per bin in LDS (ds_add_u64 / ds_max_u64 on the
+// points' area) before N global atomics.  Before: k_power_scan's byte loads and scalar phases, 100-150 Gsamples/s
+// where the 8192-bin kernel runs 380.
+template <int E>
+__global__ void __launch_bounds__(kThreads) k_power_scan_frames(const ScanParams p)
+{
+	constexpr int M = 1 << E;
+	constexpr int P = M / kThreads;  // points per thread: 8 or 16
+	constexpr int V = P / 8;
+	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+	uint32_t *pts = sm;                       // [skewed_size(M)]
+	uint32_t *tw = sm + skewed_size(M);       // [N]
+	__shared__ int red[2][kThreads / 64];
+	const int BE = p.bin_e, N = 1 << BE;      // 3 <= BE < E
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const size_t s = blockIdx.x / p.groups;
+	const int grp = (int)(blockIdx.x % p.groups);
+	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
+	if (r_begin >= r_end) return;
+	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
+	const int j0 = t * P;                     // the thread's points j0 .. j0 + P - 1: a wave reads 64 P contiguous points
+	// their LDS addresses: frame j >> BE stays, the index inside the frame is bit-reversed
+	int scatter[P];
+#pragma unroll
+	for (int k = 0; k < P; k++) {
+		const int j = j0 + k;
+		scatter[k] = skew((j & ~(N - 1)) | (int)(__brev((unsigned)(j & (N - 1))) >> (32 - BE)));
+	}
+	// window coefficients (16-bit halves, two to a register): P consecutive ones from j0 mod N (N >= 8 = a multiple of
+	// what a 16-byte load holds; N < P wraps inside the thread's points: the table is then read piece by piece)
+	uint32_t w2[P / 2];
+#pragma unroll
+	for (int k = 0; k < P / 8; k++) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(p.window16 + ((j0 + 8 * k) & (N - 1)));
+		w2[4 * k] = v.x; w2[4 * k + 1] = v.y; w2[4 * k + 2] = v.z; w2[4 * k + 3] = v.w;
+	}
+	long long acc[P];
+#pragma unroll
+	for (int k = 0; k < P; k++) acc[k] = 0;
+	const uint8_t *base = p.iq8 + s * p.stride8 + 2 * (size_t)j0;
+	uint4 cur[V], nxt[V];
+#pragma unroll
+	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base + (size_t)r_begin * p.buf_len)[v];
+	auto dc_partial = [&](const uint4 (&d4)[V]) {
+		int si = -127 * P, sq = -127 * P;
+#pragma unroll
+		for (int v = 0; v < V; v++) {
+			const uint32_t d[4] = {d4[v].x, d4[v].y, d4[v].z, d4[v].w};
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				si = (int)__builtin_amdgcn_udot4(d[q], 0x00010001u, (uint32_t)si, false);
+				sq = (int)__builtin_amdgcn_udot4(d[q], 0x01000100u, (uint32_t)sq, false);
+			}
+		}
+		si = wave_total(si);
+		sq = wave_total(sq);
+		if (lane == 63) { red[0][wave] = si; red[1][wave] = sq; }
+	};
+	auto dc_average = [&](int &ai, int &aq) {  // remove_dc over the whole read: 2 M elements (src/rtl_power.c:581-596)
+		int part = lane < 2 * (kThreads / 64) ? (&red[0][0])[lane] : 0;
+		part += __builtin_amdgcn_update_dpp(0, part, 0x111, 0xf, 0xf, false);
+		part += __builtin_amdgcn_update_dpp(0, part, 0x112, 0xf, 0xf, false);
+		part += __builtin_amdgcn_update_dpp(0, part, 0x114, 0xf, 0xf, false);
+		part += __builtin_amdgcn_update_dpp(0, part, 0x118, 0xf, 0xf, false);
+		ai = (int)(int16_t)(__builtin_amdgcn_readlane(part, 15) / (2 * M));
+		aq = (int)(int16_t)(__builtin_amdgcn_readlane(part, 31) / (2 * M - 1));
+	};
+	int ai, aq;
+	dc_partial(cur);
+	__syncthreads();  // also: the twiddle table is in place
+	dc_average(ai, aq);
+
+	for (int r = r_begin; r < r_end; r++) {
+		// ---- B: convert, DC, window on packed pairs (as k_power_scan_big), placement ----
+		typedef unsigned short upk16_t __attribute__((ext_vector_type(2)));
+		const upk16_t dcw = {(unsigned short)(127 + ai), (unsigned short)(127 + aq)};
+#pragma unroll
+		for (int k = 0; k < P; k++) {
+			const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
+			const upk16_t iq = __builtin_bit_cast(upk16_t, __builtin_amdgcn_perm(0u, d, (k & 1) ? 0x0c030c02u : 0x0c010c00u));
+			const upk16_t wpair = __builtin_bit_cast(upk16_t, w2[k / 2]);
+			const unsigned short wk = (k & 1) ? wpair.y : wpair.x;
+			const upk16_t ww = {wk, wk};
+			pts[scatter[k]] = __builtin_bit_cast(uint32_t, (upk16_t)((upk16_t)(iq - dcw) * ww));
+		}
+		const bool more = r + 1 < r_end;
+		if (more) {
+#pragma unroll
+			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
+		}
+		__syncthreads();
+		// ---- C: stages 0 .. BE - 1, three per LDS round trip; the radix-8 passes below stage 9 stay inside a wave's
+		// own 512-point blocks (k_power_scan_big), every other step needs the workgroup
+		bool dc_done = false;
+		for (int st = 0; st < BE;) {
+			const int R = BE - st >= 3 ? 3 : BE - st;
+			if (R == 3) fft_pass<3>(pts, tw, M, st, t);
+			else if (R == 2) fft_pass<2>(pts, tw, M, st, t);
+			else fft_pass<1>(pts, tw, M, st, t);
+			st += R;
+			if (more && !dc_done) { dc_partial(nxt); dc_done = true; }  // rides on the barriers the transform has anyway
+			const bool own = R == 3 && st + 3 <= 9 && BE - st >= 3;    // the next pass is a radix-8 one inside the same blocks
+			if (own) wave_sync(); else __syncthreads();
+		}
+		// ---- D: point pos is bin pos mod N; the thread's points t + 1024 a (conflict-free under the skew) ----
+#pragma unroll
+		for (int a = 0; a < P; a++) {
+			const uint32_t x = pts[skew(t + kThreads * a)];
+			if (p.peak_hold) {
+				const uint32_t pw = (uint32_t)power_of(x);
+				const uint32_t m = (uint32_t)acc[a];
+				acc[a] = (long long)(pw > m ? pw : m);
+			} else {
+				acc[a] += power_of(x);
+			}
+		}
+		if (more) dc_average(ai, aq);
+		__syncthreads();  // phase D is done reading pts: the next read may be placed
+#pragma unroll
+		for (int v = 0; v < V; v++) cur[v] = nxt[v];
+	}
+	// ---- the workgroup's sums per bin (the points' area is free now: N 64-bit words), then N global atomics ----
+	unsigned long long *bins = reinterpret_cast<unsigned long long *>(sm);
+	for (int k = t; k < N; k += kThreads) bins[k] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int a = 0; a < P; a++) {
+		const int bin = (t + kThreads * a) & (N - 1);
+		if (p.peak_hold) atomicMax(bins + bin, (unsigned long long)acc[a]);
+		else atomicAdd(bins + bin, (unsigned long long)acc[a]);
+	}
+	__syncthreads();
+	for (int k = t; k < N; k += kThreads) {
+		if (p.peak_hold) atomicMax(p.avg + s * N + k, (long long)bins[k]);
+		else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + k), bins[k]);
+	}
+	if (t == 0) atomicAdd(p.samples + s, p.ds * p.chunks * (r_end - r_begin));  // :717, once per frame
+}
+
 // ---- transforms that do not fit one workgroup's LDS: bin_e 15 ... 21, or more frames per read than 16384 points ----
 // frequency_range() plans up to 2^21 bins (src/rtl_power.c:483-486) and fix_fft (:271-327) has no size limit.  The
 // same radix-2 DIT stages, with the same FIX_MPY rounding and the same ">> 1" per stage, run over a work buffer in

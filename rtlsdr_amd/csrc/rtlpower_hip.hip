@@ -48,6 +48,8 @@ struct rtlpower_gpu {
 	uint32_t *d_work = nullptr; int2 *d_ave = nullptr;
 	// one undecimated frame per read, bin_e > 14: the window comb by comb, the batch's bytes likewise, the averages' partial sums
 	uint16_t *d_window16T = nullptr; uint8_t *d_tbuf = nullptr; int2 *d_part = nullptr; bool attr_comb = false;
+	int scan_frames = 1;  // option "scan_frames": 0 = k_power_scan also where k_power_scan_frames applies (A/B, tests)
+	bool attr_frames = false;
 	int staged_fast = 1;  // option "staged_fast": 0 = the general kernels also where the fast ones apply (A/B, tests)
 	size_t work_reads = 0;                 // reads the work buffer holds per stream
 	bool attr_lds = false;
@@ -396,6 +398,10 @@ extern "C" int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long v
 		h->staged_fast = value != 0;
 		return 0;
 	}
+	if (!strcmp(name, "scan_frames")) {
+		h->scan_frames = value != 0;
+		return 0;
+	}
 	return -ENOENT;
 }
 
@@ -654,8 +660,22 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		p.stamps = h->d_stamps;
 		h->stamp_last = (int)grid;
 	}
+	// several frames per read (rtl_power's everyday shape: every scan below 8192 bins reads 16384 bytes): raw input,
+	// reads of exactly 8192 or 16384 points
+	const int M = h->chunks * h->N;
+	const bool frames = h->scan_frames && !dec && h->chunks > 1 && c.bin_e >= 3 && (M == 8192 || M == 16384) && h->len_dec == 2 * M &&
+	                    c.buf_len == (uint32_t)(2 * M) && !(stream_stride & 15) && !((uintptr_t)d_iq & 15);
+	if (frames && !h->attr_frames) {
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_frames<13>),
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_frames<14>),
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+		h->attr_frames = true;
+	}
 	if (big && c.bin_e == 14) hipLaunchKernelGGL(k_power_scan_big<14>, dim3(grid), dim3(kThreads), lds, q, p);
 	else if (big) hipLaunchKernelGGL(k_power_scan_big<13>, dim3(grid), dim3(kThreads), lds, q, p);
+	else if (frames && M == 8192) hipLaunchKernelGGL(k_power_scan_frames<13>, dim3(grid), dim3(kThreads), lds, q, p);
+	else if (frames) hipLaunchKernelGGL(k_power_scan_frames<14>, dim3(grid), dim3(kThreads), lds, q, p);
 	else hipLaunchKernelGGL(k_power_scan, dim3(grid), dim3(kThreads), lds, q, p);
 	HIP_TRY(hipGetLastError());
 	if (h->timing) {

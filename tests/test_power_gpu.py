@@ -120,11 +120,33 @@ def test_power_random_configurations(oracle_lib, seed):
     iq = np.concatenate([synth.fm_iq_u8(ns, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=100 + seed),
                          synth.random_u8(1, L * nr, seed=200 + seed)])
     want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=2)
-    for split in (None, 1):
-        res = gpu_scan(cfg, iq, split=split)
+    # scan_frames = 0: the general in-LDS kernel also where the one written for "several frames per read" applies
+    for split, frames in ((None, 1), (1, 1), (None, 0)):
+        res = gpu_scan(cfg, iq, split=split, options=dict(scan_frames=frames))
         for s in range(ns + 1):
-            assert res[s][1] == wn[s], (kw, s, split)
-            assert np.array_equal(res[s][0], want[s]), (kw, s, split)
+            assert res[s][1] == wn[s], (kw, s, split, frames)
+            assert np.array_equal(res[s][0], want[s]), (kw, s, split, frames)
+
+
+@pytest.mark.parametrize("bin_e", list(range(3, 14)))
+@pytest.mark.parametrize("L", [16384, 32768])
+def test_power_several_frames_per_read(oracle_lib, bin_e, L):
+    """rtl_power's everyday shape - the planner never reads less than 16384 bytes (src/rtl_power.c:501-504), so a scan
+    below 8192 bins hands over reads that hold several frames - on k_power_scan_frames and on the general kernel, against
+    the oracle: every bin size, both read sizes, peak hold, full-scale bytes, few and many streams (reads split over
+    workgroups)."""
+    if (2 << bin_e) >= L:
+        pytest.skip("one frame per read: k_power_scan_big's case")
+    cfg = RtlpowerCfg.default(bin_e=bin_e, window=(bin_e % 7) + 1, buf_len=L, peak_hold=int(bin_e % 4 == 1))
+    nr, ns = 5, 3
+    iq = np.concatenate([synth.fm_iq_u8(ns - 1, L // 2 * nr, fs=2.048e6, dev_hz=40e3, seed=900 + bin_e),
+                         synth.random_u8(1, L * nr, seed=950 + bin_e)])
+    want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=2)
+    for split, frames in ((None, 1), (2, 1), (None, 0)):
+        res = gpu_scan(cfg, iq, split=split, options=dict(scan_frames=frames))
+        for s in range(ns):
+            assert res[s][1] == wn[s], (bin_e, L, s, split, frames)
+            assert np.array_equal(res[s][0], want[s]), (bin_e, L, s, split, frames)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_POWER_BIG", "10"))))
