@@ -702,6 +702,9 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	view.d_tbuf = nullptr; view.d_part = nullptr;
 	view.ev_pending.clear(); view.ev_free.clear(); view.timing = false;
 	int r = rtlpower_gpu_scan_device(&view, h->d_one, h->cfg.buf_len, 1);
+	// what the view learnt about this device stays learnt (the kernels' dynamic-LDS limits are raised once per handle)
+	h->attr_set = view.attr_set; h->attr_big = view.attr_big; h->attr_lds = view.attr_lds; h->attr_comb = view.attr_comb;
+	h->attr_frames = view.attr_frames;
 	const hipError_t e = hipStreamSynchronize(h->stream);
 	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }  // also when the sync failed
 	if (view.d_work) { (void)hipFree(view.d_work); (void)hipFree(view.d_ave); }

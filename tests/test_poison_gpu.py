@@ -25,7 +25,7 @@ def test_parity_suites_under_poison():
     assert "poison 1" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_parity_gpu.py"), os.path.join(ROOT, "tests", "test_power_gpu.py"),
-                        "-k", "golden or random or any_512n or one_frame_per_read"],
+                        "-k", "golden or random or any_512n or one_frame_per_read or several_frames"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
