@@ -693,6 +693,65 @@ def test_random_configurations_vs_oracle(oracle_lib, seed):
             assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
 
 
+def test_handles_of_several_threads_do_not_meet(oracle_lib):
+    """One process, six threads, each with handles of its own (random configurations, both tools) running at the same
+    time on one device: nothing in the library is shared between handles but the device, so every thread must get the
+    oracle's output.  (ctypes releases the GIL inside a call: the launches, copies and synchronisations of the threads
+    really interleave.)"""
+    import threading
+    from rtlsdr_amd.capi import RtlpowerCfg
+    from rtlsdr_amd.demod import GpuDemod
+    import test_power_gpu as TP
+    jobs = []
+    for seed in range(40):
+        rng = np.random.default_rng(29000 + seed)
+        ov = _random_cfg(rng)
+        L = 512 * int(rng.integers(1, 80)) if seed % 2 else int(rng.choice([8192, 16384, 32768]))
+        nb, ns = int(rng.integers(2, 5)), int(rng.choice([1, 3, 9]))
+        cfg = make_cfg(ov, L, nb)
+        try:
+            GpuDemod(cfg, ns, 0).close()
+        except capi.RtlfmError:
+            continue
+        iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=27000 + seed, fs=1.024e6, dev_hz=20e3, amplitude=25.0)
+        want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=2)
+        jobs.append(("fm", cfg, iq, want, want_len, wst, ov))
+    for seed in range(8):
+        bin_e = [5, 8, 10, 12, 13, 14, 15, 16][seed]
+        pc = RtlpowerCfg.default(bin_e=bin_e, window=seed % 7 + 1, buf_len=max(16384, 2 << bin_e))
+        iq = synth.random_u8(2, int(pc.buf_len) * 3, seed=28000 + seed)
+        want, wn = oracle_lib.power_scan_batch(pc, iq, nthreads=2)
+        jobs.append(("power", pc, iq, want, wn))
+    assert len(jobs) >= 30
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(2):
+                for j in jobs[k::6]:
+                    if j[0] == "fm":
+                        _, cfg, iq, want, want_len, wst, ov = j
+                        outs, sts, _ = gpu_run(cfg, iq, path=0)
+                        for s in range(iq.shape[0]):
+                            assert len(outs[s]) == want_len[s], (ov, s)
+                            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"thread {k}: {ov} [{s}]")
+                            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, s)
+                    else:
+                        _, pc, iq, want, wn = j
+                        res = TP.gpu_scan(pc, iq)
+                        for s in range(iq.shape[0]):
+                            assert res[s][1] == wn[s] and np.array_equal(res[s][0], want[s]), (int(pc.bin_e), s)
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)[:600]))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP_W", "24"))))
 def test_random_configurations_any_buffer_size(oracle_lib, seed):
     """The same sweep with -W n buffers (any 512 n bytes, src/rtl_fm.c:1869-1873): the partial tiles of the fifth_order
