@@ -16,11 +16,16 @@ from rtlsdr_amd.power import GpuPower  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     total = 1 << 30
-    shapes = [(14, 32768), (13, 16384), (12, 16384), (10, 16384), (8, 16384), (5, 16384), (12, 65536), (10, 65536), (13, 32768)]
-    for bin_e, L in shapes:
+    shapes = [(14, 32768, {}), (13, 16384, {}), (12, 16384, {}), (10, 16384, {}), (8, 16384, {}), (5, 16384, {}), (12, 65536, {}), (10, 65536, {}), (13, 32768, {}),
+              # a range below 1 MHz is decimated in front of the FFT (src/rtl_power.c:466-480): boxcar (default) or -F fifth_order passes
+              (10, 16384, dict(downsample=8, boxcar=1)), (8, 16384, dict(downsample=4, boxcar=1)), (12, 32768, dict(downsample=4, boxcar=1)),
+              (10, 16384, dict(downsample=8, downsample_passes=3, boxcar=0)), (10, 16384, dict(downsample=8, downsample_passes=3, boxcar=0, comp_fir_size=9))]
+    if len(sys.argv) > 1 and sys.argv[1] == "dec":
+        shapes = [x for x in shapes if x[2]]
+    for bin_e, L, extra in shapes:
         streams = 1024
         nreads = total // (streams * L)
-        cfg = RtlpowerCfg.default(bin_e=bin_e, window=1, buf_len=L)
+        cfg = RtlpowerCfg.default(bin_e=bin_e, window=1, buf_len=L, **extra)
         iq = torch.randint(0, 256, (streams, nreads * L), dtype=torch.uint8, device=dev)
         with GpuPower(cfg, streams, 0) as g:
             for _ in range(3):
@@ -33,7 +38,7 @@ def main():
             g.sync()
             dt = (time.perf_counter() - t0) / K
         samples = streams * nreads * L // 2
-        print(f"2^{bin_e} bins, {streams} streams x {nreads} reads x {L} B ({L // (2 << bin_e)} frames per read): {dt * 1e3:8.3f} ms per launch, "
+        print(f"2^{bin_e} bins {extra or ''}, {streams} streams x {nreads} reads x {L} B ({L // (2 << bin_e)} frames per read): {dt * 1e3:8.3f} ms per launch, "
               f"{samples / dt / 1e9:7.2f} Gsamples/s", flush=True)
         del iq
 
