@@ -350,6 +350,34 @@ __device__ __forceinline__ void fifth_history(uint32_t *slots, uint32_t *cr, con
 	}
 }
 
+// The same exchanges without LDS (RTLFM_DPP_EXCHANGE): lane l takes lane l - 1's values through DPP wave_shr:1, lane 0
+// takes the carry - what the last lane held one tile earlier, kept in SGPRs (v_readlane at the end of the exchange).
+// Three VALU instructions per dword (shift, select for lane 0, read-lane for the next tile) instead of an LDS store, a
+// load, the carry's store and two waits on the LDS queue in the middle of the tile's dependent chain.
+template <int W>
+__device__ __forceinline__ void hand_off_dpp(const uint32_t (&mine)[W], uint32_t (&prev)[W], const uint32_t (&carry)[W], int lane)
+{
+#pragma unroll
+	for (int k = 0; k < W; k++) {
+		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[k], 0x138, 0xf, 0xf, false);  // wave_shr:1
+		prev[k] = lane == 0 ? carry[k] : sh;
+	}
+}
+template <int C>
+__device__ __forceinline__ void fifth_history_dpp(const uint32_t (&Y)[C], uint32_t (&h)[5], uint32_t (&carry)[5], int lane,
+                                                  bool drop_newest_next, int last_lane)
+{
+	const uint32_t mine[5] = {Y[C - 5], Y[C - 4], Y[C - 3], Y[C - 2], Y[C - 1]};
+	hand_off_dpp<5>(mine, h, carry, lane);
+	// what the next tile's lane 0 sees: the last lane's newest five, or (the next tile starts a buffer) the five before
+	// the newest - the archive of src/rtl_fm.c:800-805 never holds the newest input
+	uint32_t t[6];
+#pragma unroll
+	for (int k = 0; k < 6; k++) t[k] = (uint32_t)__builtin_amdgcn_readlane((int)Y[C - 6 + k], last_lane);
+#pragma unroll
+	for (int k = 0; k < 5; k++) carry[k] = drop_newest_next ? t[k] : t[k + 1];
+}
+
 // linear ring: this tile's C values per lane go into the transient body, every lane reads the H entries
 // before its first - from the body, or, for positions before the tile, from the ring's prefix (the last
 // kPre entries of the previous tile) - and then the lanes that hold the tile's last kPre entries leave
@@ -437,6 +465,9 @@ struct AtanNodesLds {
 	__device__ __forceinline__ double operator()(int i) const { return t[i]; }
 };
 
+#ifndef RTLFM_DPP_EXCHANGE
+#define RTLFM_DPP_EXCHANGE 1  // lane-to-lane hand-offs of the first passes and the discriminator through DPP + SGPR carries instead of LDS
+#endif
 #ifndef RTLFM_FUSED_WAVES_PER_SIMD
 #define RTLFM_FUSED_WAVES_PER_SIMD 4
 #endif
@@ -558,6 +589,21 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	}
 	__builtin_amdgcn_wave_barrier();
 	const AtanNodesLds nodes{reinterpret_cast<const double *>(lds + L::atan)};
+	// RTLFM_DPP_EXCHANGE: the carries of the lane-to-lane hand-offs live in SGPRs from here on
+	// (from three passes on: the one- and two-pass kernels carry 32 / 16 outputs per lane through the tile, and with the
+	// carries in SGPRs the allocator of four of their RDC variants copied prefetched registers in front of the back-edge -
+	// a wait on the tile loads, tools/check_prefetch.py; their exchanges are a small share of the tile anyway)
+	constexpr bool DPPX = RTLFM_DPP_EXCHANGE && P >= 3;
+	uint32_t cy0[5] = {0, 0, 0, 0, 0}, cy1[5] = {0, 0, 0, 0, 0}, cy2[5] = {0, 0, 0, 0, 0}, czd[1] = {0};
+	if constexpr (DPPX) {
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			if (P >= 2) cy0[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[L::c_y0 + k]);
+			if (P >= 3) cy1[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[L::c_y1 + k]);
+			if (P >= 4) cy2[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[L::c_y2 + k]);
+		}
+		czd[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[L::c_zd]);
+	}
 
 	const uint8_t *stream_base = p.iq + (size_t)s * p.stream_stride;
 	const int out_per_tile = 64 * CZ;
@@ -946,7 +992,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		} else {
 			uint32_t h5[5];
 			uint32_t Y1[16];
-			fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lz, next_bs, last_lane);
+			if constexpr (DPPX) fifth_history_dpp<32>(Y0, h5, cy0, lz, next_bs, last_lane);
+			else fifth_history<32>(lds + L::tr, lds + L::c_y0, Y0, h5, lz, next_bs, last_lane);
 			fifth_lane<32, true>(Y0, h5, Y1);
 			archive_regs(Y0, std::integral_constant<int, 32>(), 1);
 			if (MFMA0 && RTLFM_MFMA_RELOAD_AT == 2) reload(gt, more);
@@ -955,7 +1002,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				for (int k = 0; k < 16; k++) Z[k] = Y1[k];
 			} else {
 				uint32_t Y2[8];
-				fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lz, next_bs, last_lane);
+				if constexpr (DPPX) fifth_history_dpp<16>(Y1, h5, cy1, lz, next_bs, last_lane);
+				else fifth_history<16>(lds + L::tr, lds + L::c_y1, Y1, h5, lz, next_bs, last_lane);
 				fifth_lane<16, true>(Y1, h5, Y2);
 				archive_regs(Y1, std::integral_constant<int, 16>(), 2);
 				if constexpr (P == 3) {
@@ -963,7 +1011,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					for (int k = 0; k < 8; k++) Z[k] = Y2[k];
 				} else {
 					uint32_t Y3[4];
-					fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lz, next_bs, last_lane);
+					if constexpr (DPPX) fifth_history_dpp<8>(Y2, h5, cy2, lz, next_bs, last_lane);
+					else fifth_history<8>(lds + L::tr, lds + L::c_y2, Y2, h5, lz, next_bs, last_lane);
 					// with rotation |x| <= 1023 here, so the 16-bit form cannot overflow;
 					// without it an all-255 input reaches exactly 2^15
 					if (rotate && !RDC) fifth_lane<8, true>(Y2, h5, Y3);
@@ -1057,8 +1106,13 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		uint32_t pv;
 		{
 			uint32_t mine[1] = {V[CZ - 1]}, prev[1];
-			hand_off<1>(lds + L::tr, lds + L::c_zd, mine, prev, lz);
-			leave_carry<1>(lds + L::c_zd, mine, lane, last_lane);
+			if constexpr (DPPX) {
+				hand_off_dpp<1>(mine, prev, czd, lz);
+				czd[0] = (uint32_t)__builtin_amdgcn_readlane((int)mine[0], last_lane);
+			} else {
+				hand_off<1>(lds + L::tr, lds + L::c_zd, mine, prev, lz);
+				leave_carry<1>(lds + L::c_zd, mine, lane, last_lane);
+			}
 			pv = prev[0];
 			if (archive) {
 				iq16 w = unpack_iq(V[CZ - 1]);
