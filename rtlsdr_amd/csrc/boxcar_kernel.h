@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	};
 
 	for (int gt = gt_begin; gt < gt_end; gt++) {
+		fused::prio_by_progress(gt - gt_begin, gt_end - gt_begin);
 		const bool emit = gt >= gt_first;
 		const long long left = run_bytes - (long long)gt * kTileBytes;
 		const bool partial = left < kTileBytes;               // the run's last tile, cut short

@@ -28,6 +28,9 @@
 #include "../../include/rtlpower_hip.h"
 #include "dsp_device.h"
 
+#ifndef RTLPOWER_WAVE_PRIO
+#define RTLPOWER_WAVE_PRIO 1  // the four waves of a SIMD get four priorities (wave >> 2): -0.9 % on C4 (2.825 -> 2.800 ms, alternating); by wave & 3 (one priority per SIMD): +0.9 %
+#endif
 namespace rtlpower {
 
 using rtlfm::iq16;
@@ -355,6 +358,11 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 	uint32_t *tw = sm + skewed_size(N);       // [N]
 	__shared__ int red[2][kThreads / 64];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#if RTLPOWER_WAVE_PRIO == 1
+	{ const int w4 = __builtin_amdgcn_readfirstlane(wave) >> 2; if (w4 == 0) __builtin_amdgcn_s_setprio(3); else if (w4 == 1) __builtin_amdgcn_s_setprio(2); else if (w4 == 2) __builtin_amdgcn_s_setprio(1); }
+#elif RTLPOWER_WAVE_PRIO == 2
+	{ const int w4 = __builtin_amdgcn_readfirstlane(wave) & 3; if (w4 == 0) __builtin_amdgcn_s_setprio(3); else if (w4 == 1) __builtin_amdgcn_s_setprio(2); else if (w4 == 2) __builtin_amdgcn_s_setprio(1); }
+#endif
 	// COMB: the "reads" are this workgroup's share of all blocks, in order (the combs of a frame follow each other)
 	const size_t s = COMB ? 0 : blockIdx.x / p.groups;
 	const int grp = COMB ? 0 : (int)(blockIdx.x % p.groups);
