@@ -18,6 +18,9 @@
 
 #include "dsp_device.h"
 
+#ifndef RTLFM_TAIL_PRIO
+#define RTLFM_TAIL_PRIO 3
+#endif
 namespace rtlfm {
 
 using state_t = rtlfm_stream_state;
@@ -1072,6 +1075,9 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *lc, int vec,
                   int32_t *__restrict__ cnt_out)
 {
+#if RTLFM_TAIL_PRIO >= 0
+	__builtin_amdgcn_s_setprio(RTLFM_TAIL_PRIO);
+#endif
 	__shared__ int unsettled[kSpecLprThreads];  // per stream of this workgroup
 	const int nthreads = (int)blockDim.x, tid = (int)threadIdx.x;
 	const int spw = max_chunks >= nthreads ? 1 : nthreads / max_chunks;  // streams per workgroup
@@ -1460,6 +1466,9 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, size_t lds_per_wave,
                   int32_t *__restrict__ cnt_out)
 {
+#if RTLFM_TAIL_PRIO >= 0
+	__builtin_amdgcn_s_setprio(RTLFM_TAIL_PRIO);
+#endif
 	extern __shared__ uint4 arb_lds[];
 	__shared__ int wg_unsettled;
 	const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wpw = (int)blockDim.x >> 6;
