@@ -1215,8 +1215,11 @@ struct Workspace {
 	int target_waves_tail = 20480;
 	// ... for the fifth_order front ends 12288 since the tail is ONE kernel (round 4, same box, two alternations: c3 step
 	// 0.879 / 0.876 / 0.873 / 0.884 ms at 20480 / 16384 / 12288 / 24576; the boxcar front end of -M wbfm still wants
-	// 20480: 1.392 / 1.408 / 1.424 / 1.392).  0 = as target_waves_tail (set together with it by fused_waves).
-	int target_waves_tail_fifth = 12288;
+	// 20480: 1.392 / 1.408 / 1.424 / 1.392).  With the DPP hand-offs and the priority that follows the progress (the end of
+	// round 4) the optimum moved: c3 step 0.886 / 0.884 / 0.870 / 0.857 / 0.866 / 0.880 ms at 12288 / 16384 / 20480 / 24576 /
+	// 32768 / 40960, two alternations on one box; wbfm still 20480 (1.40 against 1.42-1.46 either side).
+	// 0 = as target_waves_tail (set together with it by fused_waves).
+	int target_waves_tail_fifth = 24576;
 	bool tail_follows = false;                    // set by the host per run (rtlfm_hip.hip: plan_tail)
 	int min_tiles = 8;                            // a segment pays one warm-up tile: at most 1/8 on top
 	bool plan_by_caller = false;                  // fused_waves / fused_min_tiles were set: the planner's own rules of thumb stand back
