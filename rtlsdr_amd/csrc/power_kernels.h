@@ -358,10 +358,14 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 	uint32_t *tw = sm + skewed_size(N);       // [N]
 	__shared__ int red[2][kThreads / 64];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-#if RTLPOWER_WAVE_PRIO == 1
-	{ const int w4 = __builtin_amdgcn_readfirstlane(wave) >> 2; if (w4 == 0) __builtin_amdgcn_s_setprio(3); else if (w4 == 1) __builtin_amdgcn_s_setprio(2); else if (w4 == 2) __builtin_amdgcn_s_setprio(1); }
-#elif RTLPOWER_WAVE_PRIO == 2
-	{ const int w4 = __builtin_amdgcn_readfirstlane(wave) & 3; if (w4 == 0) __builtin_amdgcn_s_setprio(3); else if (w4 == 1) __builtin_amdgcn_s_setprio(2); else if (w4 == 2) __builtin_amdgcn_s_setprio(1); }
+#if RTLPOWER_WAVE_PRIO
+	{
+		// sixteen waves in lock step, four per SIMD (wave w on SIMD w & 3): the four of a SIMD get four priorities
+		const int w4 = __builtin_amdgcn_readfirstlane(wave) >> 2;
+		if (w4 == 0) __builtin_amdgcn_s_setprio(3);
+		else if (w4 == 1) __builtin_amdgcn_s_setprio(2);
+		else if (w4 == 2) __builtin_amdgcn_s_setprio(1);
+	}
 #endif
 	// COMB: the "reads" are this workgroup's share of all blocks, in order (the combs of a frame follow each other)
 	const size_t s = COMB ? 0 : blockIdx.x / p.groups;
