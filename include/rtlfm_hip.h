@@ -283,6 +283,8 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        away from the ring's device input; -1 before the ring exists (it is built by the first push)
  *   res_apart            the same for the audio tail's work buffers against the first run's input (-1: none yet;
  *                        0 also on a caller-owned stream, where no search is made)
+ *   deep_apart           the same for the buffer a front end's emit mode writes (-M raw, the squelch, -L, 7-10 passes);
+ *                        -1: this configuration has none / not allocated yet
  *   placement_ms         wall time the placement searches of this handle took, in all
  *   placement_walked_mb  most a search held in temporary allocations (MiB)
  *   poison               1 when RTLFM_POISON=1 was in the environment at the library's first allocation: every device

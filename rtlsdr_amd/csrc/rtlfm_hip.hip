@@ -97,6 +97,7 @@ struct rtlfm_gpu {
 		int budget_gb = 150;            // option apart_budget_gb: most the filler walk may hold; 0 = no search
 		int ring_apart = -1;            // -1: not allocated yet; 0 / 1: the ring's result buffers (both halves) are a quarter away from d_in
 		int res_apart = -1;             // the same for the audio tail's work buffers against the first run's input
+		int deep_apart = -1;            // ... and for what a front end's emit mode writes (deepA)
 		double search_ms = 0;           // wall time of all searches of this handle
 		size_t walked_peak = 0;         // most a search held in temporary allocations (bytes)
 	} place;
@@ -357,24 +358,41 @@ static int ensure_work_buffers(rtlfm_gpu *h)
 }
 // the decimated IQ a front end in emit mode leaves for the staged kernels: /2^level behind fifth_order passes
 // (run_fused_emit), 1 / D (+ 1 per buffer) behind the boxcar (run_boxfused_emit)
-static int ensure_deep_buffers(rtlfm_gpu *h)
-{
-	if (h->deepA) return 0;
-	const int N0 = (int)(h->cfg.block_len / 2);
-	if (fused::supported_emit(h->cfg)) {
-		const int level = h->cfg.downsample_passes < fused::kMaxP ? h->cfg.downsample_passes : fused::kMaxP;
-		h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
-		HIP_TRY(hipMalloc(&h->deepA, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
-		HIP_TRY(hipMalloc(&h->deepB, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
-	} else if (boxfused::supported_emit(h->cfg)) {
-		h->deep_stride = (((size_t)h->cap_blocks * N0) / h->cfg.downsample + 1 + 16 + 3) & ~(size_t)3;  // rows start on 16-byte lines
-		HIP_TRY(hipMalloc(&h->deepA, (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t)));
-	}
-	return 0;
-}
 extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
                                          void **out, int *apart, double *search_ms, size_t *walked_bytes);
 
+// d_iq / iq_bytes: the input the first run streams from - what the front end's emit mode writes (deepA) goes a quarter of
+// the HBM away from it, as the result buffers do (ensure_res_buffers; option "deep_apart" says whether it worked)
+static int ensure_deep_buffers(rtlfm_gpu *h, const uint8_t *d_iq = nullptr, size_t iq_bytes = 0)
+{
+	if (h->deepA) return 0;
+	const int N0 = (int)(h->cfg.block_len / 2);
+	const bool fifth = fused::supported_emit(h->cfg);
+	if (!fifth && !boxfused::supported_emit(h->cfg)) return 0;
+	if (fifth) {
+		const int level = h->cfg.downsample_passes < fused::kMaxP ? h->cfg.downsample_passes : fused::kMaxP;
+		h->deep_stride = (size_t)h->cap_blocks * (N0 >> level);
+	} else {
+		h->deep_stride = (((size_t)h->cap_blocks * N0) / h->cfg.downsample + 1 + 16 + 3) & ~(size_t)3;  // rows start on 16-byte lines
+	}
+	const size_t bytes = (size_t)h->nstreams * h->deep_stride * sizeof(uint32_t);
+	// (no search in the middle of an asynchronous call on a stream the caller owns, nor for buffers too small to matter)
+	const bool search = d_iq && h->stream == h->own_stream && h->place.budget_gb > 0 && bytes >= ((size_t)32 << 20);
+	if (search) {
+		void *q = nullptr; int apart = 0; double ms = 0; size_t walked = 0;
+		int r = rtlfm_gpu_malloc_apart_ex(h->device, bytes, d_iq, iq_bytes, (size_t)h->place.budget_gb << 30, &q, &apart, &ms, &walked);
+		if (r < 0) return r;
+		h->deepA = static_cast<uint32_t *>(q);
+		h->place.search_ms += ms;
+		if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+		h->place.deep_apart = apart;
+	} else {
+		HIP_TRY(hipMalloc(&h->deepA, bytes));
+		h->place.deep_apart = 0;
+	}
+	if (fifth) HIP_TRY(hipMalloc(&h->deepB, bytes));
+	return 0;
+}
 // d_iq / iq_bytes: the input the first run streams from - the buffers the front end writes the demodulated
 // samples into ([parity][0]) go a quarter of the HBM away from it where they are large enough to matter
 static int ensure_res_buffers(rtlfm_gpu *h, const uint8_t *d_iq = nullptr, size_t iq_bytes = 0)
@@ -570,6 +588,7 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 	if (!strcmp(name, "ring_apart")) { *value = h->place.ring_apart; return 0; }
 	if (!strcmp(name, "poison")) { *value = rtl_debug::poison_on() ? 1 : 0; return 0; }  // RTLFM_POISON=1 (debug_poison.h)
 	if (!strcmp(name, "res_apart")) { *value = h->place.res_apart; return 0; }
+	if (!strcmp(name, "deep_apart")) { *value = h->place.deep_apart; return 0; }
 	if (!strcmp(name, "placement_ms")) { *value = (long)(h->place.search_ms + 0.5); return 0; }
 	if (!strcmp(name, "placement_walked_mb")) { *value = (long)(h->place.walked_peak >> 20); return 0; }
 	int *slot = option_slot(h, name);
@@ -1202,7 +1221,7 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
 	{
-		int r0 = ensure_deep_buffers(h);
+		int r0 = ensure_deep_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r0 < 0) return r0;
 	}
 	TailPlan tp = plan_tail(c);
@@ -1298,7 +1317,7 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
-	int r = ensure_deep_buffers(h);
+	int r = ensure_deep_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 	if (r < 0) return r;
 	TailPlan tp = plan_tail(c);
 	if (tp.any()) {
