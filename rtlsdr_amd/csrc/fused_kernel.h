@@ -470,10 +470,11 @@ __device__ __forceinline__ void fifth_lane(const uint32_t (&x)[CIN], const uint3
 // instruction per tile) the waves of a SIMD advance together and end together: -2.5 % at four buffers per launch, -5 %
 // at one (0.2068 -> 0.1960 ms), same box, old / new library alternating.  Two levels by half gain half of it, the
 // inverse order loses 2.5-6 %.
-__device__ __forceinline__ void prio_by_progress(int done, int total)
+__device__ __forceinline__ void prio_by_progress(int done, int total, int skip_top = 0)
 {
 #if RTLFM_PRIO_BY_PROGRESS
-	const int q4 = __builtin_amdgcn_readfirstlane((done * 4) / total);
+	// skip_top: priority 3 is left to the audio tail's kernel (three levels by third of the segment)
+	const int q4 = __builtin_amdgcn_readfirstlane(skip_top ? 1 + (done * 3) / total : (done * 4) / total);
 	if (q4 <= 0) __builtin_amdgcn_s_setprio(3);
 	else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
 	else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		const bool archive = last && writes_state && lane == last_lane;
 
 		RTLFM_MARK("tile_begin");
-		prio_by_progress(gt - gt_begin, gt_end - gt_begin);
+		prio_by_progress(gt - gt_begin, gt_end - gt_begin, p.debug & 128);
 		if constexpr (RDC) {
 			if (bs || gt == gt_begin) {
 				// a scalar load (the index is wave-uniform; readfirstlane says so to the compiler): a vector load
@@ -1414,7 +1415,7 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 		}
 		p.mfma_taps = t;
 	}
-	p.debug = ws.debug;
+	p.debug = ws.debug | (ws.tail_follows ? 128 : 0);
 	if (ws.want_stamps) p.debug |= 2;
 	if (needs_partial_tiles(c) && engine != 1) return -ENOTSUP;
 	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)((c.block_len + kTileBytes - 1) / kTileBytes), true);
