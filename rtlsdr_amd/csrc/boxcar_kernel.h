@@ -277,8 +277,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		if (lane >= 8 && lane < 16 && j1 >= j0 && t < last) g16[t] = (int16_t)pcm[t];
 	};
 
+	fused::ProgressPrio prio(gt_end - gt_begin, 0);
 	for (int gt = gt_begin; gt < gt_end; gt++) {
-		fused::prio_by_progress(gt - gt_begin, gt_end - gt_begin);
+		prio.at(gt - gt_begin);
 		const bool emit = gt >= gt_first;
 		const long long left = run_bytes - (long long)gt * kTileBytes;
 		const bool partial = left < kTileBytes;               // the run's last tile, cut short

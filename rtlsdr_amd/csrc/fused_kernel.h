@@ -470,17 +470,28 @@ __device__ __forceinline__ void fifth_lane(const uint32_t (&x)[CIN], const uint3
 // instruction per tile) the waves of a SIMD advance together and end together: -2.5 % at four buffers per launch, -5 %
 // at one (0.2068 -> 0.1960 ms), same box, old / new library alternating.  Two levels by half gain half of it, the
 // inverse order loses 2.5-6 %.
-__device__ __forceinline__ void prio_by_progress(int done, int total, int skip_top = 0)
-{
+struct ProgressPrio {
+	int th1, th2, th3, base;  // loop-invariant scalars: no state is carried from tile to tile
+	// total tiles of the segment; skip_top: priority 3 is left to the audio tail's kernel (three levels by third)
+	__device__ __forceinline__ ProgressPrio(int total, int skip_top)
+	{
+		const int levels = skip_top ? 3 : 4;
+		const int step = __builtin_amdgcn_readfirstlane((total + levels - 1) / levels);
+		th1 = step; th2 = 2 * step; th3 = skip_top ? 0x7fffffff : 3 * step;
+		base = skip_top ? 1 : 0;
+	}
+	// at the top of every tile (done = tiles behind the wave): three scalar compares and an s_setprio
+	__device__ __forceinline__ void at(int done) const
+	{
 #if RTLFM_PRIO_BY_PROGRESS
-	// skip_top: priority 3 is left to the audio tail's kernel (three levels by third of the segment)
-	const int q4 = __builtin_amdgcn_readfirstlane(skip_top ? 1 + (done * 3) / total : (done * 4) / total);
-	if (q4 <= 0) __builtin_amdgcn_s_setprio(3);
-	else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
-	else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
-	else __builtin_amdgcn_s_setprio(0);
+		const int q4 = __builtin_amdgcn_readfirstlane(base + (done >= th1 ? 1 : 0) + (done >= th2 ? 1 : 0) + (done >= th3 ? 1 : 0));
+		if (q4 <= 0) __builtin_amdgcn_s_setprio(3);
+		else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
+		else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
+		else __builtin_amdgcn_s_setprio(0);
 #endif
-}
+	}
+};
 
 struct AtanNodesLds {
 	const double *t;
@@ -718,6 +729,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 	};
 
+	ProgressPrio prio(gt_end - gt_begin, __builtin_amdgcn_readfirstlane(p.debug & 128));  // 128: an audio tail follows
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		const bool more = gt + 1 < gt_end;
 		const int tib = gt % tpb;
@@ -733,7 +745,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		const bool archive = last && writes_state && lane == last_lane;
 
 		RTLFM_MARK("tile_begin");
-		prio_by_progress(gt - gt_begin, gt_end - gt_begin, p.debug & 128);
+		prio.at(gt - gt_begin);
 		if constexpr (RDC) {
 			if (bs || gt == gt_begin) {
 				// a scalar load (the index is wave-uniform; readfirstlane says so to the compiler): a vector load
