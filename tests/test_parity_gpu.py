@@ -1321,6 +1321,15 @@ def test_placement_is_observable_and_bounded():
         for s in range(ns):
             g0.rtlsdr_callback(buf, s)
         assert g0.get_option("ring_apart") == 0 and g0.get_option("placement_walked_mb") == 0
+        assert g0.get_option("deep_apart") == -1     # this configuration has no emit-mode buffer
+        # the buffer a front end's emit mode writes (here: the squelch behind four passes) is placed as well
+        ge = GpuDemod(make_cfg(dict(downsample=16, downsample_passes=4, squelch_level=50), L, 1), ns, 0)
+        hs.append(ge)
+        assert ge.get_option("deep_apart") == -1
+        for s in range(ns):
+            ge.rtlsdr_callback(buf, s)
+        ge.full_demod(); ge.fetch_all()
+        assert ge.last_path == 2 and ge.get_option("deep_apart") in (0, 1)
     finally:
         for g in hs:
             g.close()
