@@ -123,8 +123,21 @@ int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream);
  * (0 = automatic: enough to fill the 256 CUs); "staged_fast" = 0: transforms beyond 16384 bins take the general
  * kernels also where the ones written for rtl_power's own shape (an undecimated read = one frame) apply - A/B and
  * tests, the results are the same integers; "scan_frames" = 0 likewise for reads that hold several frames (the general
- * in-LDS kernel instead of k_power_scan_frames).  -ENOENT for an unknown name. */
+ * in-LDS kernel instead of k_power_scan_frames); "dec_fast" = 0 likewise for decimated scans (src/rtl_power.c:466-480, :671-691:
+ * one launch per fifth_order pass and the general in-LDS kernel instead of k_power_downsample_iq + k_power_scan_frames<13, true>).
+ * -ENOENT for an unknown name.  get_option reads them back, and "last_kernel" (read-only): which transform the last
+ * scan took, one of RTLPOWER_KERNEL_*. */
 int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long value);
+int rtlpower_gpu_get_option(rtlpower_gpu *h, const char *name, long *value);
+enum rtlpower_kernel {
+	RTLPOWER_KERNEL_NONE = 0,
+	RTLPOWER_KERNEL_GENERAL = 1,      /* k_power_scan: any shape one workgroup's LDS holds */
+	RTLPOWER_KERNEL_BIG = 2,          /* k_power_scan_big: one undecimated frame of 8192 / 16384 points per read (BASELINE configs[3]) */
+	RTLPOWER_KERNEL_FRAMES = 3,       /* k_power_scan_frames: several undecimated frames per read */
+	RTLPOWER_KERNEL_DECIMATED = 4,    /* k_power_downsample_iq | k_power_boxcar + k_power_scan_frames<13, true> */
+	RTLPOWER_KERNEL_STAGED = 5,       /* transforms through HBM, the general kernels */
+	RTLPOWER_KERNEL_STAGED_FAST = 6   /* ... rtl_power's own fine-bin shape */
+};
 /* HIP-event timing of the FFT kernel, as rtlfm_gpu_timing_*. */
 int rtlpower_gpu_timing_enable(rtlpower_gpu *h, int on);
 int rtlpower_gpu_timing_read(rtlpower_gpu *h, double *ms, int *launches);

@@ -244,6 +244,7 @@ _POWER_SIGNATURES = [
     ("rtlpower_gpu_wait_for", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rtlpower_gpu_release_to", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rtlpower_gpu_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    ("rtlpower_gpu_get_option", C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_long)]),
     ("rtlpower_gpu_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("rtlpower_gpu_timing_read", C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_int)]),
     ("rtlpower_gpu_clock_probe", C.c_int, [C.c_void_p, C.c_int]),

@@ -45,6 +45,7 @@ struct Params {
 	int variant, rotate;
 	int mode, output_scale;
 	int D, q4096, r4096;  // 4096 = q4096 * D + r4096
+	uint32_t D_magic;     // ceil(2^32 / D): n / D = mulhi(n, D_magic) for every n a tile can ask about (n D < 2^32)
 	int out_cap;          // 4096 / D + 2
 	int segs, tiles_per_seg, nlist;  // as in fused_kernel.h: runs of tiles, long segments first
 	int seg_start[fused::kMaxSegList + 1];
@@ -177,6 +178,10 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	const long long run_bytes = (long long)p.nblocks * p.block_len;
 	const int total_tiles = (int)((run_bytes + kTileBytes - 1) / kTileBytes);
 	const int N0 = (int)(p.block_len / 2);  // samples per buffer
+	// only the run's last tile can be cut short: everything the tile loop asks about a tile's extent is a 32-bit
+	// compare against these two (round 5: the 64-bit products and divisions per tile were 250 scalar instructions)
+	const int last_tile = total_tiles - 1;
+	const int last_valid = (int)(run_bytes - (long long)last_tile * kTileBytes);  // bytes of the last tile, 512 .. 8192
 	int t0, t1;
 	fused::segment_bounds(p, seg, total_tiles, t0, t1);
 	if (t0 >= t1) return;
@@ -229,8 +234,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	auto load_tile = [&](int tile) {
 		const bool real = tile < gt_end;
 		const uint8_t *tb = real ? stream_base + (size_t)tile * kTileBytes : p.dummy_tile;
-		const long long left = real ? run_bytes - (long long)tile * kTileBytes : (long long)kTileBytes;
-		const int valid = left < kTileBytes ? (int)left : kTileBytes;  // wave-uniform
+		const int valid = tile == last_tile ? last_valid : kTileBytes;  // wave-uniform
 #pragma unroll
 		for (int k = 0; k < 8; k++) {
 			const uint8_t *row = tb + k * 1024;
@@ -277,13 +281,24 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		if (lane >= 8 && lane < 16 && j1 >= j0 && t < last) g16[t] = (int16_t)pcm[t];
 	};
 
+	// (RDC: whole-tile buffers) the buffer tile gt lies in and the tile's place inside it, carried from tile to tile
+	const int tiles_per_buf = RDC ? N0 / kTileSamples : 1;
+	int rdc_b = RDC ? gt_begin / tiles_per_buf : 0, rdc_t = RDC ? gt_begin - rdc_b * tiles_per_buf : 0;
+	// fm_demod's first output of every buffer (below, behind the output loop): xs = where the next buffer start that no
+	// tile has looked at yet lies, as a sample position relative to tile gt's first sample.  The outputs that complete
+	// in tile gt cover the samples [-ph, Et D - ph) of it; consecutive tiles' ranges follow each other without a gap.
+	int xs;
+	{
+		const long long g0 = (long long)gt_begin * kTileSamples - ph;          // the only 64-bit division of the wave
+		const long long bb0 = g0 <= 0 ? 0 : (g0 + N0 - 1) / N0;
+		xs = (int)(bb0 * N0 - (long long)gt_begin * kTileSamples);
+	}
 	fused::ProgressPrio prio(gt_end - gt_begin, 0);
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		prio.at(gt - gt_begin);
 		const bool emit = gt >= gt_first;
-		const long long left = run_bytes - (long long)gt * kTileBytes;
-		const bool partial = left < kTileBytes;               // the run's last tile, cut short
-		const int vs = partial ? (int)(left / 2) : kTileSamples;  // samples in this tile
+		const bool partial = gt == last_tile && last_valid < kTileBytes;  // the run's last tile, cut short
+		const int vs = partial ? last_valid / 2 : kTileSamples;            // samples in this tile
 		int Et, ph_next;
 		if (!partial) {
 			const int wrap = (ph + p.r4096 >= D) ? 1 : 0;
@@ -296,7 +311,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		uint32_t dc1 = 0, dc2 = 0, dc3 = 0;  // c G(1), c G(2), c G(3) as packed int16 pairs
 		int dcI = 0, dcQ = 0;
 		if constexpr (RDC) {
-			const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + (int)(((long long)gt * kTileSamples) / N0));
+			const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + rdc_b);
+			if (++rdc_t == tiles_per_buf) { rdc_t = 0; rdc_b++; }
 			const int2 a = p.rdc_avg[idx];  // a scalar load: a vector one would share the in-order vmcnt with the tile prefetch
 			dcI = __builtin_amdgcn_readfirstlane(a.x); dcQ = __builtin_amdgcn_readfirstlane(a.y);
 			dc1 = pack_iq((int16_t)dcI, (int16_t)dcQ);
@@ -441,23 +457,25 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			// (src/rtl_fm.c:935-937): redone here, behind the loop, instead of as a second discriminator under a
 			// per-lane condition inside it (where it cost every output of a -A fast run the std path's
 			// instructions as well).  Buffer b starts at run sample b N0 and its first output is output
-			// (p0 + b N0) / D of the run: lane c looks at the c-th buffer that can have it in this tile.
-			const long long s_lo = (long long)gt * kTileSamples - D, s_hi = (long long)gt * kTileSamples + vs - 1;
-			const int b_a = s_lo <= 0 ? 0 : (int)(s_lo / N0), b_b = (int)(s_hi / N0);
+			// (p0 + b N0) / D of the run: lane c looks at the c-th buffer start that falls into this tile's range.
+			// (p0 + b N0) / D - kb = (ph + x) / D with x = b N0 - 4096 gt, the buffer start relative to this tile: small
+			// numbers, one multiply-high per buffer start (round 5; three 64-bit divisions per tile until then).
+			const int lim = Et * D - ph;
 			__builtin_amdgcn_wave_barrier();
-			for (int bb = b_a + lane; bb <= b_b; bb += 64) {
-				const long long K = ((long long)p0 + (long long)bb * N0) / D;
-				const long long e64 = K - kb;
-				if (bb >= p.nblocks || e64 < 0 || e64 >= Et) continue;
-				const int e = (int)e64;
-				const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
-				const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
-				const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
-				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
-				const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
-				pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v0;
+			if (xs < lim) {
+				for (int x = xs + lane * N0; x < lim; x += 64 * N0) {
+					const int e = (int)__umulhi((uint32_t)(ph + x), p.D_magic);
+					const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
+					const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
+					const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
+					const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
+					const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
+					pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v0;
+				}
+				do xs += N0; while (xs < lim);  // wave-uniform
 			}
 		}
+		xs -= kTileSamples;
 		__builtin_amdgcn_wave_barrier();
 		const uint32_t Plast = lds[ScanLds::scratch];
 		last_out = lds[ScanLds::scratch + 1];
@@ -562,6 +580,7 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.mode = c.mode; p.output_scale = c.output_scale;
 	p.D = c.downsample; p.q4096 = kTileSamples / p.D; p.r4096 = kTileSamples % p.D;
+	p.D_magic = (uint32_t)((0x100000000ull + (uint64_t)p.D - 1) / (uint64_t)p.D);
 	p.out_cap = kTileSamples / p.D + 2;
 	const long long run_bytes = (long long)nblocks * c.block_len;
 	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, (int)((run_bytes + kTileBytes - 1) / kTileBytes));

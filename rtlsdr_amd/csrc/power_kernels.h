@@ -62,6 +62,9 @@ struct ScanParams {
 	// frames' bytes comb by comb, window16 = the window likewise, ave = remove_dc's averages per frame, work = where
 	// the blocks go after stage 13
 	int comb_c; size_t comb_blocks; const int2 *ave; uint32_t *work;
+	// k_power_scan_frames<E, true>: decimated reads as packed (I, Q) int16 pairs, 2^dec_e points each, a stream's reads back
+	// to back (k_power_downsample_iq / k_power_boxcar leave them so)
+	const uint32_t *dec32; size_t dec32_stream_stride; int dec_e;
 };
 
 // FIX_MPY, src/rtl_power.c:263-269
@@ -564,21 +567,30 @@ __global__ void __launch_bounds__(kThreads, 4) k_power_scan_big(const ScanParams
 // sums over the reads, and at the end the workgroup adds them up per bin in LDS (ds_add_u64 / ds_max_u64 on the
 // points' area) before N global atomics.  Before: k_power_scan's byte loads and scalar phases, 100-150 Gsamples/s
 // where the 8192-bin kernel runs 380.
-template <int E>
+// SRC16 (round 5): the reads are DECIMATED ones - packed (I, Q) int16 pairs from k_power_downsample_iq (-F) or
+// k_power_boxcar, 2^dec_e >= 512 points each - and one "read" of this kernel is the M / 2^dec_e consecutive reads of
+// the stream that fill its M points (a trailing group that the stream's reads do not fill is topped up with zeros:
+// zero samples with a zero average transform to zero power).  remove_dc (src/rtl_power.c:581-596, called on
+// buf_len / ds elements, :692-693) runs per decimated read: a wave's 512 points lie inside one read, and the read's
+// sums are those of its 2^(dec_e - 9) waves.  Everything from the placement on is the same.
+template <int E, bool SRC16 = false>
 __global__ void __launch_bounds__(kThreads) k_power_scan_frames(const ScanParams p)
 {
 	constexpr int M = 1 << E;
 	constexpr int P = M / kThreads;  // points per thread: 8 or 16
-	constexpr int V = P / 8;
+	constexpr int V = SRC16 ? P / 4 : P / 8;  // 16-byte loads per thread
 	extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
 	uint32_t *pts = sm;                       // [skewed_size(M)]
 	uint32_t *tw = sm + skewed_size(M);       // [N]
 	__shared__ int red[2][kThreads / 64];
-	const int BE = p.bin_e, N = 1 << BE;      // 3 <= BE < E
+	const int BE = p.bin_e, N = 1 << BE;      // 3 <= BE < E (SRC16: <= dec_e)
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const size_t s = blockIdx.x / p.groups;
 	const int grp = (int)(blockIdx.x % p.groups);
-	const int r_begin = (int)((long long)grp * p.nreads / p.groups), r_end = (int)((long long)(grp + 1) * p.nreads / p.groups);
+	// SRC16: the unit of the loop is a group of `per` decimated reads
+	const int per = SRC16 ? M >> p.dec_e : 1;
+	const int units = SRC16 ? (p.nreads + per - 1) / per : p.nreads;
+	const int r_begin = (int)((long long)grp * units / p.groups), r_end = (int)((long long)(grp + 1) * units / p.groups);
 	if (r_begin >= r_end) return;
 	for (int k = t; k < N; k += kThreads) tw[k] = p.tw[k];
 	const int j0 = t * P;                     // the thread's points j0 .. j0 + P - 1: a wave reads 64 P contiguous points
@@ -600,19 +612,33 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_frames(const ScanParams
 	long long acc[P];
 #pragma unroll
 	for (int k = 0; k < P; k++) acc[k] = 0;
-	const uint8_t *base = p.iq8 + s * p.stride8 + 2 * (size_t)j0;
+	const uint8_t *base = SRC16 ? reinterpret_cast<const uint8_t *>(p.dec32 + s * p.dec32_stream_stride + (size_t)j0)
+	                            : p.iq8 + s * p.stride8 + 2 * (size_t)j0;
+	const size_t unit_bytes = SRC16 ? (size_t)4 * M : (size_t)p.buf_len;
+	// SRC16: the decimated read this thread's points belong to, inside the unit; reads the stream does not have read as zeros
+	const int my_read = SRC16 ? j0 >> p.dec_e : 0;
 	uint4 cur[V], nxt[V];
+	auto load_unit = [&](uint4 (&d4)[V], int u) {
+		const bool there = !SRC16 || u * per + my_read < p.nreads;
 #pragma unroll
-	for (int v = 0; v < V; v++) cur[v] = reinterpret_cast<const uint4 *>(base + (size_t)r_begin * p.buf_len)[v];
+		for (int v = 0; v < V; v++) d4[v] = there ? reinterpret_cast<const uint4 *>(base + (size_t)u * unit_bytes)[v] : make_uint4(0, 0, 0, 0);
+	};
+	load_unit(cur, r_begin);
 	auto dc_partial = [&](const uint4 (&d4)[V]) {
-		int si = -127 * P, sq = -127 * P;
+		int si = SRC16 ? 0 : -127 * P, sq = SRC16 ? 0 : -127 * P;
 #pragma unroll
 		for (int v = 0; v < V; v++) {
 			const uint32_t d[4] = {d4[v].x, d4[v].y, d4[v].z, d4[v].w};
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
-				si = (int)__builtin_amdgcn_udot4(d[q], 0x00010001u, (uint32_t)si, false);
-				sq = (int)__builtin_amdgcn_udot4(d[q], 0x01000100u, (uint32_t)sq, false);
+				if (SRC16) {
+					const pk16_t one_i = {1, 0}, one_q = {0, 1};
+					si = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk16_t, d[q]), one_i, si, false);
+					sq = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk16_t, d[q]), one_q, sq, false);
+				} else {
+					si = (int)__builtin_amdgcn_udot4(d[q], 0x00010001u, (uint32_t)si, false);
+					sq = (int)__builtin_amdgcn_udot4(d[q], 0x01000100u, (uint32_t)sq, false);
+				}
 			}
 		}
 		si = wave_total(si);
@@ -625,6 +651,18 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_frames(const ScanParams
 		part += __builtin_amdgcn_update_dpp(0, part, 0x112, 0xf, 0xf, false);
 		part += __builtin_amdgcn_update_dpp(0, part, 0x114, 0xf, 0xf, false);
 		part += __builtin_amdgcn_update_dpp(0, part, 0x118, 0xf, 0xf, false);
+		if (SRC16) {
+			// lanes 0-15 hold the running sums of the sixteen waves' I parts, 16-31 those of the Q parts: this wave's read
+			// is the waves [first, first + wpr)
+			const int wpr_e = p.dec_e - 9;
+			const int first = __builtin_amdgcn_readfirstlane((wave >> wpr_e) << wpr_e), last = first + (1 << wpr_e) - 1;
+			int sumI = __builtin_amdgcn_readlane(part, last), sumQ = __builtin_amdgcn_readlane(part, 16 + last);
+			if (first > 0) { sumI -= __builtin_amdgcn_readlane(part, first - 1); sumQ -= __builtin_amdgcn_readlane(part, 16 + first - 1); }
+			const int len = 2 << p.dec_e;  // elements of the decimated read
+			ai = (int)(int16_t)(sumI / len);
+			aq = (int)(int16_t)(sumQ / (len - 1));
+			return;
+		}
 		ai = (int)(int16_t)(__builtin_amdgcn_readlane(part, 15) / (2 * M));
 		aq = (int)(int16_t)(__builtin_amdgcn_readlane(part, 31) / (2 * M - 1));
 	};
@@ -636,21 +674,23 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_frames(const ScanParams
 	for (int r = r_begin; r < r_end; r++) {
 		// ---- B: convert, DC, window on packed pairs (as k_power_scan_big), placement ----
 		typedef unsigned short upk16_t __attribute__((ext_vector_type(2)));
-		const upk16_t dcw = {(unsigned short)(127 + ai), (unsigned short)(127 + aq)};
+		const upk16_t dcw = {(unsigned short)((SRC16 ? 0 : 127) + ai), (unsigned short)((SRC16 ? 0 : 127) + aq)};
 #pragma unroll
 		for (int k = 0; k < P; k++) {
-			const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
-			const upk16_t iq = __builtin_bit_cast(upk16_t, __builtin_amdgcn_perm(0u, d, (k & 1) ? 0x0c030c02u : 0x0c010c00u));
+			upk16_t iq;
+			if (SRC16) {
+				iq = __builtin_bit_cast(upk16_t, (&cur[k / 4].x)[k & 3]);
+			} else {
+				const uint32_t d = (&cur[k / 8].x)[(k / 2) & 3];
+				iq = __builtin_bit_cast(upk16_t, __builtin_amdgcn_perm(0u, d, (k & 1) ? 0x0c030c02u : 0x0c010c00u));
+			}
 			const upk16_t wpair = __builtin_bit_cast(upk16_t, w2[k / 2]);
 			const unsigned short wk = (k & 1) ? wpair.y : wpair.x;
 			const upk16_t ww = {wk, wk};
 			pts[scatter[k]] = __builtin_bit_cast(uint32_t, (upk16_t)((upk16_t)(iq - dcw) * ww));
 		}
 		const bool more = r + 1 < r_end;
-		if (more) {
-#pragma unroll
-			for (int v = 0; v < V; v++) nxt[v] = reinterpret_cast<const uint4 *>(base + (size_t)(r + 1) * p.buf_len)[v];
-		}
+		if (more) load_unit(nxt, r + 1);
 		__syncthreads();
 		// ---- C: stages 0 .. BE - 1, three per LDS round trip; the radix-8 passes below stage 9 stay inside a wave's
 		// own 512-point blocks (k_power_scan_big), every other step needs the workgroup
@@ -697,7 +737,14 @@ __global__ void __launch_bounds__(kThreads) k_power_scan_frames(const ScanParams
 		if (p.peak_hold) atomicMax(p.avg + s * N + k, (long long)bins[k]);
 		else atomicAdd(reinterpret_cast<unsigned long long *>(p.avg + s * N + k), bins[k]);
 	}
-	if (t == 0) atomicAdd(p.samples + s, p.ds * p.chunks * (r_end - r_begin));  // :717, once per frame
+	if (t == 0) {  // :717, once per frame
+		if (SRC16) {
+			const int reads = min(p.nreads, r_end * per) - r_begin * per;  // the stream's own reads in this group's units
+			atomicAdd(p.samples + s, p.ds * ((1 << p.dec_e) >> BE) * reads);
+		} else {
+			atomicAdd(p.samples + s, p.ds * p.chunks * (r_end - r_begin));
+		}
+	}
 }
 
 // ---- transforms that do not fit one workgroup's LDS: bin_e 15 ... 21, or more frames per read than 16384 points ----
@@ -1153,6 +1200,151 @@ __global__ void __launch_bounds__(256) k_power_fir9(const int16_t *in, int16_t *
 		for (int k = 0; k < 9; k++) { hi[k] = x[2 * (n - 9 + k)]; hq[k] = x[2 * (n - 9 + k) + 1]; }
 		y[2 * n] = (int16_t)rtlfm::fir9_tap(hi, rtlfm::k_cic9[passes]);
 		y[2 * n + 1] = (int16_t)rtlfm::fir9_tap(hq, rtlfm::k_cic9[passes]);
+	}
+}
+
+// ---- -F in ONE launch (round 5): u8 -> (-127) -> downsample_iq x passes -> generic_fir -> packed int16 pairs ----
+// downsample_iq (src/rtl_power.c:628-634) runs the stateless fifth_order (:554-579) over I and Q: output m of a pass
+// needs the inputs 2m - 5 .. 2m of the pass before (the first five outputs of a READ are the ease-in forms below), so
+// a tile of final outputs needs 5 (2^passes - 1) more input samples than it decimates - the passes run tile by tile
+// in LDS, every level's samples as packed (I, Q) int16 pairs, ping-pong between two areas.  The general kernels
+// (k_power_fifth per pass, k_power_fir9) went through HBM once per pass with 2-byte accesses: 57-59 Gsamples/s where
+// the undecimated scans run 320-560 (profiles/r04_power_small.txt).
+//   * passes 0-2 in packed 16-bit arithmetic: the taps sum to 32, the bytes span -127 .. 128, so the sum of pass p is
+//     at most 32 * 128 * 2^p <= 16384 for p <= 2 - three v_pk_add, two v_pk_mad, one v_pk_ashr per complex output;
+//     later passes (1/8 of the data and less) in 32 bits, the reference's `int` arithmetic with its int16 stores;
+//   * generic_fir (:598-626) on the last level: the first nine samples pass, sample n >= 9 is the tap sum over the
+//     nine ORIGINAL samples n - 9 .. n - 1 (`hist` is fed from `temp`);
+//   * output: dword n of read r of stream s = the decimated sample n - what k_power_scan_frames<E, true> loads.
+struct DecimateParams {
+	const uint8_t *iq8; size_t stride8;  // raw reads: 16-byte aligned rows, buf_len a multiple of 16
+	int nreads, buf_len;
+	int passes;                         // 1 .. kDecMaxPasses
+	int fir;                            // 9: generic_fir with cic_9_tables[passes] behind the passes
+	uint32_t *out; size_t out_stream_stride;  // dwords
+	int out_per_read;                   // (buf_len / 2) >> passes
+	int tile_out, tiles_per_read;
+	size_t total_tiles;
+};
+constexpr int kDecMaxPasses = 6;
+constexpr int kDecTileIn = 4096;        // input samples a tile decimates (before the halo)
+// dwords of LDS: level 0 holds the tile's input samples, the passes' reach-back (five samples per pass, rounded to even
+// indices), the filter's nine samples of the last level and the rounding to 16-byte pieces; level 1 half of that
+constexpr int kDecLdsA = kDecTileIn + 6 * 63 + 9 * 64 + 64, kDecLdsB = kDecLdsA / 2 + 16;
+
+__device__ __forceinline__ uint32_t fifth_pk(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+	const pk16_t t1 = __builtin_bit_cast(pk16_t, b) + __builtin_bit_cast(pk16_t, e);
+	const pk16_t t2 = __builtin_bit_cast(pk16_t, c) + __builtin_bit_cast(pk16_t, d);
+	const pk16_t s0 = __builtin_bit_cast(pk16_t, a) + __builtin_bit_cast(pk16_t, f);
+	const pk16_t five = {5, 5}, ten = {10, 10};
+	return __builtin_bit_cast(uint32_t, (pk16_t)((t1 * five + s0 + t2 * ten) >> 4));
+}
+__device__ __forceinline__ uint32_t fifth_32(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f)
+{
+	const iq16 A = unpack_iq(a), B = unpack_iq(b), C = unpack_iq(c), D = unpack_iq(d), E = unpack_iq(e), F = unpack_iq(f);
+	const int vi = ((int)A.i + ((int)B.i + E.i) * 5 + ((int)C.i + D.i) * 10 + F.i) >> 4;
+	const int vq = ((int)A.q + ((int)B.q + E.q) * 5 + ((int)C.q + D.q) * 10 + F.q) >> 4;
+	return pack_iq((int16_t)vi, (int16_t)vq);
+}
+
+template <int P>  // passes
+__global__ void __launch_bounds__(256) k_power_downsample_iq(const DecimateParams p)
+{
+	static_assert(P >= 1 && P <= kDecMaxPasses, "the LDS areas are sized for six passes");
+	__shared__ __attribute__((aligned(16))) uint32_t bufA[kDecLdsA];
+	__shared__ __attribute__((aligned(16))) uint32_t bufB[kDecLdsB];
+	const int t = threadIdx.x;
+	for (size_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+		const int tl = (int)(tile % p.tiles_per_read);
+		const size_t sr = tile / p.tiles_per_read;
+		const int r = (int)(sr % p.nreads);
+		const size_t s = sr / p.nreads;
+		const int o0 = tl * p.tile_out, o1 = min(o0 + p.tile_out, p.out_per_read);
+		// what each level must hold: lo[k] .. hi[k] - 1 of level k (level 0 = the input samples, level P = the last pass's outputs)
+		int lo[P + 1], hi[P + 1];
+		lo[P] = p.fir ? max(0, o0 - 9) : o0;
+		hi[P] = o1;
+#pragma unroll
+		for (int k = P - 1; k >= 0; k--) {
+			const int len = (p.buf_len / 2) >> k;
+			lo[k] = max(0, 2 * lo[k + 1] - 5) & ~1;            // even: the pairs of a level sit on 8-byte boundaries
+			hi[k] = min(len, max(2 * (hi[k + 1] - 1), 5) + 1);
+		}
+		lo[0] &= ~7;  // whole 16-byte pieces of the read
+		__syncthreads();  // the tile before is done with the LDS areas
+		// ---- level 0: the bytes, as packed (I - 127, Q - 127)
+		{
+			const uint8_t *raw = p.iq8 + s * p.stride8 + (size_t)r * p.buf_len;
+			const int c0 = lo[0] >> 3, c1 = (hi[0] + 7) >> 3;
+			for (int c = c0 + t; c < c1; c += 256) {
+				const uint4 v = *reinterpret_cast<const uint4 *>(raw + (size_t)c * 16);
+				const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+				uint32_t o[8];
+				const pk16_t off = {127, 127};
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					o[2 * q] = __builtin_bit_cast(uint32_t, (pk16_t)(__builtin_bit_cast(pk16_t, __builtin_amdgcn_perm(0u, d[q], 0x0c010c00u)) - off));
+					o[2 * q + 1] = __builtin_bit_cast(uint32_t, (pk16_t)(__builtin_bit_cast(pk16_t, __builtin_amdgcn_perm(0u, d[q], 0x0c030c02u)) - off));
+				}
+				uint4 *dst = reinterpret_cast<uint4 *>(bufA + (c - c0) * 8);
+				dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+				dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+			}
+		}
+		__syncthreads();
+		// ---- the passes: level k in `src` (index 0 = sample lo[k]) -> level k + 1 in `dst`
+		uint32_t *src = bufA, *dst = bufB;
+#pragma unroll
+		for (int k = 0; k < P; k++) {
+			const int b0 = lo[k], n0 = lo[k + 1], n1 = hi[k + 1];
+			// the general form for every output (indices clamped at the level's first sample: outputs 0 .. 4 of a read
+			// are overwritten below)
+			for (int m = n0 + t; m < n1; m += 256) {
+				const int i5 = max(2 * m - 5 - b0, 0);  // odd unless clamped: b32, two aligned b64, b32
+				uint32_t a, b, c, d, e, f;
+				if (2 * m - 5 >= b0) {
+					a = src[i5];
+					const uint2 bc = *reinterpret_cast<const uint2 *>(src + i5 + 1), de = *reinterpret_cast<const uint2 *>(src + i5 + 3);
+					b = bc.x; c = bc.y; d = de.x; e = de.y;
+					f = src[i5 + 5];
+				} else {
+					a = b = c = d = e = f = 0;  // m < 5 at the start of a read
+				}
+				dst[m - n0] = k < 3 ? fifth_pk(a, b, c, d, e, f) : fifth_32(a, b, c, d, e, f);
+			}
+			if (n0 < 5) {
+				// ease-in (src/rtl_power.c:559-569 and the first two rounds of the loop, where d and e are both data[10]):
+				// with x(k) = sample k of this level
+				__syncthreads();
+				if (t < 5 && t >= n0 && t < n1) {
+					auto X = [&](int q) { return unpack_iq(src[q - b0]); };  // b0 == 0 here
+					int vi, vq;
+					const iq16 x0 = X(0), x1 = X(1), x2 = X(2), x3 = X(3), x4 = X(4), x5 = X(5);
+					if (t == 0) { vi = ((x0.i + x1.i) * 10 + (x2.i + x3.i) * 5 + x3.i + x5.i) >> 4; vq = ((x0.q + x1.q) * 10 + (x2.q + x3.q) * 5 + x3.q + x5.q) >> 4; }
+					else if (t == 1) { vi = ((x1.i + x2.i) * 10 + (x0.i + x3.i) * 5 + x4.i + x5.i) >> 4; vq = ((x1.q + x2.q) * 10 + (x0.q + x3.q) * 5 + x4.q + x5.q) >> 4; }
+					else if (t == 2) { vi = (x0.i + (x1.i + x4.i) * 5 + (x2.i + x3.i) * 10 + x5.i) >> 4; vq = (x0.q + (x1.q + x4.q) * 5 + (x2.q + x3.q) * 10 + x5.q) >> 4; }
+					else if (t == 3) { const iq16 x6 = X(6); vi = (x2.i + (x3.i + x5.i) * 5 + (x4.i + x5.i) * 10 + x6.i) >> 4; vq = (x2.q + (x3.q + x5.q) * 5 + (x4.q + x5.q) * 10 + x6.q) >> 4; }
+					else { const iq16 x6 = X(6), x7 = X(7), x8 = X(8); vi = (x4.i + (x5.i + x7.i) * 5 + (x5.i + x6.i) * 10 + x8.i) >> 4; vq = (x4.q + (x5.q + x7.q) * 5 + (x5.q + x6.q) * 10 + x8.q) >> 4; }
+					dst[t - n0] = pack_iq((int16_t)vi, (int16_t)vq);
+				}
+			}
+			__syncthreads();
+			uint32_t *tmp = src; src = dst; dst = tmp;
+		}
+		// ---- generic_fir and the store
+		uint32_t *orow = p.out + s * p.out_stream_stride + (size_t)r * p.out_per_read;
+		const int bP = lo[P];
+		for (int n = o0 + t; n < o1; n += 256) {
+			uint32_t v = src[n - bP];
+			if (p.fir && n >= 9) {
+				int hi_[9], hq_[9];
+#pragma unroll
+				for (int q = 0; q < 9; q++) { const iq16 x = unpack_iq(src[n - 9 + q - bP]); hi_[q] = x.i; hq_[q] = x.q; }
+				v = pack_iq((int16_t)rtlfm::fir9_tap(hi_, rtlfm::k_cic9[P]), (int16_t)rtlfm::fir9_tap(hq_, rtlfm::k_cic9[P]));
+			}
+			orow[n] = v;
+		}
 	}
 }
 

@@ -50,6 +50,12 @@ struct rtlpower_gpu {
 	uint16_t *d_window16T = nullptr; uint8_t *d_tbuf = nullptr; int2 *d_part = nullptr; bool attr_comb = false;
 	int scan_frames = 1;  // option "scan_frames": 0 = k_power_scan also where k_power_scan_frames applies (A/B, tests)
 	bool attr_frames = false;
+	// decimated scans (a range below 1 MHz, src/rtl_power.c:466-480) in two launches: k_power_downsample_iq (-F) or
+	// k_power_boxcar into packed int16 pairs, k_power_scan_frames<13, true> on them
+	int dec_fast = 1;     // option "dec_fast": 0 = the general kernels (one launch per pass, k_power_scan) also where these apply
+	uint32_t *d_dec32 = nullptr; size_t dec32_cap = 0;  // dwords
+	bool attr_frames16 = false;
+	int last_kernel = 0;  // option "last_kernel" (read-only): which transform kernel the last scan took (RTLPOWER_KERNEL_*)
 	int staged_fast = 1;  // option "staged_fast": 0 = the general kernels also where the fast ones apply (A/B, tests)
 	size_t work_reads = 0;                 // reads the work buffer holds per stream
 	bool attr_lds = false;
@@ -330,7 +336,7 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 		if (e) (void)hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one, h->d_stamps, h->d_work, h->d_ave, h->d_window16T, h->d_tbuf, h->d_part};
+	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one, h->d_stamps, h->d_work, h->d_ave, h->d_window16T, h->d_tbuf, h->d_part, h->d_dec32};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -398,10 +404,25 @@ extern "C" int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long v
 		h->staged_fast = value != 0;
 		return 0;
 	}
+	if (!strcmp(name, "dec_fast")) {
+		h->dec_fast = value != 0;
+		return 0;
+	}
 	if (!strcmp(name, "scan_frames")) {
 		h->scan_frames = value != 0;
 		return 0;
 	}
+	return -ENOENT;
+}
+
+extern "C" int rtlpower_gpu_get_option(rtlpower_gpu *h, const char *name, long *value)
+{
+	if (!h || !name || !value) return -EINVAL;
+	if (!strcmp(name, "groups")) { *value = h->groups; return 0; }
+	if (!strcmp(name, "staged_fast")) { *value = h->staged_fast; return 0; }
+	if (!strcmp(name, "dec_fast")) { *value = h->dec_fast; return 0; }
+	if (!strcmp(name, "scan_frames")) { *value = h->scan_frames; return 0; }
+	if (!strcmp(name, "last_kernel")) { *value = h->last_kernel; return 0; }
 	return -ENOENT;
 }
 
@@ -484,6 +505,79 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		k_power_rms<<<S, 256, 0, q>>>(d_iq, stream_stride, nreads, (int)c.buf_len, c.peak_hold, h->d_avg, h->d_samples);
 		HIP_TRY(hipGetLastError());
 		return 0;
+	}
+	// ---- a decimated scan whose reads are whole frames of at least 512 points: two launches (power_kernels.h) ----
+	{
+		const int Pr = h->len_dec / 2;  // points of a decimated read
+		const bool pow2 = Pr >= 512 && Pr <= 8192 && (Pr & (Pr - 1)) == 0 && h->len_dec == 2 * Pr;
+		const bool aligned = !(stream_stride & 15) && !((uintptr_t)d_iq & 15) && !(c.buf_len & 15);
+		const bool by_fifth = !c.boxcar && c.downsample_passes >= 1 && c.downsample_passes <= kDecMaxPasses &&
+		                      (int)((c.buf_len / 2) >> c.downsample_passes) == Pr;
+		const bool by_boxcar = c.boxcar && c.downsample > 1 && (int)(c.buf_len / 2) == Pr * c.downsample;
+		if (h->dec_fast && h->decimates && !h->staged && pow2 && aligned && c.bin_e >= 3 && h->N <= Pr && (by_fifth || by_boxcar)) {
+			const size_t need = (size_t)S * nreads * Pr;
+			if (h->dec32_cap < need) {
+				HIP_TRY(hipStreamSynchronize(q));
+				if (h->d_dec32) (void)hipFree(h->d_dec32);
+				h->d_dec32 = nullptr; h->dec32_cap = 0;
+				HIP_TRY(hipMalloc(&h->d_dec32, need * sizeof(uint32_t)));
+				h->dec32_cap = need;
+			}
+			std::pair<hipEvent_t, hipEvent_t> ev;
+			if (h->timing) {
+				if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); }
+				else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+				HIP_TRY(hipEventRecord(ev.first, q));
+			}
+			if (by_fifth) {
+				DecimateParams dp{};
+				dp.iq8 = d_iq; dp.stride8 = stream_stride; dp.nreads = nreads; dp.buf_len = (int)c.buf_len;
+				dp.passes = c.downsample_passes; dp.fir = c.comp_fir_size;
+				dp.out = h->d_dec32; dp.out_stream_stride = (size_t)nreads * Pr; dp.out_per_read = Pr;
+				dp.tile_out = kDecTileIn >> c.downsample_passes;
+				dp.tiles_per_read = (Pr + dp.tile_out - 1) / dp.tile_out;
+				dp.total_tiles = (size_t)S * nreads * dp.tiles_per_read;
+				const unsigned g = (unsigned)(dp.total_tiles < 256 * 20 ? dp.total_tiles : 256 * 20);
+				switch (c.downsample_passes) {
+				case 1: k_power_downsample_iq<1><<<g, 256, 0, q>>>(dp); break;
+				case 2: k_power_downsample_iq<2><<<g, 256, 0, q>>>(dp); break;
+				case 3: k_power_downsample_iq<3><<<g, 256, 0, q>>>(dp); break;
+				case 4: k_power_downsample_iq<4><<<g, 256, 0, q>>>(dp); break;
+				case 5: k_power_downsample_iq<5><<<g, 256, 0, q>>>(dp); break;
+				default: k_power_downsample_iq<6><<<g, 256, 0, q>>>(dp); break;
+				}
+			} else {
+				k_power_boxcar<<<grid_for((size_t)S * nreads * Pr), 256, 0, q>>>(
+				    d_iq, stream_stride, nreads, (int)c.buf_len, c.downsample, S, reinterpret_cast<int16_t *>(h->d_dec32),
+				    (size_t)nreads * 2 * Pr, (size_t)2 * Pr, Pr);
+			}
+			ScanParams p{};
+			p.dec32 = h->d_dec32; p.dec32_stream_stride = (size_t)nreads * Pr;
+			for (p.dec_e = 9; (1 << p.dec_e) < Pr; p.dec_e++) {}
+			p.nreads = nreads; p.bin_e = c.bin_e; p.ds = c.downsample; p.peak_hold = c.peak_hold;
+			p.window16 = h->d_window16; p.tw = h->d_tw; p.avg = h->d_avg; p.samples = h->d_samples;
+			constexpr int M = 8192;
+			const int units = (nreads + (M / Pr) - 1) / (M / Pr);
+			int groups = (512 + S - 1) / S;
+			if (h->groups > 0) groups = h->groups;
+			if (groups > units) groups = units;
+			if (groups < 1) groups = 1;
+			p.groups = groups;
+			if (!h->attr_frames16) {
+				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_power_scan_frames<13, true>),
+				                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+				h->attr_frames16 = true;
+			}
+			const size_t lds16 = ((size_t)skewed_size(M) + (size_t)h->N) * 4;
+			hipLaunchKernelGGL((k_power_scan_frames<13, true>), dim3((unsigned)S * (unsigned)groups), dim3(kThreads), lds16, q, p);
+			h->last_kernel = RTLPOWER_KERNEL_DECIMATED;
+			HIP_TRY(hipGetLastError());
+			if (h->timing) {
+				HIP_TRY(hipEventRecord(ev.second, q));
+				h->ev_pending.push_back(ev);
+			}
+			return 0;
+		}
 	}
 	const int16_t *dec = nullptr;
 	size_t dss = 0, drs = 0;
@@ -601,6 +695,7 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 				st += R;
 			}
 			if (c.bin_e <= 14) k_power_accum<<<grid_for((size_t)S * h->N, 256, 256 * 64), 256, 0, q>>>(sp);
+			h->last_kernel = fast ? RTLPOWER_KERNEL_STAGED_FAST : RTLPOWER_KERNEL_STAGED;
 		}
 		HIP_TRY(hipGetLastError());
 		if (h->timing) {
@@ -677,6 +772,7 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 	else if (frames && M == 8192) hipLaunchKernelGGL(k_power_scan_frames<13>, dim3(grid), dim3(kThreads), lds, q, p);
 	else if (frames) hipLaunchKernelGGL(k_power_scan_frames<14>, dim3(grid), dim3(kThreads), lds, q, p);
 	else hipLaunchKernelGGL(k_power_scan, dim3(grid), dim3(kThreads), lds, q, p);
+	h->last_kernel = big ? RTLPOWER_KERNEL_BIG : frames ? RTLPOWER_KERNEL_FRAMES : RTLPOWER_KERNEL_GENERAL;
 	HIP_TRY(hipGetLastError());
 	if (h->timing) {
 		HIP_TRY(hipEventRecord(ev.second, q));
@@ -700,15 +796,19 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	view.d_decA = view.d_decB = nullptr; view.dec_cap_reads = 0;
 	view.d_work = nullptr; view.d_ave = nullptr; view.work_reads = 0;
 	view.d_tbuf = nullptr; view.d_part = nullptr;
+	view.d_dec32 = nullptr; view.dec32_cap = 0;
+	view.want_stamps = false;  // (the stamp buffer would be the view's: one leak per scan, and nothing for rtlpower_gpu_clock_read to find)
 	view.ev_pending.clear(); view.ev_free.clear(); view.timing = false;
 	int r = rtlpower_gpu_scan_device(&view, h->d_one, h->cfg.buf_len, 1);
 	// what the view learnt about this device stays learnt (the kernels' dynamic-LDS limits are raised once per handle)
 	h->attr_set = view.attr_set; h->attr_big = view.attr_big; h->attr_lds = view.attr_lds; h->attr_comb = view.attr_comb;
-	h->attr_frames = view.attr_frames;
+	h->attr_frames = view.attr_frames; h->attr_frames16 = view.attr_frames16;
+	h->last_kernel = view.last_kernel;
 	const hipError_t e = hipStreamSynchronize(h->stream);
 	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }  // also when the sync failed
 	if (view.d_work) { (void)hipFree(view.d_work); (void)hipFree(view.d_ave); }
 	if (view.d_tbuf) { (void)hipFree(view.d_tbuf); (void)hipFree(view.d_part); }
+	if (view.d_dec32) (void)hipFree(view.d_dec32);
 	if (e != hipSuccess) return -EIO;
 	return r;
 }

@@ -70,8 +70,18 @@ class GpuPower:
         check(self.lib.rtlpower_gpu_clear(self._h), "rtlpower_gpu_clear")
 
     def set_option(self, name: str, value: int):
-        """Tunables by name (include/rtlpower_hip.h): "groups", "pair"."""
+        """Tunables by name (include/rtlpower_hip.h): "groups", "staged_fast", "scan_frames", "dec_fast"."""
         check(self.lib.rtlpower_gpu_set_option(self._h, name.encode(), int(value)), f"rtlpower_gpu_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_long()
+        check(self.lib.rtlpower_gpu_get_option(self._h, name.encode(), C.byref(v)), f"rtlpower_gpu_get_option({name})")
+        return v.value
+
+    @property
+    def last_kernel(self) -> int:
+        """Which transform the last scan took (RTLPOWER_KERNEL_*: 1 general, 2 big, 3 frames, 4 decimated, 5 / 6 staged)."""
+        return self.get_option("last_kernel")
 
     def sync(self):
         check(self.lib.rtlpower_gpu_sync(self._h), "rtlpower_gpu_sync")

@@ -128,6 +128,58 @@ def test_power_random_configurations(oracle_lib, seed):
             assert np.array_equal(res[s][0], want[s]), (kw, s, split, frames)
 
 
+
+def _decimated_cases():
+    """What frequency_range() plans for a range below 1 MHz (src/rtl_power.c:466-504): buf_len = 2 N ds, at least 16384."""
+    cases = []
+    for passes in (1, 2, 3, 4, 5, 6):
+        for bin_e in (3, 7, 9, 10, 11, 12, 13):
+            L = max(16384, (2 << bin_e) << passes)
+            per = (L >> passes) // 2
+            if per < 512 or per > 8192:
+                continue
+            for fir in (0, 9):
+                cases.append(dict(bin_e=bin_e, window=(bin_e + passes) % 8, downsample=1 << passes, downsample_passes=passes, boxcar=0,
+                                  comp_fir_size=fir, buf_len=L, peak_hold=int((bin_e + passes) % 5 == 0)))
+    for ds in (2, 4, 7, 8, 14, 16):
+        for bin_e in (5, 9, 10, 12):
+            L = max(16384, (2 << bin_e) * ds)
+            cases.append(dict(bin_e=bin_e, window=(bin_e + ds) % 8, downsample=ds, boxcar=1, buf_len=L))
+    return cases
+
+
+@pytest.mark.parametrize("kw", _decimated_cases(), ids=lambda kw: "-".join(f"{k[:3]}{v}" for k, v in kw.items() if k in ("bin_e", "downsample", "boxcar", "comp_fir_size", "buf_len")))
+def test_power_decimated_scans(oracle_lib, kw):
+    """A scan of a range below 1 MHz decimates in front of the FFT (downsample_iq x passes + generic_fir with -F, the boxcar
+    without: src/rtl_power.c:671-691).  Where the decimated read is whole frames of 512 ... 8192 points the library takes
+    k_power_downsample_iq / k_power_boxcar + k_power_scan_frames<13, true> (last_kernel == 4); the general kernels (option
+    dec_fast = 0) and the oracle must give the same integers: FM signal and full-scale bytes, read counts that do and do
+    not fill the scan kernel's groups of reads, reads split over launches and over workgroups."""
+    from rtlsdr_amd.power import GpuPower
+    cfg = RtlpowerCfg.default(**kw)
+    L = int(cfg.buf_len)
+    per = (L // int(cfg.downsample)) // 2
+    fast_expected = (512 <= per <= 8192 and per & (per - 1) == 0 and (L // 2) % int(cfg.downsample) == 0 and (1 << cfg.bin_e) <= per)
+    for nr, ns in ((5, 3), (16, 2)):
+        iq = np.concatenate([synth.fm_iq_u8(ns, L // 2 * nr, fs=2.048e6, dev_hz=30e3, seed=300 + cfg.bin_e),
+                             synth.random_u8(1, L * nr, seed=400 + cfg.bin_e)])
+        want, wn = oracle_lib.power_scan_batch(cfg, iq, nthreads=4)
+        for opts, split in ((dict(), None), (dict(), 2), (dict(groups=3), None), (dict(dec_fast=0), None)):
+            with GpuPower(cfg, ns + 1, 0) as g:
+                for k, v in opts.items():
+                    g.set_option(k, v)
+                d = torch.from_numpy(iq).cuda()
+                if split:
+                    g.scan_torch(d[:, :split * L].contiguous()); g.scan_torch(d[:, split * L:].contiguous())
+                else:
+                    g.scan_torch(d)
+                g.sync()
+                assert (g.last_kernel == 4) == (fast_expected and opts.get("dec_fast", 1) == 1), (kw, opts, g.last_kernel)
+                for s in range(ns + 1):
+                    avg, samples = g.fetch(s)
+                    assert samples == wn[s], (kw, opts, split, s)
+                    assert np.array_equal(avg, want[s]), (kw, opts, split, s, nr)
+
 @pytest.mark.parametrize("bin_e", list(range(3, 14)))
 @pytest.mark.parametrize("L", [16384, 32768])
 def test_power_several_frames_per_read(oracle_lib, bin_e, L):
