@@ -66,6 +66,7 @@ struct rtlfm_gpu {
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
 	int32_t *d_arb_i = nullptr;           // k_deemph_spec_arb: (i, frac) of every output of a buffer, [arb_len2]
 	double *d_arb_frac = nullptr;
+	ArbTab *d_arb_tab = nullptr;          // k_deemph_arb_span: the same as one 16-byte entry per output
 	int arb_len2 = 0, arb_len1 = 0;
 	int deemph_chunks = 0;   // capacity of d_deemph_tab / d_deemph_inc, chunks per stream
 	int lpr_chunks_cap = 0;  // ... of d_lpr_chunks
@@ -106,6 +107,8 @@ struct rtlfm_gpu {
 	struct Options {
 		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
 		int lpr_chunk = 2720;  // samples per lane of the one-pass deemph + low_pass_real kernel
+		int arb_span = 1;      // 0: k_deemph_spec_arb (round 4's form of config 3's tail) instead of k_deemph_arb_span
+		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
 	} opt;
 
 	// timing of the decimating front end
@@ -439,7 +442,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_arb_tab, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -549,6 +552,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -576,6 +580,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
 	// the chunk tables of the one-pass deemph + low_pass_real kernel are sized from it: keep it in a sane range
 	if (!strcmp(name, "lpr_chunk") && (value < 256 || value > (1 << 20))) return -EINVAL;
+	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;
 	*slot = (int)value;
 	return 0;
 }
@@ -824,26 +829,51 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 					// has them when it writes buf2[j]: walked once here, shared by every stream and buffer
 					std::vector<int32_t> ti((size_t)arb_l2);
 					std::vector<double> tf((size_t)arb_l2);
+					std::vector<ArbTab> tt((size_t)arb_l2);
 					int i = 1, tick = 0;
 					for (int j = 0; j < arb_l2; j++) {
 						ti[j] = i;
 						tf[j] = (double)tick / (double)arb_l2;
+						tt[j] = ArbTab{tf[j], i, 0};
 						tick += Nblk;
 						if (tick > arb_l2) { tick -= arb_l2; i++; }
 						if (i >= Nblk) { i = Nblk - 1; tick = arb_l2; }
 					}
 					HIP_TRY(hipStreamSynchronize(q));  // the tables of another geometry may still be in use
-					if (h->d_arb_i) { HIP_TRY(hipFree(h->d_arb_i)); HIP_TRY(hipFree(h->d_arb_frac)); }
-					h->d_arb_i = nullptr; h->d_arb_frac = nullptr;
+					// the keys say "no tables" until every allocation and copy has succeeded (a failure half way must not
+					// leave the old geometry's keys beside freed or short tables)
+					h->arb_len2 = 0; h->arb_len1 = 0;
+					for (void **pp : {(void **)&h->d_arb_i, (void **)&h->d_arb_frac, (void **)&h->d_arb_tab})
+						if (*pp) { HIP_TRY(hipFree(*pp)); *pp = nullptr; }
 					HIP_TRY(hipMalloc(&h->d_arb_i, ti.size() * sizeof(int32_t)));
 					HIP_TRY(hipMalloc(&h->d_arb_frac, tf.size() * sizeof(double)));
+					HIP_TRY(hipMalloc(&h->d_arb_tab, tt.size() * sizeof(ArbTab)));
 					HIP_TRY(hipMemcpy(h->d_arb_i, ti.data(), ti.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 					HIP_TRY(hipMemcpy(h->d_arb_frac, tf.data(), tf.size() * sizeof(double), hipMemcpyHostToDevice));
+					HIP_TRY(hipMemcpy(h->d_arb_tab, tt.data(), tt.size() * sizeof(ArbTab), hipMemcpyHostToDevice));
 					h->arb_len2 = arb_l2; h->arb_len1 = Nblk;
 				}
 				int16_t *arb_dst = nullptr; size_t arb_ds = 0;
 				next_dst(&arb_dst, &arb_ds);
 				if (arb_dst != final_dst) return -EFAULT;  // routing bug
+				if (h->opt.arb_span) {
+					// round 5's form: the span linear in LDS, 32 or 64 samples per lane (staged_kernels.h, k_deemph_arb_span)
+					const int Cc = h->opt.arb_chunk == 64 ? 64 : 32;
+					const int sp_n = (T + 64 * Cc - 1) / (64 * Cc);
+					const size_t lds_w = (((size_t)(Ws + 64 * Cc) * sizeof(int16_t) + 16) + 15) & ~(size_t)15;
+					int wv = 8192 / S;
+					if (wv > sp_n) wv = sp_n;
+					if (wv > kSpecArbMaxWaves) wv = kSpecArbMaxWaves;
+					if (wv < 1) wv = 1;
+					const int M3 = c.deemph_a == 2 ? 3 : M;
+#define RTLFM_ARB_SPAN(MM, CC) k_deemph_arb_span<MM, CC><<<(unsigned)S, 64 * wv, lds_w * wv, q>>>(cur, cur_stride, T, S, st, Ws, sp_n, Nblk, arb_l2, nblocks, \
+				h->d_arb_tab, arb_dst, arb_ds, sin, sout, lds_w, cnt_dst)
+					if (Cc == 64) { if (M3 == 3) RTLFM_ARB_SPAN(3, 64); else if (M3 == 2) RTLFM_ARB_SPAN(2, 64); else if (M3 == 1) RTLFM_ARB_SPAN(1, 64); else RTLFM_ARB_SPAN(0, 64); }
+					else { if (M3 == 3) RTLFM_ARB_SPAN(3, 32); else if (M3 == 2) RTLFM_ARB_SPAN(2, 32); else if (M3 == 1) RTLFM_ARB_SPAN(1, 32); else RTLFM_ARB_SPAN(0, 32); }
+#undef RTLFM_ARB_SPAN
+					RTLFM_DBG_SYNC("one pass (arb span)");
+					return 0;
+				}
 				const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
 				// a workgroup per stream (nothing crosses workgroups), its spans dealt to up to eight waves: enough
 				// waves in all to fill the GPU when the streams alone do not

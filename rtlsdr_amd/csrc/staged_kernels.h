@@ -511,12 +511,15 @@ k_post_downsample(const int16_t *__restrict__ A, size_t astride, int16_t *__rest
 //   * add / subtract are both formed, the compare that picks one is off the chain.
 // Samples move in 16-byte groups, a 128-byte line at a time with the next line in flight.
 // MAGIC: 0 = hardware division, 1 = multiply-high, 2 = a is a power of two (a = 2 at 16 / 24 kHz,
-// 4 at 44.1 / 48 kHz): a shift, which takes the quarter-rate v_mul_hi_u32 out of the chain
+// 4 at 44.1 / 48 kHz): a shift, which takes the quarter-rate v_mul_hi_u32 out of the chain;
+// 3 = a == 2 (round 5): avg + sign(d) ((|d| + 1) >> 1) is (x + avg + [x > avg]) >> 1 - the mean of the two, the odd
+// half rounded away from avg: add, compare, add-with-carry, shift
 struct DeemphStep {
 	uint32_t a, half, magic;  // magic: M for MAGIC 1, log2(a) for MAGIC 2
 	template <int MAGIC>
 	__device__ __forceinline__ uint32_t step(uint32_t xb, uint32_t avgb) const
 	{
+		if (MAGIC == 3) return (xb + avgb + (xb > avgb ? 1u : 0u)) >> 1;
 		const uint32_t n = (xb > avgb ? xb - avgb : avgb - xb) + half;
 		const uint32_t q = MAGIC == 2 ? n >> magic : MAGIC == 1 ? __umulhi(n, magic) : n / a;
 		const uint32_t up = avgb + q, dn = avgb - q;
@@ -1600,6 +1603,163 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		}
 	}
 	if (__any(unsettled) && lane == 0) wg_unsettled = 1;
+	}  // spans of this wave
+	// ---- anybody who could not settle (or a state outside int16): the reference's sequential loop, by wave 0 ------
+	__syncthreads();
+	if (wave != 0 || !(plain || wg_unsettled)) return;
+	if (lane == 0) {
+		// deemph_filter (src/rtl_fm.c:1011-1026) over the run, in place
+		if (plain) sout[s].deemph_avg = deemph_plain(r, T, carried, (int)ds.a);
+		else sout[s].deemph_avg = (int)deemph_walk<MAGIC, true>(r, T, (uint32_t)(carried + 32768), ds) - 32768;
+	}
+	__threadfence_block();
+	wave_sync();
+	for (int b = 0; b < nblocks; b++)
+		arb_upsample_wave(r + (size_t)b * N, B + s * bstride + (size_t)b * len2, N, len2, lane);
+}
+
+// ---- round 5: the same tail at half the instructions (k_deemph_spec_arb above stays as the cross-check, option
+// "arb_span" = 0).  profiles/r04_pmc_c3_k_deemph_spec_arb.txt counted 65 lane-operations per demodulated sample on 1 / 64
+// of the data - 16 % of config 3's step, and the step pays a tail's WORK in full.  Where they went and
+// what is different here:
+//   * the resampler's two samples per output came out of a padded chunk array: shift, multiply, mask and add per look-up,
+//     twice per output.  The span lies LINEAR in LDS here (sample k at y[k - (k0 - W)]): one address per output, the two
+//     samples at offsets -2 and 0.  The lane-per-chunk walks then read and write 16 bytes at a lane stride of 2 C bytes,
+//     four-way conflicted - eight LDS instructions per lane and chunk, against the hundreds of VALU ones saved;
+//   * (i, frac) of an output as ONE 16-byte table entry (one load, one pointer to advance) instead of two arrays;
+//   * a = 2 (16 and 24 kHz) takes the four-instruction step (DeemphStep::step<3>) instead of six;
+//   * the settle window grows in steps of 32 samples whatever the chunk length C is, so C = 64 halves the settling per
+//     sample (two walks over 32 samples per chunk of 64).
+struct ArbTab { double frac; int32_t i; int32_t pad; };
+static_assert(sizeof(ArbTab) == 16, "one 16-byte load per output");
+constexpr int kArbSettle = 32;  // samples per settling step
+
+template <int MAGIC, int C>
+__global__ void __launch_bounds__(64 * kSpecArbMaxWaves)
+k_deemph_arb_span(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
+                  int N, int len2, int nblocks, const ArbTab *__restrict__ tab,
+                  int16_t *__restrict__ B, size_t bstride,
+                  const state_t *__restrict__ sin, state_t *__restrict__ sout, size_t lds_per_wave,
+                  int32_t *__restrict__ cnt_out)
+{
+#if RTLFM_TAIL_PRIO >= 0
+	__builtin_amdgcn_s_setprio(RTLFM_TAIL_PRIO);
+#endif
+	static_assert(C % kArbSettle == 0, "the settling steps end at the chunk's first sample");
+	extern __shared__ uint4 arb_lds[];
+	__shared__ int wg_unsettled;
+	const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wpw = (int)blockDim.x >> 6;
+	int16_t *y = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(arb_lds) + (size_t)wave * lds_per_wave);
+	const size_t s = blockIdx.x;
+	constexpr int span = 64 * C;
+	int16_t *r = R + s * rstride;
+	const int carried = sin[s].deemph_avg;
+	if (threadIdx.x == 0) {
+		wg_unsettled = 0;
+		if (cnt_out) cnt_out[s] = nblocks * len2;
+	}
+	__syncthreads();
+	const bool plain = (uint32_t)(carried + 32768) > 65535u;  // no biased form: the reference's loop below
+	auto wave_sync = [&]() {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
+	auto walk8 = [&](const uint4 &q4, uint32_t &lo, uint32_t &hi) {
+		const uint32_t w4[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const uint32_t b2 = w4[i] ^ 0x80008000u;
+			lo = ds.step<MAGIC>(b2 & 0xffffu, lo); hi = ds.step<MAGIC>(b2 & 0xffffu, hi);
+			lo = ds.step<MAGIC>(b2 >> 16, lo); hi = ds.step<MAGIC>(b2 >> 16, hi);
+		}
+	};
+	for (int sp = wave; sp < spans && !plain; sp += wpw) {
+		const int k0 = sp * span, k1 = min(k0 + span, T);
+		const int kbase = k0 - W;  // y[p] = sample kbase + p
+		bool unsettled = false;
+		wave_sync();  // the span before is done with this wave's LDS region
+		// samples [k0 - W, k0 + span), zero outside the run: coalesced 16-byte loads, linear in LDS
+		for (int g = lane; g < (W + span) / 8; g += 64) {
+			const int k = kbase + g * 8;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (k >= 0 && k + 8 <= T) v = *reinterpret_cast<const uint4 *>(r + k);
+			else if (k + 8 > 0 && k < T) {
+				uint32_t t[4] = {0, 0, 0, 0};
+				for (int j = 0; j < 8; j++)
+					if (k + j >= 0 && k + j < T) t[j >> 1] |= (uint32_t)(uint16_t)r[k + j] << (16 * (j & 1));
+				v = make_uint4(t[0], t[1], t[2], t[3]);
+			}
+			*reinterpret_cast<uint4 *>(y + g * 8) = v;
+		}
+		wave_sync();
+		const int begin = k0 + lane * C, end = min(begin + C, T);
+		uint32_t v = (uint32_t)(carried + 32768);
+		{
+			// both extreme states over the samples before the chunk: where they have met, that is the state, whatever came
+			// earlier (k_deemph_spec_arb).  32 samples first, more only while some lane of the wave is undecided.
+			const bool mine = begin > 0 && begin < T;
+			uint32_t lo = 0, hi = 65535;
+			const int steps_max = W / kArbSettle;
+			for (int nw = 1;; nw = nw * 2 < steps_max ? nw * 2 : steps_max) {
+				lo = 0; hi = 65535;
+				if (begin < nw * kArbSettle) lo = hi = v;  // the run starts inside the window: from the carried state, over the samples there are
+				for (int b = nw; b >= 1; b--) {
+					const int st = begin - b * kArbSettle;
+					if (st < 0) continue;
+					const uint4 *wp = reinterpret_cast<const uint4 *>(y + (st - kbase));
+#pragma unroll
+					for (int g = 0; g < kArbSettle / 8; g++) walk8(wp[g], lo, hi);
+				}
+				if (nw >= steps_max || !__any(mine && lo != hi)) break;
+			}
+			if (mine) {
+				unsettled = lo != hi;  // what this workgroup writes for the stream is replaced afterwards
+				v = lo;
+			}
+		}
+		wave_sync();  // every lane has read what it settles on: the chunks may be filtered in place
+		if (lane == 0) y[W - 1] = (int16_t)(uint16_t)(v ^ 0x8000u);  // the filtered sample before the span
+		if (begin < T) {
+			int16_t *cp = y + W + lane * C;
+			const int cntc = end - begin;
+			int k = 0;
+			for (; k + 8 <= cntc; k += 8) {
+				uint4 q4 = *reinterpret_cast<uint4 *>(cp + k);
+				uint32_t w4[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const uint32_t b2 = w4[i] ^ 0x80008000u;
+					v = ds.step<MAGIC>(b2 & 0xffffu, v);
+					const uint32_t l16 = v;
+					v = ds.step<MAGIC>(b2 >> 16, v);
+					w4[i] = ((l16 & 0xffffu) | (v << 16)) ^ 0x80008000u;
+				}
+				*reinterpret_cast<uint4 *>(cp + k) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+			}
+			for (; k < cntc; k++) {
+				v = ds.step<MAGIC>((uint32_t)(uint16_t)cp[k] ^ 0x8000u, v);
+				cp[k] = (int16_t)(uint16_t)(v ^ 0x8000u);
+			}
+			if (end == T) sout[s].deemph_avg = (int)v - 32768;
+		}
+		wave_sync();
+		// arbitrary_upsample (src/rtl_fm.c:1114-1135) of the buffers that intersect the span: output j of a buffer from the
+		// filtered samples i - 1 and i, (i, frac) as the reference's loop holds them when it writes buf2[j] (the host walks
+		// that loop once per (len1, len2): rtlfm_hip.hip)
+		for (int b = k0 / N; b <= (k1 - 1) / N; b++) {
+			const int base = b * N;
+			const int ia = max(k0, base) - base, ib = min(k1, base + N) - base;
+			const int j0 = arb_first_output(ia, N, len2), j1 = arb_first_output(ib, N, len2);
+			int16_t *bo = B + s * bstride + (size_t)b * len2;
+			const int16_t *yb = y + (base - kbase);  // yb[i] = filtered sample i of buffer b
+			for (int j = j0 + lane; j < j1; j += 64) {
+				const ArbTab e = tab[j];
+				const int16_t *pp = yb + e.i;
+				bo[j] = (int16_t)((double)pp[-1] * (1 - e.frac) + (double)pp[0] * e.frac);
+			}
+		}
+		if (__any(unsettled) && lane == 0) wg_unsettled = 1;
 	}  // spans of this wave
 	// ---- anybody who could not settle (or a state outside int16): the reference's sequential loop, by wave 0 ------
 	__syncthreads();
