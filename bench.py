@@ -68,6 +68,11 @@ WORKLOADS = {
     "wbfm": dict(streams=1024, blocks=16, block_len=262144, passes=0, boxcar=6, fir9=0, atan="fast", fs=1.02e6, tail="wbfm"),
     "c3": dict(streams=4096, blocks=4, block_len=262144, passes=6, boxcar=0, fir9=1, atan="std", fs=1.024e6, tail="c3"),
     "c4": dict(streams=1024, blocks=64, block_len=32768, passes=0, boxcar=0, fir9=0, atan="std", fs=2.048e6, tail="power"),
+    # configs[1]'s chain on the reference's OWN buffer size (dongle_init(), src/rtl_fm.c:1605: 16384 bytes): every second
+    # tile starts a buffer
+    "c2_16k": dict(streams=256, blocks=1024, block_len=16384, passes=4, boxcar=0, fir9=0, atan="std", fs=2.4e6, tail=""),
+    # the everyday command line, rtl_fm -M fm -s 12k -l 50 (boxcar /84 at 1.008 MS/s + the power squelch)
+    "scanner": dict(streams=256, blocks=64, block_len=262144, passes=0, boxcar=84, fir9=0, atan="std", fs=1.008e6, tail="", squelch=50),
 }
 
 
@@ -86,7 +91,7 @@ def parse():
                     help="D > 0: the reference's default low_pass boxcar /D instead of fifth_order passes")
     ap.add_argument("--fir9", type=int, default=None)
     ap.add_argument("--rdc", type=int, default=0, help="1: -E rdc (dc_block_raw_filter) in front of the chain")
-    ap.add_argument("--squelch", type=int, default=0, help="-l N: the power squelch behind the decimator (the front end's emit mode + squelch kernels)")
+    ap.add_argument("--squelch", type=int, default=None, help="-l N: the power squelch behind the decimator (the front end's emit mode + squelch kernels)")
     ap.add_argument("--atan", choices=["std", "fast", "lut"], default=None)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 staged, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,6 +115,8 @@ def parse():
     for k, v in WORKLOADS[a.workload].items():
         if getattr(a, k, None) is None:
             setattr(a, k, v)
+    if a.squelch is None:
+        a.squelch = 0
     if a.boxcar:
         a.passes, a.fir9 = 0, 0
     return a
@@ -222,6 +229,7 @@ def workload_args(a, name):
     import copy
     b = copy.copy(a)
     b.workload = name
+    b.squelch = 0
     for k, v in WORKLOADS[name].items():
         setattr(b, k, v)
     b.rdc, b.path = 0, 0
@@ -478,7 +486,7 @@ class ApartRows:
     computed from (rtlfm_gpu_malloc_apart: the read and the write stream of a launch get in each other's way when
     they share a 72 GB quarter of the MI355X's memory - DESIGN.md section 3).  Quacks like the torch tensor it replaces."""
 
-    def __init__(self, rows, cols, other_ptr, other_bytes, device, budget_gb=150):
+    def __init__(self, rows, cols, other_ptr, other_bytes, device, budget_gb=16):
         import ctypes as C
         from rtlsdr_amd.capi import check, load
         self.lib = load()
@@ -539,6 +547,47 @@ def _timed(job, warm, K):
     return ms / max(cnt, 1), dt / K * 1e3
 
 
+class ColocatedRows:
+    """int16 [rows, cols] device memory that SHARES its class of the HBM with `other` - what a caller who knows nothing of
+    the placement often gets.  Plain allocations of several sizes are classified with rtlfm_gpu_placement_probe until one
+    is co-located (probe: 0); `colocated` says whether one was found, `tries` how many allocations it took."""
+
+    def __init__(self, rows, cols, other_ptr, other_bytes, device):
+        import ctypes as C
+        from rtlsdr_amd.capi import check, load
+        self.lib = load()
+        self.rows, self.cols = rows, cols
+        need = rows * cols * 2
+        held, self.ptr, self.colocated, self.tries = [], None, False, 0
+        for gib in (0, 0, 1, 2, 4, 1, 2, 4):
+            p = C.c_void_p()
+            if self.lib.rtlfm_gpu_malloc(device, max(need, gib << 30), C.byref(p)) != 0:
+                break
+            self.tries += 1
+            rd, rw = C.c_double(), C.c_double()
+            r = self.lib.rtlfm_gpu_placement_probe(device, other_ptr, other_bytes, p, need, C.byref(rd), C.byref(rw))
+            if r == 0:
+                self.ptr, self.colocated = p.value, True
+                break
+            held.append(p.value)
+        if self.ptr is None:  # every allocation came out apart: the last one serves, and the leg says so
+            self.ptr = held.pop()
+        for q in held:
+            self.lib.rtlfm_gpu_free(q)
+        self.apart = not self.colocated
+
+    def data_ptr(self):
+        return self.ptr
+
+    def stride(self, dim):
+        return self.cols if dim == 0 else 1
+
+    def free(self):
+        if self.ptr:
+            self.lib.rtlfm_gpu_free(self.ptr)
+            self.ptr = None
+
+
 def _leg_entry(name, job, launch_ms, step_ms, K, ceiling):
     alg = job.alg_bytes_per_sample * job.samples
     ach = alg / (launch_ms * 1e-3) / 1e9
@@ -571,15 +620,19 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
     class Reuse:
         """the resident bytes through the default chain under another (streams, buffers) shape"""
 
-        def __init__(self, S, nb, per_stream):
+        def __init__(self, S, nb, per_stream, block_len=None, colocated=False):
             self.a = a
             self.S, self.nb, self.per_stream = S, nb, per_stream
+            self.L = block_len or L
             cfg = RtlfmCfg.from_buffer_copy(bytes(job.cfg))
             cfg.max_blocks = nb
+            cfg.block_len = self.L
             self.g = GpuDemod(cfg, S, local_rank)
             cap = self.g.result_cap(nb)
             have = job.out.rows * job.out.cols if isinstance(job.out, ApartRows) else 0
-            if S * cap <= have:
+            if colocated:
+                self.o = ColocatedRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
+            elif S * cap <= have:
                 # the default workload's own output buffer, whose placement is known, under this leg's row length
                 outer = job.out
 
@@ -599,7 +652,7 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
                 self.o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
             self.output_apart = self.o.apart
             self.n = torch.zeros(S, dtype=torch.int32, device=dev)
-            self.samples = S * nb * L // 2
+            self.samples = S * nb * self.L // 2
             self.alg_bytes_per_sample = job.alg_bytes_per_sample
 
         def step(self):
@@ -609,7 +662,7 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
             self.g.sync()
 
         def describe(self):
-            return (f"{self.S} streams/GPU x {self.nb} buffer(s) x {L} B per launch, the default workload's chain and bytes")
+            return (f"{self.S} streams/GPU x {self.nb} buffer(s) x {self.L} B per launch, the default workload's chain and bytes")
 
         def kernel_name(self):
             return job.kernel_name()
@@ -618,16 +671,24 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
             self.g.close(); self.o.free()
 
     if a.workload == "ns4096" and not a.boxcar and total == 4096 * 4 * L:
-        for name, S, nb, per in (("ns4096x1", 4096, 1, total // 4096), ("c2", 256, 64, total // 256)):
-            r = Reuse(S, nb, per)
+        # ns4096_colocated: the headline launch with its output where input and output SHARE a class of the HBM (what a
+        # caller gets who allocates one after the other): the other end of the placement's effect;
+        # c2_16k: configs[1] on the reference's own 16384-byte buffers (src/rtl_fm.c:1605)
+        for name, S, nb, per, bl, colo in (("ns4096x1", 4096, 1, total // 4096, L, False), ("c2", 256, 64, total // 256, L, False),
+                                           ("ns4096_colocated", 4096, 4, total // 4096, L, True),
+                                           ("c2_16k", 256, total // 256 // 16384, total // 256, 16384, False)):
+            r = Reuse(S, nb, per, bl, colo)
             launch_ms, step_ms = _timed(r, 400 if nb == 1 else 100, 4 * K if nb == 1 else K)
             e = _leg_entry(name, r, launch_ms, step_ms, 4 * K if nb == 1 else K, ceiling)
             r.g.clock_probe(True); r.step(); st = r.g.clock_stamps(); r.g.clock_probe(False); r.sync()
             if st is not None:
                 e["waves_per_stream"] = len(st) // S
+            if colo:
+                e["colocated"] = r.o.colocated
+                e["colocated_tries"] = r.o.tries
             out[name] = e
             r.close()
-    for name in ("c3", "c1", "wbfm", "c4"):
+    for name in ("c3", "c1", "wbfm", "scanner", "c4"):
         b = workload_args(a, name)
         j = None
         try:
@@ -735,9 +796,10 @@ class FmJob:
             # "apart" is a minority of the memory and where it lies differs from box to box: if the
             # search comes back empty-handed, the input moves (a second copy somewhere else; the first stays parked so that
             # the allocator cannot hand the same place out again) and the search runs once more - three tries in all
-            # (r04: a first search walked 152 GB in 4.7 s and found nothing; with the input moved the first candidate was apart)
+            # (r04: a first search walked 152 GB in 4.7 s and found nothing; with the input moved the first candidate was apart.
+            # Round 5: the search itself is bounded - eight candidates of different sizes, 16 GiB held at most)
             tries = []
-            for attempt, budget_gb in enumerate((48, 48, 150)):
+            for attempt, budget_gb in enumerate((16, 16, 16)):
                 self.out = ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank, budget_gb)
                 tries.append({"apart": self.out.apart, "search_ms": self.out.search_ms, "walked_mb": self.out.walked_mb})
                 if self.out.apart or attempt == 2 or a.pmc_child:

@@ -276,13 +276,17 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   lpr_scalar_stores    1: the resampler's outputs one by one
  *   lpr_chunk            samples per lane of the one-pass deemph + low_pass_real kernel (default 2720; 256 ... 2^20,
  *                        anything else -EINVAL)
- *   apart_budget_gb      most device memory (GiB, default 150, never more than 60 % of what is free) a placement
- *                        search may hold in temporary allocations; 0 = no search, plain allocations
+ *   apart_budget_gb      most device memory (GiB, default 16, never more than half of what is free) a placement
+ *                        search may hold in candidate allocations; 0 = no search, plain allocations
+ *   arb_span             0: round 4's form of config 3's one-kernel tail (k_deemph_spec_arb) instead of k_deemph_arb_span
+ *   arb_chunk            samples per lane of k_deemph_arb_span: 32 (default) or 64, anything else -EINVAL
  * Read-only (rtlfm_gpu_get_option):
  *   ring_apart           1 / 0: the result buffers behind rtlfm_gpu_push() / _run() are / are not a quarter of the HBM
  *                        away from the ring's device input; -1 before the ring exists (it is built by the first push)
  *   res_apart            the same for the audio tail's work buffers against the first run's input (-1: none yet;
- *                        0 also on a caller-owned stream, where no search is made)
+ *                        0 also on a caller-owned stream (rtlfm_gpu_set_stream), where no search is made - the search
+ *                        times launches on the null stream and synchronises the device; a caller on its own stream
+ *                        places its OWN output with rtlfm_gpu_malloc_apart before the first run: INTEGRATION.md)
  *   deep_apart           the same for the buffer a front end's emit mode writes (-M raw, the squelch, -L, 7-10 passes);
  *                        -1: this configuration has none / not allocated yet
  *   placement_ms         wall time the placement searches of this handle took, in all
@@ -370,28 +374,29 @@ int rtlfm_gpu_selftest_const_div(int device, const int32_t *nd, int n, int32_t *
 int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream);
 
 /*
- * Where the output lives relative to the input matters on MI355X: its HBM behaves as four quarters of
- * 72 GB, and a kernel that reads from one quarter and writes into the SAME quarter - the PCM is 1/16 of
- * the bytes at /16 - streams 5.6 TB/s where it streams 6.5 TB/s with the writes in another quarter
- * (read only: 6.9).  Buffers allocated one after the other normally share a quarter.
+ * Where the output lives relative to the input matters on MI355X: every allocation belongs to one of (as far as the
+ * probes have seen) three classes of its HBM, and a kernel that reads from one class and writes into the SAME class -
+ * the PCM is 1/16 of the bytes at /16 - streams 5.6 TB/s where it streams 6.5 TB/s with the writes in another class
+ * (read only: 6.9).  Buffers allocated one after the other normally share a class.
  *
  * rtlfm_gpu_malloc_apart: `bytes` of device memory for a write stream that runs beside the read stream
- * of `other` (other_bytes long; only read): candidates are timed against `other` with the bandwidth
- * probe until one lies in another quarter (a few ms each; up to 150 GiB of temporary allocations - two
- * quarters - are walked over and freed again).  A candidate is at least 1 GiB and the winner is kept whole
- * (the driver's allocator serves smaller requests from holes that all sit in one place; from 1 GiB on the
- * allocations move through the quarters): up to 1 GiB - bytes stay unused behind a placed buffer.
- * *apart (may be NULL) = 1 when found; otherwise - buffers too small to
- * matter (< 256 MiB streamed), no budget, probe failure - ordinary memory is returned with *apart = 0.
+ * of `other` (other_bytes long; only read).  A bounded search: at most eight candidates - the request's own size, then
+ * 1, 2, 1, 4, 1, 2, 4 GiB (the driver's allocator serves different sizes from different places) -, each timed against
+ * `other` with one short bandwidth probe, never more than 16 GiB (rtlfm_gpu_malloc_apart_ex: budget_bytes) or half of
+ * the free device memory held at once, typically 5-30 ms; the step that succeeded on a device is tried first the next
+ * time in this process.  A winning candidate larger than the request is kept whole (the library asks for the buffers of
+ * one handle that belong together as ONE block).  *apart (may be NULL) = 1 when found; otherwise - buffers too small to
+ * matter (< 256 MiB streamed), no budget, every candidate in `other`'s class, probe failure - ordinary memory is
+ * returned with *apart = 0: the result is always usable, and the caller can see which it got.
  * The library's own result buffers behind rtlfm_gpu_push() / _run() are placed this way.
- * rtlfm_gpu_placement_probe: 1 if existing buffers `in` / `out` are a quarter apart, 0 if not (or too
+ * rtlfm_gpu_placement_probe: 1 if existing buffers `in` / `out` are in different classes, 0 if not (or too
  * small to tell); OVERWRITES the first in_bytes / 16 bytes of `out`.
  * rtlfm_gpu_malloc / _free: plain device memory through the library.
  */
 int rtlfm_gpu_malloc(int device, size_t bytes, void **out);
 int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart);
-/* The same with the search's cost in the open: budget_bytes = most the filler walk may hold (0: no search, plain
- * memory; rtlfm_gpu_malloc_apart uses 150 GiB; never more than 60 % of the free device memory is taken),
+/* The same with the search's cost in the open: budget_bytes = most the search may hold in candidates (0: no search, plain
+ * memory; rtlfm_gpu_malloc_apart uses 16 GiB; never more than half of the free device memory is taken),
  * *search_ms = wall time of the call, *walked_bytes = most it held at once (either may be NULL). */
 int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
                               void **out, int *apart, double *search_ms, size_t *walked_bytes);

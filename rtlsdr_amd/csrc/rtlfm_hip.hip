@@ -59,6 +59,7 @@ struct rtlfm_gpu {
 	// int16 per stream.  Two sets, because the tail of step k runs on its own stream while the front
 	// end of step k + 1 already fills the other set.
 	int16_t *res[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+	bool res_one_block = false;  // res[0][0] and res[1][0] are ONE placed allocation (res[1][0] points into it)
 	size_t tstride = 0;
 	int32_t *d_cnt[2] = {nullptr, nullptr}, *d_cnt2 = nullptr;  // d_cnt: per step parity
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
@@ -95,7 +96,7 @@ struct rtlfm_gpu {
 	bool no_deemph_scan = false;      // stream-range views (ragged runs) keep to the sequential filter
 	// placement of the write streams (rtlfm_gpu_malloc_apart_ex): what the searches found and what they cost
 	struct Placement {
-		int budget_gb = 150;            // option apart_budget_gb: most the filler walk may hold; 0 = no search
+		int budget_gb = 16;             // option apart_budget_gb: most a search may hold in candidates; 0 = no search
 		int ring_apart = -1;            // -1: not allocated yet; 0 / 1: the ring's result buffers (both halves) are a quarter away from d_in
 		int res_apart = -1;             // the same for the audio tail's work buffers against the first run's input
 		int deep_apart = -1;            // ... and for what a front end's emit mode writes (deepA)
@@ -403,26 +404,27 @@ static int ensure_res_buffers(rtlfm_gpu *h, const uint8_t *d_iq = nullptr, size_
 	const size_t S = (size_t)h->nstreams;
 	if (!h->res[0][0]) {
 		// The search times probe launches on the null stream and synchronises the device: not in the middle
-		// of an asynchronous call on a stream the caller owns - there the buffers are plain allocations.
+		// of an asynchronous call on a stream the caller owns - there the buffers are plain allocations, and
+		// res_apart says 0 (the caller can place its OWN output with rtlfm_gpu_malloc_apart: INTEGRATION.md).
 		const bool search = d_iq && h->stream == h->own_stream && h->place.budget_gb > 0;
-		int all_apart = search ? 1 : 0;
-		for (int p = 0; p < 2; p++)
-			for (int k = 0; k < 2; k++) {
-				void *q = nullptr;
-				if (k == 0 && search) {
-					int apart = 0; double ms = 0; size_t walked = 0;
-					int r = rtlfm_gpu_malloc_apart_ex(h->device, S * h->tstride * sizeof(int16_t), d_iq, iq_bytes,
-					                                  (size_t)h->place.budget_gb << 30, &q, &apart, &ms, &walked);
-					if (r < 0) return r;
-					h->place.search_ms += ms;
-					if (walked > h->place.walked_peak) h->place.walked_peak = walked;
-					if (!apart) all_apart = 0;
-				} else {
-					HIP_TRY(hipMalloc(&q, S * h->tstride * sizeof(int16_t)));
-				}
-				h->res[p][k] = (int16_t *)q;
-			}
-		h->place.res_apart = all_apart;
+		const size_t one = (S * h->tstride * sizeof(int16_t) + 255) & ~(size_t)255;
+		int apart = 0;
+		if (search) {
+			// the two buffers the front end writes (one per step parity) as ONE placed block: one search, and a
+			// candidate that had to be larger than the request (rtlfm_gpu_malloc_apart_ex) is shared by both
+			void *q = nullptr; double ms = 0; size_t walked = 0;
+			int r = rtlfm_gpu_malloc_apart_ex(h->device, 2 * one, d_iq, iq_bytes, (size_t)h->place.budget_gb << 30, &q, &apart, &ms, &walked);
+			if (r < 0) return r;
+			h->place.search_ms += ms;
+			if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+			h->res[0][0] = (int16_t *)q;
+			h->res[1][0] = (int16_t *)((char *)q + one);
+			h->res_one_block = true;
+		} else {
+			for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&h->res[p][0], one));
+		}
+		for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&h->res[p][1], one));
+		h->place.res_apart = apart;
 	}
 	return 0;
 }
@@ -442,7 +444,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (e) hipEventDestroy(e);
 	for (auto &p : h->ev_pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_arb_tab, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res[1][0], h->res[1][1],
+	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_arb_tab, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res_one_block ? nullptr : (void *)h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
@@ -1505,6 +1507,7 @@ struct Ingest {
 	hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr};
 	bool h2d_pending[2] = {false, false}, run_pending[2] = {false, false};
 	int16_t *d_result[2] = {nullptr, nullptr};  // ostride int16 per stream
+	bool result_one_block = false;              // d_result[1] points into d_result[0]'s allocation
 	int32_t *d_result_len[2] = {nullptr, nullptr};
 	size_t ostride = 0;
 	int last = -1;                              // half of the last run
@@ -1526,7 +1529,7 @@ static void ingest_free(Ingest *in)
 	if (in->copy_stream) { hipStreamSynchronize(in->copy_stream); hipStreamDestroy(in->copy_stream); }
 	for (int k = 0; k < 2; k++) {
 		if (in->h_stage[k]) hipHostFree(in->h_stage[k]);
-		for (void *p : {(void *)in->d_in[k], (void *)in->d_result[k], (void *)in->d_result_len[k]})
+		for (void *p : {(void *)in->d_in[k], k == 1 && in->result_one_block ? nullptr : (void *)in->d_result[k], (void *)in->d_result_len[k]})
 			if (p) hipFree(p);
 		for (hipEvent_t e : {in->ev_h2d[k], in->ev_run[k]})
 			if (e) hipEventDestroy(e);
@@ -1548,25 +1551,47 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 	for (int k = 0; k < 2; k++) {
 		HIP_TRY(hipHostMalloc(&in->h_stage[k], bytes, hipHostMallocDefault));
 		HIP_TRY(hipMalloc(&in->d_in[k], bytes));
-		{
-			// the results a quarter of the HBM away from the input they are demodulated from (see
-			// rtlfm_gpu_malloc_apart; plain memory when the ring is too small for it to matter)
-			void *p = nullptr;
-			int apart = 0; double ms = 0; size_t walked = 0;
-			int r = rtlfm_gpu_malloc_apart_ex(h->device, S * in->ostride * sizeof(int16_t), in->d_in[k], bytes,
-			                                  (size_t)h->place.budget_gb << 30, &p, &apart, &ms, &walked);
-			if (r < 0) return r;
-			in->d_result[k] = (int16_t *)p;
-			h->place.search_ms += ms;
-			if (walked > h->place.walked_peak) h->place.walked_peak = walked;
-			h->place.ring_apart = (k == 0 ? 1 : h->place.ring_apart) && apart ? 1 : 0;
-		}
 		HIP_TRY(hipMalloc(&in->d_result_len[k], S * sizeof(int32_t)));
 		HIP_TRY(hipEventCreateWithFlags(&in->ev_h2d[k], hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&in->ev_run[k], hipEventDisableTiming));
 		in->h_len[k].assign(S * h->cap_blocks, 0);
 		in->pushed[k].reset(new std::atomic<int>[S]);
 		for (size_t s = 0; s < S; s++) in->pushed[k][s].store(0);
+	}
+	{
+		// the results away from the input they are demodulated from (rtlfm_gpu_malloc_apart_ex; plain memory when the
+		// ring is too small for it to matter).  Both halves' results as ONE block placed against the first half's input;
+		// the second half's input was allocated right behind the first and is almost always of the same class - one probe
+		// says whether it is, and only if not the second half gets a block and a search of its own.
+		const size_t one = (S * in->ostride * sizeof(int16_t) + 255) & ~(size_t)255;
+		const size_t budget = (size_t)h->place.budget_gb << 30;
+		void *p = nullptr;
+		int apart = 0; double ms = 0; size_t walked = 0;
+		int r = rtlfm_gpu_malloc_apart_ex(h->device, 2 * one, in->d_in[0], bytes, budget, &p, &apart, &ms, &walked);
+		if (r < 0) return r;
+		h->place.search_ms += ms;
+		if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+		in->d_result[0] = (int16_t *)p;
+		in->d_result[1] = (int16_t *)((char *)p + one);
+		in->result_one_block = true;
+		h->place.ring_apart = apart;
+		if (apart) {
+			double rd = 0, rw = 0;
+			const auto t0 = std::chrono::steady_clock::now();
+			const int both = rtlfm_gpu_placement_probe(h->device, in->d_in[1], bytes, in->d_result[1], one, &rd, &rw);
+			h->place.search_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			if (both < 0) return both;
+			if (!both) {
+				void *p2 = nullptr; int apart2 = 0;
+				r = rtlfm_gpu_malloc_apart_ex(h->device, one, in->d_in[1], bytes, budget, &p2, &apart2, &ms, &walked);
+				if (r < 0) return r;
+				h->place.search_ms += ms;
+				if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+				in->d_result[1] = (int16_t *)p2;
+				in->result_one_block = false;
+				h->place.ring_apart = apart2;
+			}
+		}
 	}
 	in->open_slot.reset(new std::atomic<int>[S]);
 	for (size_t s = 0; s < S; s++) in->open_slot[s].store(0);
@@ -2058,7 +2083,7 @@ struct ProbeRig {
 	}
 	// ms per launch: `region` bytes of `in` streamed by 8192 waves, W bytes stored per lane and tile into `out`
 	// (region / 8192 * 64 * W / 8192 ... = region * W / 128 bytes in all)
-	int run(const uint8_t *in, size_t region, uint8_t *out, int W, int reps, float *ms)
+	int run(const uint8_t *in, size_t region, uint8_t *out, int W, int reps, float *ms, int warm = 3)
 	{
 		const int waves = 8192;
 		const size_t seg = (region / waves) & ~(size_t)8191;
@@ -2072,7 +2097,7 @@ struct ProbeRig {
 			default: hipLaunchKernelGGL((bwprobe::k_stream<16>), dim3(waves), dim3(64), bwprobe::kLdsBytes, 0, in, seg, sink, out); break;
 			}
 		};
-		for (int i = 0; i < 3; i++) go();  // clocks, TLBs
+		for (int i = 0; i < warm; i++) go();  // clocks, TLBs
 		if (hipEventRecord(a, 0) != hipSuccess) return -EIO;
 		for (int i = 0; i < reps; i++) go();
 		if (hipEventRecord(b, 0) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return -EIO;
@@ -2091,20 +2116,30 @@ size_t probe_region(size_t in_bytes, size_t out_bytes)
 	return r & ~(((size_t)8192 * 8192) - 1);      // whole tiles for 8192 waves
 }
 
-constexpr float kApartRatio = 1.21f;  // read+write over read-only time: 1.12 apart, 1.31 in the same quarter
-// (80 GiB until the end of round 4: on one of the pool's boxes two searches in a row walked all of it - 82 GB - and found
-// nothing where others found the boundary after 61 and 70 GB; the walk is ~1 ms per GB)
-constexpr size_t kApartBudgetDefault = (size_t)150 << 30;
+constexpr float kApartRatio = 1.21f;  // read+write over read-only time: 1.12 apart, 1.31 in the same class
+// What a search may hold in temporary allocations unless the caller says otherwise.  Rounds 3-4 walked up to 150 GiB (a
+// run of one class can be 64 GB long, profiles/r04_placement_classes.txt) and a first search of a session was seen to take
+// 4.7 s and find nothing; round 5 bounds the search instead of the memory it walks: a handful of candidates of
+// DIFFERENT SIZES - the driver's allocator serves sizes from different places (268 MiB blocks out of one class of holes,
+// 1 GiB ones B A A B B A B ..., 4 GiB ones C C C C C C A A ...: profiles/r04_placement_sizes.txt) -, at most 16 GiB held,
+// one short probe each.
+constexpr size_t kApartBudgetDefault = (size_t)16 << 30;
+// GiB of the candidates after the request's own size, in order; a step that found the placement on this device before
+// is tried first the next time (g_recipe)
+constexpr int kApartSchedule[] = {1, 2, 1, 4, 1, 2, 4};
+constexpr int kApartSteps = (int)(sizeof(kApartSchedule) / sizeof(kApartSchedule[0])) + 1;  // + the request's own size
+std::atomic<int> g_recipe[64];  // per device: 1 + the step that won last, 0 = nothing known
 
 }  // namespace
 
 // Device memory for a WRITE stream that is to run next to the read stream of `other` (the output of
-// rtlfm_gpu_run_device next to its input): `bytes` in another quarter of the HBM than `other`.
-// Candidates are allocated and timed against `other` with the bandwidth probe; those that share its
-// quarter are kept (with 4 GiB of filler each) so that the allocator moves on, and everything but the
-// winner is freed at the end.  *apart = 1 when a quarter away was found, 0 when the buffers are too
-// small for it to matter (< 256 MiB streamed), the search ran out of memory budget, or the probe
-// failed - the memory returned is good device memory in every case.  `other` is only read.
+// rtlfm_gpu_run_device next to its input): `bytes` in another class of the HBM than `other` (see above).
+// Candidates are allocated and timed against `other` with the bandwidth probe (read only once, then read + write per
+// candidate: one warm-up launch and two timed ones); those that share its class are kept until the search ends, so
+// that the allocator moves on, and everything but the winner is freed.  *apart = 1 when a place away from `other` was
+// found, 0 when the buffers are too small for it to matter (< 256 MiB streamed), the search ran out of its budget, or
+// the probe failed - the memory returned is good device memory in every case.  `other` is only read.
+// budget_bytes: the most the search may hold at any time, winner included (0 = no search at all).
 extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
                                          void **out, int *apart, double *search_ms, size_t *walked_bytes)
 {
@@ -2135,50 +2170,47 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 	if (r < 0) return r;
 	HIP_TRY(hipDeviceSynchronize());
 	float rd = 0;
-	if ((r = rig.run((const uint8_t *)other, region, nullptr, 0, 6, &rd)) < 0) return r;
+	if ((r = rig.run((const uint8_t *)other, region, nullptr, 0, 3, &rd, 2)) < 0) return r;
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	const size_t step = (size_t)4 << 30;
-	// a quarter is 72 GB, and a buffer near the start of its quarter needs nearly all of it walked over: the caller's
-	// budget (the library's default: two quarters), and never more than 60 % of what is free - the device may have other
-	// tenants, whose next allocation must not fail because of a search
+	// never more than half of what is free: the device may have other tenants, whose next allocation must not fail
+	// because of a search
 	size_t budget = budget_bytes;
-	if (budget > free_b / 5 * 3) budget = free_b / 5 * 3;
-	// Candidates are at least 1 GiB (the winner is kept whole: up to 1 GiB - bytes of it stay unused).  The driver's
-	// allocator serves small requests from whatever holes it has, and those sit in ONE place: a walk with 268 MiB
-	// candidates between 4 GiB fillers kept getting its candidates from the input's own quarter while the fillers
-	// advanced through the others (round 4, tools/placement_sizes.py: twenty 268 MiB blocks in a row all landed in class
-	// A, 1 GiB blocks went B A A B B A B B B B B B C C ..., 4 GiB ones C C C C C C A A ...; one search walked 152 GB that
-	// way and found nothing).  From 1 GiB on an allocation goes where the big free ranges are and the classes rotate.
-	const size_t cand_bytes = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
-	std::vector<void *> keep;       // fillers
+	if (budget > free_b / 2) budget = free_b / 2;
 	std::vector<void *> cand;       // candidates that did not pass, with their times
 	std::vector<float> cand_rw;
 	void *win = nullptr;
-	size_t walked = 0;
-	for (int tries = 0;; tries++) {
-		void *p = nullptr;
-		if (hipMalloc(&p, cand_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-		float rw = 0;
-		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 6, &rw) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
-		if (rw < kApartRatio * rd) { win = p; break; }
-		cand.push_back(p); cand_rw.push_back(rw);
-		walked += cand_bytes;
-		clk.peak = walked;
-		// a long run of one class (40 GB and more were seen): from the sixth try on, 4 GiB of filler per try as well
-		const size_t push = tries >= 5 ? step : 0;
-		if (walked + push + cand_bytes > budget) break;
-		if (push) {
-			void *f = nullptr;
-			if (hipMalloc(&f, push) != hipSuccess) { (void)hipGetLastError(); break; }
-			keep.push_back(f);
-			walked += push;
-			clk.peak = walked;
-		}
+	size_t held = 0;
+	// the order of the steps: the one that found the placement on this device last time first
+	int order[kApartSteps];
+	{
+		const int known = device < 64 ? g_recipe[device].load(std::memory_order_relaxed) - 1 : -1;
+		int n = 0;
+		if (known >= 0 && known < kApartSteps) order[n++] = known;
+		for (int k = 0; k < kApartSteps; k++)
+			if (k != known) order[n++] = k;
 	}
-	for (void *k : keep) hipFree(k);
-	// no candidate under the threshold (a noisy box, or the walk ran out of budget): the one that measured
-	// fastest is still the best place there is
+	int won_step = -1;
+	for (int t = 0; t < kApartSteps; t++) {
+		const int step = order[t];
+		size_t cb = bytes;
+		if (step > 0) {
+			const size_t g = (size_t)kApartSchedule[step - 1] << 30;
+			if (g <= bytes) continue;  // the request itself is as large: that size has been tried
+			cb = g;
+		}
+		if (held + cb > budget) continue;
+		void *p = nullptr;
+		if (hipMalloc(&p, cb) != hipSuccess) { (void)hipGetLastError(); continue; }
+		held += cb;
+		if (held > clk.peak) clk.peak = held;
+		float rw = 0;
+		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 2, &rw, 1) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
+		if (rw < kApartRatio * rd) { win = p; won_step = step; break; }
+		cand.push_back(p); cand_rw.push_back(rw);
+	}
+	// no candidate under the threshold (a noisy box, or every candidate the budget allowed shares the input's class): the
+	// one that measured fastest is still the best place there is
 	if (!win && !cand.empty()) {
 		size_t best = 0;
 		for (size_t i = 1; i < cand.size(); i++)
@@ -2186,12 +2218,13 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 		win = cand[best];
 		cand[best] = nullptr;
 		if (apart) *apart = 0;
-	} else if (win && apart) {
-		*apart = 1;
+	} else if (win) {
+		if (apart) *apart = 1;
+		if (device < 64) g_recipe[device].store(won_step + 1, std::memory_order_relaxed);
 	}
 	for (void *c : cand)
 		if (c) hipFree(c);
-	if (!win) HIP_TRY(hipMalloc(&win, bytes));  // (nothing could be allocated at candidate size)
+	if (!win) HIP_TRY(hipMalloc(&win, bytes));  // (nothing could be allocated at any candidate size)
 	*out = win;
 	return 0;
 }

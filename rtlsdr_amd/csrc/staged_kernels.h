@@ -1753,10 +1753,27 @@ k_deemph_arb_span(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 			const int j0 = arb_first_output(ia, N, len2), j1 = arb_first_output(ib, N, len2);
 			int16_t *bo = B + s * bstride + (size_t)b * len2;
 			const int16_t *yb = y + (base - kbase);  // yb[i] = filtered sample i of buffer b
-			for (int j = j0 + lane; j < j1; j += 64) {
-				const ArbTab e = tab[j];
-				const int16_t *pp = yb + e.i;
-				bo[j] = (int16_t)((double)pp[-1] * (1 - e.frac) + (double)pp[0] * e.frac);
+			// The table entries of the NEXT four outputs of the lane travel while these four are computed: a tail wave beside
+			// the front end costs the step the wave slot it holds, not its instructions, and with one dependent
+			// trip to L2 per output (44 per span and lane) the wave spent most of its life waiting.
+			constexpr int PF = 4;
+			ArbTab cur[PF], nxt[PF];
+			int j = j0 + lane;
+#pragma unroll
+			for (int u = 0; u < PF; u++) cur[u] = tab[min(j + 64 * u, len2 - 1)];
+			for (; j < j1; j += 64 * PF) {
+#pragma unroll
+				for (int u = 0; u < PF; u++) nxt[u] = tab[min(j + 64 * (PF + u), len2 - 1)];
+#pragma unroll
+				for (int u = 0; u < PF; u++) {
+					const int ju = j + 64 * u;
+					if (ju < j1) {
+						const int16_t *pp = yb + cur[u].i;
+						bo[ju] = (int16_t)((double)pp[-1] * (1 - cur[u].frac) + (double)pp[0] * cur[u].frac);
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < PF; u++) cur[u] = nxt[u];
 			}
 		}
 		if (__any(unsettled) && lane == 0) wg_unsettled = 1;
