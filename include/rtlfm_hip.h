@@ -278,7 +278,9 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        anything else -EINVAL)
  *   apart_budget_gb      most device memory (GiB, default 16, never more than half of what is free) a placement
  *                        search may hold in candidate allocations; 0 = no search, plain allocations
- *   arb_span             0: round 4's form of config 3's one-kernel tail (k_deemph_spec_arb) instead of k_deemph_arb_span
+ *   arb_span             1: config 3's one-kernel tail as k_deemph_arb_span (the span linear in LDS, 16-byte table entries,
+ *                        a four-instruction filter step for a == 2) instead of k_deemph_spec_arb: 18 % fewer instructions,
+ *                        the same time - kept for A/B
  *   arb_chunk            samples per lane of k_deemph_arb_span: 32 (default) or 64, anything else -EINVAL
  * Read-only (rtlfm_gpu_get_option):
  *   ring_apart           1 / 0: the result buffers behind rtlfm_gpu_push() / _run() are / are not a quarter of the HBM

@@ -163,9 +163,12 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fu
 // RDC: dc_block_raw_filter (-E rdc, src/rtl_fm.c:1043-1065) in front of the boxcar.  It subtracts one (aI, aQ) per
 // buffer before the rotation, and the rotated constant sums to zero over every four samples: with c = aI + j aQ,
 // sum_{m<n} (-j)^m c = c G(n & 3), G = 0, 1, 1 - j, -j.  So P~(n) = P(n) - c G(n & 3) is the prefix sum of the filtered
-// samples, a tile (4096 samples of ONE buffer: whole-tile buffers only) starts and ends with a correction of zero, and
-// the only change is one subtraction where a prefix is looked up.  The averages come from a pre-pass over the input
-// (k_rdc_sums_wide, k_rdc_smooth), as for the fifth_order front end.  Rotating chains only (no offset tuning).
+// samples, a tile starts and ends with a correction of zero, and the only change is one subtraction where a prefix is
+// looked up.  Buffers are multiples of four samples, so where a buffer ends INSIDE a tile (round 5: any buffer of at
+// least 8192 bytes, not only whole tiles - a tile then holds samples of at most two buffers) the samples before the
+// boundary have summed to zero as well, and a look-up behind the boundary takes the second buffer's averages.  The
+// averages come from a pre-pass over the input (k_rdc_sums_wide, k_rdc_smooth), as for the fifth_order front end.
+// Rotating chains only (no offset tuning).
 template <int V, bool RDC = false>
 __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_scan(const Params p)
 {
@@ -281,9 +284,13 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		if (lane >= 8 && lane < 16 && j1 >= j0 && t < last) g16[t] = (int16_t)pcm[t];
 	};
 
-	// (RDC: whole-tile buffers) the buffer tile gt lies in and the tile's place inside it, carried from tile to tile
-	const int tiles_per_buf = RDC ? N0 / kTileSamples : 1;
-	int rdc_b = RDC ? gt_begin / tiles_per_buf : 0, rdc_t = RDC ? gt_begin - rdc_b * tiles_per_buf : 0;
+	// (RDC) the buffer tile gt's first sample lies in and that sample's place inside it, carried from tile to tile
+	int rdc_b = 0, rdc_off = 0;
+	if constexpr (RDC) {
+		const long long g = (long long)gt_begin * kTileSamples;
+		rdc_b = (int)(g / N0);
+		rdc_off = (int)(g - (long long)rdc_b * N0);
+	}
 	// fm_demod's first output of every buffer (below, behind the output loop): xs = where the next buffer start that no
 	// tile has looked at yet lies, as a sample position relative to tile gt's first sample.  The outputs that complete
 	// in tile gt cover the samples [-ph, Et D - ph) of it; consecutive tiles' ranges follow each other without a gap.
@@ -308,17 +315,25 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			Et = __builtin_amdgcn_readfirstlane((ph + vs) / D);
 			ph_next = ph + vs - Et * D;
 		}
-		uint32_t dc1 = 0, dc2 = 0, dc3 = 0;  // c G(1), c G(2), c G(3) as packed int16 pairs
-		int dcI = 0, dcQ = 0;
+		// c G(1), c G(2), c G(3) as packed int16 pairs, for the buffer the tile starts in (lo) and the one that follows (hi);
+		// dc_nb: the tile's first sample of the second buffer (beyond the tile when it holds one buffer's samples only)
+		uint32_t dc1 = 0, dc2 = 0, dc3 = 0, dh1 = 0, dh2 = 0, dh3 = 0;
+		int dc_nb = 1 << 30;
 		if constexpr (RDC) {
 			const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + rdc_b);
-			if (++rdc_t == tiles_per_buf) { rdc_t = 0; rdc_b++; }
-			const int2 a = p.rdc_avg[idx];  // a scalar load: a vector one would share the in-order vmcnt with the tile prefetch
-			dcI = __builtin_amdgcn_readfirstlane(a.x); dcQ = __builtin_amdgcn_readfirstlane(a.y);
+			const int idx2 = __builtin_amdgcn_readfirstlane(s * p.nblocks + (rdc_b + 1 < p.nblocks ? rdc_b + 1 : rdc_b));
+			const int2 a = p.rdc_avg[idx], a2 = p.rdc_avg[idx2];  // scalar loads: a vector one would share the in-order vmcnt with the tile prefetch
+			const int dcI = __builtin_amdgcn_readfirstlane(a.x), dcQ = __builtin_amdgcn_readfirstlane(a.y);
+			const int dhI = __builtin_amdgcn_readfirstlane(a2.x), dhQ = __builtin_amdgcn_readfirstlane(a2.y);
 			dc1 = pack_iq((int16_t)dcI, (int16_t)dcQ);
 			dc2 = pack_iq((int16_t)(dcI + dcQ), (int16_t)(dcQ - dcI));
 			dc3 = pack_iq((int16_t)dcQ, (int16_t)-dcI);
-			if (gt + 1 == gt_end && writes_state && lane == 0) { sout->dc_avgI = dcI; sout->dc_avgQ = dcQ; }  // src/rtl_fm.c:1062-1063
+			dh1 = pack_iq((int16_t)dhI, (int16_t)dhQ);
+			dh2 = pack_iq((int16_t)(dhI + dhQ), (int16_t)(dhQ - dhI));
+			dh3 = pack_iq((int16_t)dhQ, (int16_t)-dhI);
+			dc_nb = N0 - rdc_off;
+			rdc_off += kTileSamples;
+			if (rdc_off >= N0) { rdc_off -= N0; rdc_b++; }  // N0 >= 4096: once at most
 		}
 
 		// ---- 1. stage S: chunk c = 64k + lane -> row c >> 3, 16-byte slot c & 7
@@ -405,7 +420,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			if constexpr (RDC) {
 				const int k = n & 3;
-				const uint32_t corr = k == 0 ? 0u : (k == 1 ? dc1 : (k == 2 ? dc2 : dc3));
+				const bool hi = n > dc_nb;  // (at the boundary itself k == 0: no correction either way)
+				const uint32_t c1 = hi ? dh1 : dc1, c2 = hi ? dh2 : dc2, c3 = hi ? dh3 : dc3;
+				const uint32_t corr = k == 0 ? 0u : (k == 1 ? c1 : (k == 2 ? c2 : c3));
 				Pv = pk_sub16(Pv, corr);
 			}
 			return Pv;
@@ -464,7 +481,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			__builtin_amdgcn_wave_barrier();
 			if (xs < lim) {
 				for (int x = xs + lane * N0; x < lim; x += 64 * N0) {
-					const int e = (int)__umulhi((uint32_t)(ph + x), p.D_magic);
+					const int e = D == 1 ? ph + x : (int)__umulhi((uint32_t)(ph + x), p.D_magic);
 					const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
 					const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
 					const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
@@ -492,6 +509,10 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	}
 	flush();
 	if (writes_state && lane == 0) {
+		if constexpr (RDC) {  // dc_block_raw_filter keeps the averages of the buffer it saw last (src/rtl_fm.c:1062-1063)
+			const int2 a = p.rdc_avg[(size_t)s * p.nblocks + (p.nblocks - 1)];
+			sout->dc_avgI = a.x; sout->dc_avgQ = a.y;
+		}
 		sout->prev_index = ph;
 		sout->now_r = carry_r;
 		sout->now_j = carry_j;
@@ -540,10 +561,12 @@ inline bool supported_front(const rtlfm_cfg &c)
 {
 	// at least two outputs per 4096-sample tile: a wave that starts mid-stream takes its first
 	// "previous output" from its warm-up tile
-	if (c.downsample_passes != 0 || c.downsample < 2 || c.downsample > kMaxD) return false;
+	// (downsample == 1, rtl_fm -s 1.2M: low_pass() hands every sample on - 4096 outputs per tile, the same kernel)
+	if (c.downsample_passes != 0 || c.downsample < 1 || c.downsample > kMaxD) return false;
 	if (c.comp_fir_size) return false;
-	// -E rdc: the rotated constant sums to zero over a tile only when buffers are whole tiles and the chain rotates
-	if (c.dc_block_raw && (c.offset_tuning || (c.block_len % kTileBytes))) return false;
+	// -E rdc: the rotated constant sums to zero over every four samples only when the chain rotates; a tile may hold
+	// samples of two buffers, not of three
+	if (c.dc_block_raw && (c.offset_tuning || c.block_len < (uint32_t)kTileBytes)) return false;
 	return true;  // else any buffer length (a multiple of 512 bytes): the run is one continuous sample stream here
 }
 
@@ -580,7 +603,7 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.variant = c.custom_atan; p.rotate = c.offset_tuning ? 0 : 1;
 	p.mode = c.mode; p.output_scale = c.output_scale;
 	p.D = c.downsample; p.q4096 = kTileSamples / p.D; p.r4096 = kTileSamples % p.D;
-	p.D_magic = (uint32_t)((0x100000000ull + (uint64_t)p.D - 1) / (uint64_t)p.D);
+	p.D_magic = p.D == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)p.D - 1) / (uint64_t)p.D);  // (D == 1: no division)
 	p.out_cap = kTileSamples / p.D + 2;
 	const long long run_bytes = (long long)nblocks * c.block_len;
 	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, (int)((run_bytes + kTileBytes - 1) / kTileBytes));

@@ -538,12 +538,13 @@ struct AtanNodesLds {
 // and put right in LDS), "the tile's last lane" is lane 4k - 1 instead of 63 wherever a carry is left for the next
 // tile or the state is archived, a ring's new prefix is copied inside LDS, and a wave that starts mid-stream
 // warms up on as many tiles as hold 1024 samples (every carried quantity depends on fewer than
-// 15 * 2^P - 5 <= 955 earlier samples).  MFMA engine only; the PT = false kernels are untouched.
+// 15 * 2^P - 5 <= 955 earlier samples).  MFMA engine only; the PT = false kernels are untouched.  Round 5: PT and RDC
+// together (the averages are per BUFFER and a partial tile ends its buffer: a tile never holds two buffers' samples).
 template <int P, bool FIR9, bool STD, bool MFMA0, bool RDC = false, bool PT = false>
 __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAVES_PER_SIMD)) k_fused(const Params p)
 {
 	static_assert(!RDC || MFMA0, "the raw DC block rides on the MFMA accumulators");
-	static_assert(!PT || (MFMA0 && !RDC), "partial tiles: MFMA engine, no raw DC block");
+	static_assert(!PT || MFMA0, "partial tiles: MFMA engine");
 	using L = Lds<P, FIR9, MFMA0>;
 	constexpr int CZ = L::cz;
 	__shared__ __attribute__((aligned(128))) uint32_t lds[L::total];
@@ -823,9 +824,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					uint32_t e[11];
 #pragma unroll
 					for (int k = 0; k < 5; k++) e[k] = lds[L::xh + 1 + k];
-					unpack_rot(first.x ^ 0x7f7f7f7fu, 0, rotate, e[5], e[6]);
-					unpack_rot(first.y ^ 0x7f7f7f7fu, 1, rotate, e[7], e[8]);
-					unpack_rot(first.z ^ 0x7f7f7f7fu, 0, rotate, e[9], e[10]);
+					unpack_rot(first.x ^ 0x7f7f7f7fu, 0, rotate, e[5], e[6], dcI, dcQ);
+					unpack_rot(first.y ^ 0x7f7f7f7fu, 1, rotate, e[7], e[8], dcI, dcQ);
+					unpack_rot(first.z ^ 0x7f7f7f7fu, 0, rotate, e[9], e[10], dcI, dcQ);
 					fix0 = tap_pk16(e[0], e[1], e[2], e[3], e[4], e[5]);
 					fix1 = tap_pk16(e[2], e[3], e[4], e[5], e[6], e[7]);
 					fix2 = tap_pk16(e[4], e[5], e[6], e[7], e[8], e[9]);
@@ -835,10 +836,10 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				if (next_bs) {
 					// archive x'[N-7..N-2] of the buffer that ends here: the last eight samples' raw bytes again
 					uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
-					unpack_rot(last.x ^ 0x7f7f7f7fu, 0, rotate, a0, a1);
-					unpack_rot(last.y ^ 0x7f7f7f7fu, 1, rotate, a2, a3);
-					unpack_rot(last.z ^ 0x7f7f7f7fu, 0, rotate, a4, a5);
-					unpack_rot(last.w ^ 0x7f7f7f7fu, 1, rotate, a6, a7);
+					unpack_rot(last.x ^ 0x7f7f7f7fu, 0, rotate, a0, a1, dcI, dcQ);
+					unpack_rot(last.y ^ 0x7f7f7f7fu, 1, rotate, a2, a3, dcI, dcQ);
+					unpack_rot(last.z ^ 0x7f7f7f7fu, 0, rotate, a4, a5, dcI, dcQ);
+					unpack_rot(last.w ^ 0x7f7f7f7fu, 1, rotate, a6, a7, dcI, dcQ);
 					if (lane == last_lane) {
 						lds[L::xh + 0] = a1; lds[L::xh + 1] = a2; lds[L::xh + 2] = a3;
 						lds[L::xh + 3] = a4; lds[L::xh + 4] = a5; lds[L::xh + 5] = a6;
@@ -1329,13 +1330,12 @@ inline int effective_engine(const Workspace &ws)
 
 // What the front end in emit mode plus staged kernels covers beyond supported(): 7..10 passes,
 // -M raw, and the squelch (rtlfm_hip.hip: run_fused_emit)
-// buffers that are not whole 8 KiB tiles (-W n) take the partial-tile kernels: MFMA engine, no raw DC block
+// buffers that are not whole 8 KiB tiles (-W n) take the partial-tile kernels: MFMA engine
 inline bool needs_partial_tiles(const rtlfm_cfg &c) { return (c.block_len % kTileBytes) != 0; }
 
 inline bool supported_emit(const rtlfm_cfg &c)
 {
 	if (c.downsample_passes < 1 || c.downsample_passes > RTLFM_MAX_PASSES) return false;
-	if (c.dc_block_raw) return false;
 	return c.downsample_passes > kMaxP || c.mode == RTLFM_MODE_RAW || c.squelch_level != 0 || c.report_levels != 0;
 }
 
@@ -1357,7 +1357,6 @@ inline bool supported(const rtlfm_cfg &c, int nblocks)
 	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
 		return false;
 	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
-	if (needs_partial_tiles(c) && c.dc_block_raw) return false;
 	if (c.squelch_level || c.report_levels) return false;
 	(void)nblocks;
 	// -E rdc: the RDC instantiations; -W n: the PT ones (both MFMA pass 0 only; rtlfm_hip.hip checks the engine)
@@ -1368,8 +1367,11 @@ template <int P, bool FIR9>
 static int launch_one(const Params &p, int waves, hipStream_t q)
 {
 	if (p.block_len % kTileBytes) {
-		if (!p.mfma_taps || p.rdc_avg) return -ENOTSUP;
-		if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true, false, true>), dim3(waves), dim3(64), 0, q, p);
+		if (!p.mfma_taps) return -ENOTSUP;
+		if (p.rdc_avg) {
+			if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true, true, true>), dim3(waves), dim3(64), 0, q, p);
+			else hipLaunchKernelGGL((k_fused<P, FIR9, false, true, true, true>), dim3(waves), dim3(64), 0, q, p);
+		} else if (p.variant == RTLFM_ATAN_STD) hipLaunchKernelGGL((k_fused<P, FIR9, true, true, false, true>), dim3(waves), dim3(64), 0, q, p);
 		else hipLaunchKernelGGL((k_fused<P, FIR9, false, true, false, true>), dim3(waves), dim3(64), 0, q, p);
 		return hipGetLastError() == hipSuccess ? 0 : -EIO;
 	}

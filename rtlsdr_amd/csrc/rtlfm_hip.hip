@@ -108,7 +108,7 @@ struct rtlfm_gpu {
 	struct Options {
 		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
 		int lpr_chunk = 2720;  // samples per lane of the one-pass deemph + low_pass_real kernel
-		int arb_span = 1;      // 0: k_deemph_spec_arb (round 4's form of config 3's tail) instead of k_deemph_arb_span
+		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
 	} opt;
 
@@ -1264,8 +1264,9 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
+	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);  // -E rdc in front of -M raw, the squelch, 7-10 passes
 	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, sin, sout, h->d_lut, q, h->deepA,
-	                  h->deep_stride);
+	                  h->deep_stride, rdc);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -1418,7 +1419,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg);
 	const bool can_box_emit = boxfused::supported_emit(h->cfg);
-	const bool can_deep = fused::supported_emit(h->cfg) && !(fused::needs_partial_tiles(h->cfg) && fused::effective_engine(h->fws) != 1);
+	const bool can_deep = fused::supported_emit(h->cfg) && !(mfma_only && fused::effective_engine(h->fws) != 1);
 	int r;
 	{
 		// this step reuses the res[] / d_cnt[] set and the state copy the step before last handed to

@@ -435,6 +435,63 @@ def test_buffers_of_any_512n_bytes(oracle_lib, front, L):
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, splits, opts, s_)
 
 
+@pytest.mark.parametrize("L", [12288, 20480, 512 * 23, 512 * 37, 32768, 1536])
+@pytest.mark.parametrize("front", ["p1rdc", "p3rdc", "p4rdc", "p4rdcfast", "p5firrdc", "p6firrdc", "p4rdcraw", "p4rdcsq", "p7firrdc",
+                                   "box10rdc", "box7fastrdc", "box42rdc", "box10rdcraw", "box10rdcsq",
+                                   "box1", "box1fast", "box1lut", "box1raw", "box1sq", "box1am", "box1rdc"])
+def test_what_round_four_left_on_the_staged_kernels(oracle_lib, front, L):
+    """tools/path_census.py of round 4: 57 of 561 accepted random configurations still took the staged front end - -E rdc
+    together with buffers that are not whole tiles (src/rtl_fm.c:1043-1065, :1869-1873), -E rdc in front of -M raw / the
+    squelch / 7 and more passes (the fifth_order front end's emit mode had no raw DC block), and low_pass with
+    downsample == 1 (rtl_fm -s 1.2M: optimal_settings gives 1, :1415).  All of them on the one-launch front ends now
+    (`last_path == 2`): the partial-tile kernels with the averages on pass 0's accumulators, a tile of the boxcar kernel
+    with two buffers' averages, 4096 outputs per tile at /1.  Drifting DC offsets, full-scale bytes, split launches,
+    segments that start anywhere."""
+    ov = {}
+    rdc = "rdc" in front
+    if front.startswith("box"):
+        D = int("".join(ch for ch in front[3:6] if ch.isdigit()))
+        ov = dict(downsample=D, downsample_passes=0, rate_out=int(2.4e6 / D))
+        if rdc and L < 8192:
+            pytest.skip("the raw DC block in front of the boxcar needs buffers of a tile at least (shorter: the staged kernels)")
+    else:
+        passes = int(front[1])
+        ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if "fir" in front else 0)
+        if L % (2 << passes):
+            pytest.skip("fifth_order needs buffers of whole groups of 2^(passes+1) bytes")
+    if rdc: ov["dc_block_raw"] = 1
+    if "fast" in front: ov["custom_atan"] = 1
+    if "lut" in front: ov["custom_atan"] = 2
+    if "raw" in front: ov["mode"] = capi.MODE_RAW
+    if "am" in front: ov.update(mode=capi.MODE_AM, output_scale=4)
+    if "sq" in front: ov["squelch_level"] = 300
+    nb, ns = 5, 5
+    cfg = make_cfg(ov, L, nb)
+    amp = 25.0 if ov.get("custom_atan") == 1 else 50.0
+    if ov.get("custom_atan") == 1 and front.startswith("box"):
+        amp = max(2.0, min(25.0, 500.0 / ov["downsample"]))
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=L + 17 * len(front), fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    if rdc:
+        rng = np.random.default_rng(L)
+        for s_ in range(ns - 1):  # a DC offset per stream that changes from buffer to buffer
+            for b in range(nb):
+                off = rng.integers(-30, 31, size=2)
+                blk = iq[s_, b * L:(b + 1) * L].astype(np.int32)
+                blk[0::2] += off[0]; blk[1::2] += off[1]
+                iq[s_, b * L:(b + 1) * L] = np.clip(blk, 0, 255).astype(np.uint8)
+    if ov.get("custom_atan") != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=L)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits, opts in ((None, None), ([(0, 1), (1, 3), (3, nb)], dict(fused_tiles_per_seg=3)), (None, dict(fused_waves=1)),
+                         (None, dict(fused_tiles_per_seg=1))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        assert used == 2, (front, L)
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_], (front, L, splits, opts, s_)
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"{front} L={L} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, splits, opts, s_)
+
+
 def test_options_by_name():
     """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
     from rtlsdr_amd.demod import GpuDemod
@@ -1525,9 +1582,11 @@ def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
     st0[ns - 1].deemph_avg = -70000
     st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
-    for splits in (None, [(0, 1), (1, nb)]):
+    # arb_span: round 5's form of the kernel (k_deemph_arb_span: the span linear in LDS), with 32 and 64 samples per lane
+    for splits, options in ((None, {}), ([(0, 1), (1, nb)], {}), (None, dict(arb_span=1)), ([(0, 1), (1, nb)], dict(arb_span=1, arb_chunk=64)),
+                            (None, dict(arb_span=1, arb_chunk=64))):
         outs = [[] for _ in range(ns)]
-        with GpuDemod(cfg, ns, 0) as g:
+        with GpuDemod(cfg, ns, 0, options=options) as g:
             for s in range(ns):
                 g.state_set(s, st_copy[s])
             d = torch.from_numpy(iq).cuda()
@@ -1539,9 +1598,9 @@ def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
             sts = [g.state_get(s) for s in range(ns)]
         for s in range(ns):
             got = np.concatenate(outs[s])
-            assert got.shape[0] == want_len[s], (splits, s)
-            assert_parity(got, want[s, :want_len[s]], cfg, f"{splits} stream {s}")
-            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (splits, s)
+            assert got.shape[0] == want_len[s], (splits, options, s)
+            assert_parity(got, want[s, :want_len[s]], cfg, f"{splits} {options} stream {s}")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (splits, options, s)
 
 
 @pytest.mark.parametrize("ov,sig", [

@@ -34,11 +34,11 @@ def main():
         _, _, path = T.gpu_run(cfg, iq, path=0)
         by[path] += 1
         if path == 1:
-            keys = tuple(sorted(k for k in ("dc_block_raw", "squelch_level", "post_downsample", "deemph", "dc_block_audio") if ov.get(k)))
-            why[(ov["mode"], ov["downsample_passes"], ov["downsample"] if not ov["downsample_passes"] else 0, L % 8192 != 0, keys)] += 1
+            keys = tuple(sorted(k for k in ("dc_block_raw", "offset_tuning", "squelch_level", "post_downsample", "deemph", "dc_block_audio") if ov.get(k)))
+            why[(ov["mode"], ov["downsample_passes"], ov["downsample"] if not ov["downsample_passes"] else 0, L, keys)] += 1
     print("runs by path (1 = staged front end, 2 = one-launch front end):", dict(by))
-    for k, v in why.most_common(40):
-        print(f"  {v:3d} x mode={k[0]} passes={k[1]} boxcar={k[2]} partial_tiles={k[3]} {k[4]}")
+    for k, v in why.most_common():  # every one of them
+        print(f"  {v:3d} x mode={k[0]} passes={k[1]} boxcar={k[2]} block_len={k[3]} {k[4]}")
 
 
 if __name__ == "__main__":
