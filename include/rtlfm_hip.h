@@ -191,6 +191,16 @@ int rtlfm_gpu_commit(rtlfm_gpu *h, int stream, uint32_t len);
  * other half, the next run's transfer overlaps this run's kernels.  One caller at a time.
  */
 int rtlfm_gpu_run(rtlfm_gpu *h);
+/*
+ * The same in two steps.  _begin takes what the ring's filling half holds and flips the halves (-EAGAIN as above;
+ * *taken, may be NULL = buffers per stream taken) - the only part of a run during which the producers must not
+ * acquire or push; _end queues the transfer and the kernels (-EINVAL without a begun run; _begin says -EBUSY while one
+ * is pending).  A caller that gates its producers itself (one that counts queued buffers: host/rtl_fm_hip.cpp) holds
+ * its gate around _begin only, so that a callback waits for a flip, never for a transfer, a first run's allocations or
+ * a kernel launch.  rtlfm_gpu_run() is _begin followed by _end.
+ */
+int rtlfm_gpu_run_begin(rtlfm_gpu *h, int *taken);
+int rtlfm_gpu_run_end(rtlfm_gpu *h);
 
 /*
  * The same on input already resident in device memory.

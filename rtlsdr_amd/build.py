@@ -39,9 +39,21 @@ def _obj(src: str) -> str:
     return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
 
 
-def _unit_stale(src: str) -> bool:
+def _flags_key(extra) -> str:
+    return " ".join(FLAGS + list(extra or []))
+
+
+def _unit_stale(src: str, extra=None) -> bool:
+    """An object is reused only if it is newer than everything it was built from AND was built with the same flags
+    (an A/B build with -D... must not leave its objects to a later plain build)."""
     o = _obj(src)
     if not os.path.exists(o):
+        return True
+    try:
+        with open(o + ".flags") as f:
+            if f.read() != _flags_key(extra):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(o)
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in UNIT_HEADERS[src]]
@@ -58,25 +70,37 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
-    """One object per translation unit (compiled side by side), then one link: librtlfm_hip.so."""
-    if not force and not needs_build():
+    """One object per translation unit (compiled side by side), then one link: librtlfm_hip.so.  Objects and the
+    library are written under a temporary name and renamed, and the whole build holds a file lock: several test
+    processes that find the library stale at once (pytest -n) neither link nor load half-written files."""
+    if not force and not extra and not needs_build():
         return OUT
+    import fcntl
     os.makedirs(OBJDIR, exist_ok=True)
-    procs = []
-    for src in SOURCES:
-        if not (force or extra or _unit_stale(src)):
-            continue
-        cmd = [_hipcc()] + FLAGS + ["-c", "-o", _obj(src), os.path.join(CSRC, src)] + (extra or [])
+    with open(os.path.join(OBJDIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not extra and not needs_build():
+            return OUT  # another process built it while this one waited
+        procs = []
+        tag = f".tmp{os.getpid()}"
+        for src in SOURCES:
+            if not (force or _unit_stale(src, extra)):
+                continue
+            cmd = [_hipcc()] + FLAGS + ["-c", "-o", _obj(src) + tag, os.path.join(CSRC, src)] + (extra or [])
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((src, cmd, subprocess.Popen(cmd)))
+        for src, cmd, p in procs:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+            os.replace(_obj(src) + tag, _obj(src))
+            with open(_obj(src) + ".flags", "w") as f:
+                f.write(_flags_key(extra))
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", OUT + tag] + [_obj(s) for s in SOURCES]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", OUT] + [_obj(s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        subprocess.check_call(cmd)
+        os.replace(OUT + tag, OUT)
     return OUT
 
 

@@ -174,6 +174,8 @@ _SIGNATURES = [
     ("rtlfm_gpu_acquire", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_uint32)]),
     ("rtlfm_gpu_commit", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("rtlfm_gpu_run", C.c_int, [C.c_void_p]),
+    ("rtlfm_gpu_run_begin", C.c_int, [C.c_void_p, _P(C.c_int)]),
+    ("rtlfm_gpu_run_end", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_run_device", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rtlfm_gpu_fetch", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, _P(C.c_int)]),

@@ -174,7 +174,10 @@ void demod_thread(App *a)
 			if (a->p.failed) break;
 			taken = a->p.queued;  // rtlfm_gpu_run takes everything that is queued
 		}
-		int r = rtlfm_gpu_run(a->gpu);
+		// The gate is held around the FLIP of the ring's halves only (rtlfm_gpu_run_begin): the transfer, a first run's
+		// allocations and the kernel launches (rtlfm_gpu_run_end) happen with the device thread already filling the other
+		// half - a callback never waits for a transfer or a kernel, as include/rtlfm_hip.h promises.
+		int r = rtlfm_gpu_run_begin(a->gpu, &taken);
 		{
 			std::lock_guard<std::mutex> g(a->p.m);
 			a->p.want_run = false;
@@ -183,6 +186,7 @@ void demod_thread(App *a)
 			a->p.cv_room.notify_all();
 		}
 		if (r == -EAGAIN) { std::this_thread::yield(); continue; }
+		if (r == 0) r = rtlfm_gpu_run_end(a->gpu);
 		std::vector<int16_t> pcm((size_t)cap);
 		int n = 0;
 		if (r == 0) r = rtlfm_gpu_fetch(a->gpu, 0, pcm.data(), cap, &n);

@@ -167,6 +167,15 @@ extern "C" int32_t rtlfm_deemph_a(int32_t rate_out, int32_t tc_us)
 	return (int32_t)round(1.0 / (1.0 - exp(-1.0 / (rate_out * tc))));
 }
 
+// the first fifth_order pass that is handed a length which is not a multiple of four elements (src/rtl_fm.c:1188-1191),
+// or downsample_passes if there is none; buffers are multiples of 512 bytes, so this is pass 8 or 9
+static int first_irregular_pass(const rtlfm_cfg &c)
+{
+	for (int p = 0; p < c.downsample_passes; p++)
+		if ((c.block_len >> p) % 4) return p;
+	return c.downsample_passes;
+}
+
 // per-block decimated complex samples, or -1 when the boxcar phase makes it vary
 static int dec_per_block(const rtlfm_cfg *c)
 {
@@ -181,7 +190,7 @@ extern "C" int rtlfm_result_len(const rtlfm_cfg *c)
 	if (!c) return -EINVAL;
 	int n = dec_per_block(c);
 	if (n < 0) return -1;
-	if (c->mode == RTLFM_MODE_RAW) return 2 * n;
+	if (c->mode == RTLFM_MODE_RAW) return c->downsample_passes > 0 ? (int)(c->block_len >> c->downsample_passes) : 2 * n;
 	if (c->post_downsample > 1) n /= c->post_downsample;
 	if (c->rate_out2 > 0) {
 		if (c->resampler == RTLFM_RESAMPLE_ARBITRARY)
@@ -197,7 +206,7 @@ extern "C" int rtlfm_result_cap(const rtlfm_cfg *c)
 	int n0 = (int)(c->block_len / 2);
 	int n = c->downsample_passes > 0 ? n0 >> c->downsample_passes
 	                                  : (c->downsample > 1 ? n0 / c->downsample + 1 : n0);
-	if (c->mode == RTLFM_MODE_RAW) return 2 * n;
+	if (c->mode == RTLFM_MODE_RAW) return 2 * n + 1;
 	if (c->rate_out2 > 0 && c->resampler == RTLFM_RESAMPLE_ARBITRARY && c->rate_out > 0) {
 		long long up = (long long)n * c->rate_out2 / c->rate_out + 2;
 		if (up > n) n = (int)up;
@@ -210,8 +219,9 @@ static int validate_cfg(const rtlfm_cfg *c)
 	if (c->mode < RTLFM_MODE_FM || c->mode > RTLFM_MODE_RAW) return -EINVAL;
 	if (c->block_len < 512 || c->block_len > RTLFM_MAX_BLOCK_LEN || c->block_len % 512) return -EINVAL;
 	if (c->downsample_passes < 0 || c->downsample_passes > RTLFM_MAX_PASSES) return -EINVAL;
-	// every fifth_order call must see a length that is a multiple of 4 elements
-	if (c->downsample_passes > 0 && c->block_len % (2u << c->downsample_passes)) return -EINVAL;
+	// (a buffer the passes do not divide - nine or ten passes, 512 n bytes with n odd / n % 4 != 0 - is something the
+	// reference runs, src/rtl_fm.c:1188-1191: the last passes then see lengths that are not multiples of four elements;
+	// k_fifth_irregular, staged_kernels.h)
 	if (c->downsample_passes == 0 && c->downsample < 1) return -EINVAL;
 	// a buffer shorter than the boxcar leaves low_pass() with lp_len == 0 and fm_demod() then reads
 	// lowpassed[-2] (src/rtl_fm.c:955-956): outside the reference's domain
@@ -573,16 +583,18 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	}
 	int *slot = option_slot(h, name);
 	if (!slot) return -ENOENT;
+	// every range check first: a refused value must leave the handle as it was
 	if ((!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) && value < 1) return -EINVAL;
-	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
-	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
-	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_min_tiles")) h->fws.plan_by_caller = true;       // ... and so do these
 	if (!strcmp(name, "pass0_engine") && (value < -1 || value > 1)) return -EINVAL;
 	if ((!strcmp(name, "fused_min_tiles") || !strcmp(name, "fused_tiles_per_seg")) && value < 0) return -EINVAL;
 	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
 	// the chunk tables of the one-pass deemph + low_pass_real kernel are sized from it: keep it in a sane range
 	if (!strcmp(name, "lpr_chunk") && (value < 256 || value > (1 << 20))) return -EINVAL;
 	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;
+	// ... then what an accepted value implies
+	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
+	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
+	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_min_tiles")) h->fws.plan_by_caller = true;       // ... and so do these
 	*slot = (int)value;
 	return 0;
 }
@@ -1045,6 +1057,46 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	return 0;
 }
 
+// Passes first .. passes - 1 where `first` is handed a length that is not a multiple of four elements, and everything
+// up to mode_demod() behind them (staged_kernels.h, k_fifth_irregular); then the ordinary audio tail.  `cur` holds the
+// level in front of pass `first` (n_in samples per buffer, buffers back to back).
+static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_stride, int T, bool varcnt,
+                    int nblocks, int Nblk, int D, int16_t *final_dst, size_t final_stride, int32_t *d_out_len);
+static int run_irregular_rest(rtlfm_gpu *h, const uint32_t *cur, size_t xstride, int first, int nblocks, int16_t *d_out,
+                              size_t out_stride, int32_t *d_out_len, const uint8_t *d_iq, size_t iq_bytes)
+{
+	const rtlfm_cfg &c = h->cfg;
+	const int S = h->nstreams;
+	hipStream_t q = h->stream;
+	TailPlan tp = plan_tail(c);
+	if (tp.any()) {
+		int r = ensure_res_buffers(h, d_iq, iq_bytes);
+		if (r < 0) return r;
+	}
+	int16_t *dd; size_t dds;
+	tail_route(h, tp, d_out, out_stride, &dd, &dds);
+	IrregularParams ip{};
+	ip.X = cur; ip.xstride = xstride; ip.n_in = (int)((c.block_len / 2) >> first); ip.nblocks = nblocks; ip.nstreams = S;
+	ip.first = first; ip.passes = c.downsample_passes; ip.lp_len = (int)(c.block_len >> c.downsample_passes);
+	ip.fir = c.comp_fir_size == 9 ? 1 : 0; ip.mode = c.mode; ip.variant = c.custom_atan; ip.output_scale = c.output_scale;
+	ip.squelch_level = c.squelch_level; ip.report_levels = c.report_levels; ip.omit_dc_fix = c.dc_block_raw;
+	ip.lut = h->d_lut; ip.R = dd; ip.rstride = dds;
+	ip.levels = (c.squelch_level || c.report_levels) ? h->d_levels : nullptr;
+	ip.sin = h->st[h->st_cur]; ip.sout = h->st[(h->st_cur + 1) % 3];
+	if (2 * ip.n_in + 8 > kIrregularMaxElems) return -ENOTSUP;
+	k_fifth_irregular<<<(unsigned)((S + 63) / 64), 64, 0, q>>>(ip);
+	if (c.mode == RTLFM_MODE_RAW) {
+		if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, nblocks * ip.lp_len);
+		return 0;
+	}
+	const int Nblk = ip.lp_len / 2, T = nblocks * Nblk;
+	if (T == 0) {  // every buffer is down to one element or none: fm_demod() has nothing to pair
+		if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 0);
+		return 0;
+	}
+	return run_tail(h, tp, dd, dds, T, false, nblocks, Nblk, 1, d_out, out_stride, d_out_len);
+}
+
 static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks, int16_t *d_out,
                       size_t out_stride, int32_t *d_out_len)
 {
@@ -1078,11 +1130,18 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	int Nblk, D;    // block geometry for "first output of a block" tests
 	bool varcnt = false;
 	if (c.downsample_passes > 0) {
-		for (int p = 0; p < c.downsample_passes; p++) {
+		const int first_irr = first_irregular_pass(c);
+		for (int p = 0; p < first_irr; p++) {
 			int N = N0 >> p;
 			k_fifth<<<grid_for((size_t)S * nblocks * (N / 2)), 256, 0, q>>>(cur, oth, h->xstride, N, nblocks, S,
 			                                                              p, sin, sout);
 			std::swap(cur, oth);
+		}
+		if (first_irr < c.downsample_passes) {
+			r = timing_end(h, ev);
+			if (r < 0) return r;
+			return run_irregular_rest(h, cur, h->xstride, first_irr, nblocks, d_out, out_stride, d_out_len, d_iq,
+			                          iq_extent(h, stream_stride, nblocks));
 		}
 		Nblk = N0 >> c.downsample_passes;
 		D = 1;
@@ -1271,12 +1330,16 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	r = timing_end(h, ev);
 	if (r < 0) return r;
 	uint32_t *cur = h->deepA, *oth = h->deepB;
-	for (int p = level; p < c.downsample_passes; p++) {
+	const int first_irr = first_irregular_pass(c);
+	for (int p = level; p < c.downsample_passes && p < first_irr; p++) {
 		const int N = N0 >> p;
 		k_fifth<<<grid_for((size_t)S * nblocks * (N / 2)), 256, 0, q>>>(cur, oth, h->deep_stride, N, nblocks, S, p,
 		                                                              sin, sout);
 		std::swap(cur, oth);
 	}
+	if (first_irr < c.downsample_passes)  // nine or ten passes on buffers they do not divide: the reference's own loops from here
+		return run_irregular_rest(h, cur, h->deep_stride, first_irr, nblocks, d_out, out_stride, d_out_len, d_iq,
+		                          iq_extent(h, stream_stride, nblocks));
 	const int Nblk = N0 >> c.downsample_passes;
 	const int T = nblocks * Nblk;
 	if (c.downsample_passes > level && c.comp_fir_size == 9) {
@@ -1511,6 +1574,8 @@ struct Ingest {
 	bool result_one_block = false;              // d_result[1] points into d_result[0]'s allocation
 	int32_t *d_result_len[2] = {nullptr, nullptr};
 	size_t ostride = 0;
+	int pending_f = -1, pending_nb = 0;         // rtlfm_gpu_run_begin() has flipped the halves, _end() has not run yet
+	bool pending_ragged = false;
 	int last = -1;                              // half of the last run
 	int prev = -1;                              // ... and of the run before it (rtlfm_gpu_fetch_all_prev)
 	int tail_par[2] = {0, 0};                   // per half: step parity of its run, and whether that run left an audio tail
@@ -1632,6 +1697,7 @@ static void ingest_reset(rtlfm_gpu *h)
 	for (int s = 0; s < h->nstreams; s++) in->open_slot[s].store(0);
 	in->last = -1;
 	in->prev = -1;
+	in->pending_f = -1;
 	in->mirror_valid = false;
 }
 
@@ -1815,16 +1881,20 @@ static int run_ragged(rtlfm_gpu *h, Ingest *in, int f, int nb)
 	return 0;
 }
 
-extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
+// rtlfm_gpu_run() in two steps, for a caller that gates its producers around the flip only (host/rtl_fm_hip.cpp): _begin
+// takes what the ring's filling half holds - every stream the same number of buffers, no slot open - and flips the
+// halves, which is all that must exclude the producers; _end queues the H2D copy and the kernels.  Between the two the
+// producers already fill the other half.  *taken (may be NULL) = buffers per stream the run took.
+extern "C" int rtlfm_gpu_run_begin(rtlfm_gpu *h, int *taken)
 {
 	if (!h) return -EINVAL;
 	int r = ingest_ensure(h);
 	if (r < 0) return r;
 	Ingest *in = h->ing;
+	if (in->pending_f >= 0) return -EBUSY;  // a begun run has not been ended
 	HIP_TRY(hipSetDevice(h->device));
 	const int S = h->nstreams;
 	const uint32_t L = h->cfg.block_len;
-	const size_t stride = (size_t)h->cap_blocks * L;
 	int f, nb;
 	bool ragged = false;
 	{
@@ -1849,6 +1919,24 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 		for (int s = 0; s < S; s++) in->pushed[f ^ 1][s].store(0);
 		in->fill = f ^ 1;
 	}
+	in->pending_f = f; in->pending_nb = nb; in->pending_ragged = ragged;
+	if (taken) *taken = nb;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_run_end(rtlfm_gpu *h)
+{
+	if (!h || !h->ing) return -EINVAL;
+	Ingest *in = h->ing;
+	if (in->pending_f < 0) return -EINVAL;  // nothing begun
+	HIP_TRY(hipSetDevice(h->device));
+	const int S = h->nstreams;
+	const uint32_t L = h->cfg.block_len;
+	const size_t stride = (size_t)h->cap_blocks * L;
+	const int f = in->pending_f, nb = in->pending_nb;
+	const bool ragged = in->pending_ragged;
+	in->pending_f = -1;  // whatever happens below, the buffers of this run are gone from the ring
+	int r;
 	// d_in[f] is free once the kernels of the run that read it are done
 	if (in->run_pending[f]) {
 		HIP_TRY(hipStreamWaitEvent(in->copy_stream, in->ev_run[f], 0));
@@ -1873,6 +1961,13 @@ extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
 	in->last = f;
 	in->mirror_valid = false;
 	return 0;
+}
+
+extern "C" int rtlfm_gpu_run(rtlfm_gpu *h)
+{
+	int r = rtlfm_gpu_run_begin(h, nullptr);
+	if (r < 0) return r;
+	return rtlfm_gpu_run_end(h);
 }
 
 // Results of the run BEFORE the last one (they stay valid until the second run after theirs).  Waits for

@@ -481,6 +481,126 @@ k_simple_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restri
 	}
 }
 
+// ---- fifth_order on lengths its passes do not divide (round 5) -------------------------------------------------
+// `rtl_fm -W n -F 9` with nine or ten passes and n odd (n % 4 != 0 for ten) is something the reference runs
+// (src/rtl_fm.c:1188-1191): pass 8 (or 9) is then called with a length that is not a multiple of four elements - it
+// produces ceil(length / 4) outputs per component from whatever the array holds, the Q call (`lowpassed + 1,
+// length - 1`) sees another count than the I call, the last passes stop decimating, and everything behind them
+// (generic_fir, rms, the demodulators, fm_demod's pre_r / pre_j) works on an ODD number of elements and pairs I with Q
+// of different samples.  None of that is arithmetic worth parallelising - a buffer is down to at most 512 samples
+// there - and all of it is defined by the reference's loops over its `lowpassed` array, so those loops are what runs
+// here: one lane per stream walks its buffers in order with the array in private memory, from the first pass whose
+// length is not a multiple of four to mode_demod().  The regular passes in front (k_fused emit / k_fifth) and the
+// audio tail behind (run_tail, result_len = lp_len / 2 per buffer) are the ordinary kernels.
+constexpr int kIrregularMaxElems = 1024 + 16;  // block_len >> 8 elements at most (RTLFM_MAX_BLOCK_LEN = 262144)
+struct IrregularParams {
+	const uint32_t *X; size_t xstride;  // packed (I, Q) of the level in front of pass `first`: n_in samples per buffer
+	int n_in, nblocks, nstreams;
+	int first, passes;                  // passes first .. passes - 1 run here
+	int lp_len;                         // block_len >> passes: elements mode_demod() is given
+	int fir, mode, variant, output_scale, squelch_level, report_levels, omit_dc_fix;
+	const int32_t *lut;
+	int16_t *R; size_t rstride;         // result: lp_len / 2 samples per buffer (raw: lp_len elements)
+	int32_t *levels;                    // [stream][nblocks] rms() per buffer (squelch / -L), or nullptr
+	const state_t *sin; state_t *sout;
+};
+
+__global__ void __launch_bounds__(64) k_fifth_irregular(const IrregularParams p)
+{
+	const int s = (int)(blockIdx.x * 64 + threadIdx.x);
+	if (s >= p.nstreams) return;
+	int16_t lp[kIrregularMaxElems];
+	const state_t &in = p.sin[s];
+	state_t &out = p.sout[s];
+	int16_t hi[RTLFM_MAX_PASSES][6], hq[RTLFM_MAX_PASSES][6], di[9], dq[9];
+	for (int q = p.first; q < p.passes; q++)
+		for (int j = 0; j < 6; j++) { hi[q][j] = in.lp_i_hist[q][j]; hq[q][j] = in.lp_q_hist[q][j]; }
+	for (int j = 0; j < 9; j++) { di[j] = in.droop_i_hist[j]; dq[j] = in.droop_q_hist[j]; }
+	int pre_r = in.pre_r, pre_j = in.pre_j, hits = in.squelch_hits;
+	// fifth_order(), src/rtl_fm.c:777-806, as it is
+	auto fifth = [&](int16_t *data, int length, int16_t *hist) {
+		int a = hist[1], b = hist[2], c = hist[3], d = hist[4], e = hist[5], f = data[0];
+		data[0] = (int16_t)((a + (b + e) * 5 + (c + d) * 10 + f) >> 4);
+		for (int i = 4; i < length; i += 4) {
+			a = c; b = d; c = e; d = f;
+			e = data[i - 2];
+			f = data[i];
+			data[i / 2] = (int16_t)((a + (b + e) * 5 + (c + d) * 10 + f) >> 4);
+		}
+		hist[0] = (int16_t)a; hist[1] = (int16_t)b; hist[2] = (int16_t)c; hist[3] = (int16_t)d; hist[4] = (int16_t)e; hist[5] = (int16_t)f;
+	};
+	// generic_fir(), :808-831
+	auto fir9 = [&](int16_t *data, int length, int16_t *hist) {
+		const int32_t *t = k_cic9[p.passes];
+		for (int d = 0; d < length; d += 2) {
+			const int16_t temp = data[d];
+			int h[9];
+			for (int j = 0; j < 9; j++) h[j] = hist[j];
+			data[d] = (int16_t)fir9_tap(h, t);
+			for (int j = 0; j < 8; j++) hist[j] = hist[j + 1];
+			hist[8] = temp;
+		}
+	};
+	const int len0 = 2 * p.n_in;  // elements pass `first` is given
+	const int n_res = p.mode == RTLFM_MODE_RAW ? p.lp_len : p.lp_len / 2;
+	for (int b = 0; b < p.nblocks; b++) {
+		const uint32_t *x = p.X + (size_t)s * p.xstride + (size_t)b * p.n_in;
+		for (int k = 0; k < p.n_in; k++) { const iq16 w = unpack_iq(x[k]); lp[2 * k] = w.i; lp[2 * k + 1] = w.q; }
+		for (int k = len0; k < len0 + 8; k++) lp[k] = 0;
+		for (int q = p.first; q < p.passes; q++) {
+			const int length = len0 >> (q - p.first);
+			fifth(lp, length, hi[q]);
+			fifth(lp + 1, length - 1, hq[q]);
+		}
+		const int lp_len = p.lp_len;
+		if (p.fir) {  // :1193-1199
+			fir9(lp, lp_len, di);
+			fir9(lp + 1, lp_len - 1, dq);
+		}
+		if ((p.squelch_level || p.report_levels) && lp_len > 0) {
+			// rms(), :1083-1112, and the squelch, :1204-1215
+			uint32_t pw = 0; int32_t t = 0;
+			int step = 1;
+			while (lp_len > step * 32768) ++step;
+			for (int i = 0; i < lp_len; i += step) { const int v = lp[i]; t = (int32_t)((uint32_t)t + (uint32_t)v); pw += (uint32_t)(v * v); }
+			double r;
+			if (p.omit_dc_fix) r = sqrt((double)pw / (lp_len / step));
+			else {
+				const double dc = (double)(int32_t)((uint32_t)t * (uint32_t)step) / (double)lp_len;
+				const double err = t * 2 * dc - dc * dc * lp_len;
+				r = sqrt((pw - err) / lp_len);
+			}
+			const int sr = r == r ? (int)r : INT32_MIN;  // (int)NaN is INT_MIN on the reference's machine: the squelch skips it
+			if (p.levels) p.levels[(size_t)s * p.nblocks + b] = sr;
+			if (p.squelch_level && sr >= 0) {
+				if (sr < p.squelch_level) { hits++; for (int i = 0; i < lp_len; i++) lp[i] = 0; }
+				else hits = 0;
+			}
+		}
+		int16_t *res = p.R + (size_t)s * p.rstride + (size_t)b * n_res;
+		if (p.mode == RTLFM_MODE_FM) {
+			// fm_demod(), :932-959; with fewer than two elements the reference reads lowpassed[-1]: nothing is produced
+			if (lp_len >= 2) {
+				res[0] = (int16_t)disc_std(lp[0], lp[1], pre_r, pre_j);
+				for (int i = 2; i < lp_len - 1; i += 2)
+					res[i / 2] = (int16_t)discriminate(p.variant, lp[i], lp[i + 1], lp[i - 2], lp[i - 1], p.lut);
+				pre_r = lp[lp_len - 2]; pre_j = lp[lp_len - 1];
+			}
+		} else if (p.mode == RTLFM_MODE_RAW) {
+			for (int i = 0; i < lp_len; i++) res[i] = lp[i];
+		} else {
+			// am_demod / usb_demod / lsb_demod, :961-1000: pairs (lp[i], lp[i + 1]) for i = 0, 2, ... < lp_len
+			for (int i = 0; i < lp_len; i += 2)
+				if (i / 2 < n_res) res[i / 2] = simple_demod(p.mode, pack_iq(lp[i], lp[i + 1]), p.output_scale);
+		}
+	}
+	for (int q = p.first; q < p.passes; q++)
+		for (int j = 0; j < 6; j++) { out.lp_i_hist[q][j] = hi[q][j]; out.lp_q_hist[q][j] = hq[q][j]; }
+	for (int j = 0; j < 9; j++) { out.droop_i_hist[j] = di[j]; out.droop_q_hist[j] = dq[j]; }
+	if (p.mode == RTLFM_MODE_FM) { out.pre_r = pre_r; out.pre_j = pre_j; }
+	if (p.squelch_level) out.squelch_hits = hits;
+}
+
 // ------------------------------------------------------------- audio tail ----
 // low_pass_simple (src/rtl_fm.c:739-753): sums of `step`, no divide.
 __global__ void __launch_bounds__(256)

@@ -492,6 +492,43 @@ def test_what_round_four_left_on_the_staged_kernels(oracle_lib, front, L):
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, splits, opts, s_)
 
 
+@pytest.mark.parametrize("L", [512, 1536, 2560, 3072, 512 * 7, 512 * 13, 512 * 30])
+@pytest.mark.parametrize("front", ["p9", "p9fir", "p9fast", "p9lutsq", "p9am", "p9raw", "p10", "p10fir", "p10usb", "p10rawsq", "p10deemph"])
+def test_fifth_order_on_buffers_its_passes_do_not_divide(oracle_lib, front, L):
+    """`rtl_fm -W n -F 9` with nine or ten passes and a buffer of 512 n bytes that 2^(passes + 1) does not divide
+    (src/rtl_fm.c:1188-1191): the last passes are handed lengths that are not multiples of four elements - ceil(len / 4)
+    outputs per component, the Q call another count than the I call, odd element counts behind them (generic_fir, rms,
+    fm_demod's pre_r / pre_j pair I with Q of different samples), buffers that come down to one element or none.  The
+    library refused these with -EINVAL until round 5; now the regular passes run on the ordinary kernels and the rest is
+    the reference's own loops, one lane per stream (k_fifth_irregular).  Against the oracle: outputs, counts and the
+    carried state, through the automatic path (the six-pass front end's emit mode in front) and the staged kernels,
+    one run and split runs.  Lengths the passes DO divide take the ordinary kernels and are here as the control."""
+    passes = int("".join(ch for ch in front[1:3] if ch.isdigit()))
+    ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if "fir" in front else 0, rate_out=2000)
+    if "fast" in front: ov["custom_atan"] = 1
+    if "lut" in front: ov["custom_atan"] = 2
+    if "raw" in front: ov["mode"] = capi.MODE_RAW
+    if "am" in front: ov.update(mode=capi.MODE_AM, output_scale=2)
+    if "usb" in front: ov.update(mode=capi.MODE_USB, output_scale=3)
+    if "sq" in front: ov["squelch_level"] = 2000
+    if "deemph" in front: ov.update(deemph=1, deemph_a=3)
+    nb, ns = 7, 5
+    cfg = make_cfg(ov, L, nb)
+    amp = 20.0 if ov.get("custom_atan") == 1 else 50.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=L + 13 * len(front), fs=1.024e6, dev_hz=300.0, amplitude=amp)
+    if ov.get("custom_atan") != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=L)[0]
+    iq[1, : L * 3] = 127  # a stream that is silent for three buffers: the squelch closes
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=2)
+    for path, splits in ((0, None), (0, [(0, 2), (2, 3), (3, nb)]), (1, None)):
+        outs, sts, used = gpu_run(cfg, iq, path=path, splits=splits)
+        assert used == (1 if path == 1 else 2), (front, L, path, used)
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_], (front, L, path, splits, s_, len(outs[s_]), want_len[s_])
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"{front} L={L} path={path} {splits} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, path, splits, s_)
+
+
 def test_options_by_name():
     """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
     from rtlsdr_amd.demod import GpuDemod
@@ -707,17 +744,14 @@ def _random_cfg(rng):
 
 def _skip_only_outside_reference_domain(oracle_lib, cfg, L, err):
     """rtlfm_gpu_create may only reject what the reference itself cannot run: the oracle (pinned to
-    the reference) must refuse the same configuration, or the rejection is a -EDOM / -EINVAL the
-    header documents as outside the reference's domain."""
+    the reference) must refuse the same configuration - anything else fails the test."""
     iq = synth.fm_iq_u8(1, L // 2 * 2, seed=1)
     try:
         oracle_lib.run_batch(cfg, iq, nthreads=1)
     except RuntimeError:
         pytest.skip(f"outside the reference's domain (oracle refuses it too): {err}")
-    import errno
-    if err.code in (-errno.EDOM, -errno.EINVAL):
-        pytest.skip(f"outside the reference's domain: {err}")
-    raise AssertionError(f"the library rejects a configuration the reference runs: {err}")
+    # (until round 5 any -EDOM / -EINVAL was let through here, which hid `rtl_fm -W 1 -F 9` with nine passes)
+    raise AssertionError(f"the library rejects a configuration the reference (the oracle pinned to it) runs: {err}")
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RTLFM_SWEEP", "48"))))
