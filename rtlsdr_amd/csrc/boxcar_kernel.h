@@ -58,6 +58,10 @@ struct Params {
 	uint32_t *emit_iq;
 	size_t emit_iq_stride;      // dwords between streams
 	const int2 *rdc_avg;        // RDC kernels: [stream][nblocks] (avgI, avgQ) of dc_block_raw_filter (k_rdc_sums_wide / k_rdc_smooth)
+	// SQ kernels (the power squelch / -L behind the boxcar, round 5): [stream][nblocks] (sum of squares, sum) of every
+	// buffer's decimated elements, both modulo 2^32 as rms() has them (src/rtl_fm.c:1093-1098) - zeroed by the host, added
+	// to with atomics (a buffer's outputs come from several waves); k_squelch_apply makes the decisions
+	uint32_t *sq_sums;
 };
 
 // Per 8 KiB tile (round 1 walked every window: O(D/2) LDS gathers and dot products per output and
@@ -169,9 +173,14 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fu
 // boundary have summed to zero as well, and a look-up behind the boundary takes the second buffer's averages.  The
 // averages come from a pre-pass over the input (k_rdc_sums_wide, k_rdc_smooth), as for the fifth_order front end.
 // Rotating chains only (no offset tuning).
-template <int V, bool RDC = false>
+// SQ: the launch also leaves what rms() needs of every buffer's decimated IQ (Params::sq_sums), so that the squelch needs
+// no emit mode: a muted buffer's PCM is zero whatever the samples were (the discriminator of zeroed samples, and of the
+// first sample behind them, is atan2(0, 0) = 0; am / usb / lsb of zeros are zeros), and k_squelch_apply writes those
+// zeros once it knows the levels.  Buffers of at least 8192 samples (a tile's outputs belong to two buffers at most).
+template <int V, bool RDC = false, bool SQ = false>
 __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_scan(const Params p)
 {
+	static_assert(!SQ || V != 3, "emit mode hands the samples themselves on");
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	const int lane = threadIdx.x;
 	const int wave = blockIdx.x;
@@ -295,10 +304,12 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	// tile has looked at yet lies, as a sample position relative to tile gt's first sample.  The outputs that complete
 	// in tile gt cover the samples [-ph, Et D - ph) of it; consecutive tiles' ranges follow each other without a gap.
 	int xs;
+	int sq_b;  // SQ: the buffer the outputs in front of that start belong to (-1: there are none)
 	{
 		const long long g0 = (long long)gt_begin * kTileSamples - ph;          // the only 64-bit division of the wave
 		const long long bb0 = g0 <= 0 ? 0 : (g0 + N0 - 1) / N0;
 		xs = (int)(bb0 * N0 - (long long)gt_begin * kTileSamples);
+		sq_b = (int)bb0 - 1;
 	}
 	fused::ProgressPrio prio(gt_end - gt_begin, 0);
 	for (int gt = gt_begin; gt < gt_end; gt++) {
@@ -430,6 +441,13 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		auto P_at = [&](int e) -> uint32_t { return P_n((e + 1) * D - ph); };  // P(n_e) for e >= 0
 		const int R = p.R;
 		const int e0 = lane * R;
+		// SQ: the tile's first output of the NEXT buffer (the outputs that complete in this tile cover its samples
+		// [-ph, Et D - ph); xs = where the next buffer starts), and the lane's sums for both buffers
+		int sq_eb = 1 << 30;
+		uint32_t sq_p0 = 0, sq_t0 = 0, sq_p1 = 0, sq_t1 = 0;
+		if constexpr (SQ) {
+			if (xs < Et * D - ph) sq_eb = D == 1 ? ph + xs : (int)__umulhi((uint32_t)(ph + xs), p.D_magic);
+		}
 		uint32_t prevP, b;
 		{
 			const uint32_t a1 = P_at(e0 > 0 ? e0 - 1 : 0), a2 = P_at(e0 > 1 ? e0 - 2 : 0);
@@ -451,6 +469,12 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 					if (e == Et - 1) { lds[ScanLds::scratch] = curP; lds[ScanLds::scratch + 1] = z; }
 				}
 			} else if (e < Et) {
+				if constexpr (SQ) {
+					// rms()'s two sums over the elements of this output (I and Q), by the buffer the output belongs to
+					const fused::short2_t zz = fused::as_s2(z), ones = {(short)1, (short)1};
+					const uint32_t sq = (uint32_t)__builtin_amdgcn_sdot2(zz, zz, 0, false), sm = (uint32_t)__builtin_amdgcn_sdot2(zz, ones, 0, false);
+					if (e < sq_eb) { sq_p0 += sq; sq_t0 += sm; } else { sq_p1 += sq; sq_t1 += sm; }
+				}
 				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
 				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
 				const int cr = fused::dot2_first(z, b);
@@ -469,27 +493,47 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			prevP = curP; b = z; curP = nxtP;
 		}
-		if (V != 1 && !EMIT && (V != 0 || p.mode == RTLFM_MODE_FM) && Et > 0) {
-			// fm_demod's first sample of a buffer is always polar_discriminant, whatever -A says
-			// (src/rtl_fm.c:935-937): redone here, behind the loop, instead of as a second discriminator under a
-			// per-lane condition inside it (where it cost every output of a -A fast run the std path's
-			// instructions as well).  Buffer b starts at run sample b N0 and its first output is output
-			// (p0 + b N0) / D of the run: lane c looks at the c-th buffer start that falls into this tile's range.
-			// (p0 + b N0) / D - kb = (ph + x) / D with x = b N0 - 4096 gt, the buffer start relative to this tile: small
-			// numbers, one multiply-high per buffer start (round 5; three 64-bit divisions per tile until then).
-			const int lim = Et * D - ph;
-			__builtin_amdgcn_wave_barrier();
-			if (xs < lim) {
-				for (int x = xs + lane * N0; x < lim; x += 64 * N0) {
-					const int e = D == 1 ? ph + x : (int)__umulhi((uint32_t)(ph + x), p.D_magic);
-					const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
-					const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
-					const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
-					const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
-					const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
-					pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v0;
+		if constexpr (SQ) {
+			if (emit && Et > 0) {
+				// the wave's sums into the buffers' (an atomic per sum: four per tile at most; buffers whose outputs this tile
+				// does not hold add nothing)
+				const int a0 = wave_inclusive_scan((int)sq_p0), a1 = wave_inclusive_scan((int)sq_t0);
+				if (lane == 63 && sq_b >= 0 && sq_eb > 0) {
+					uint32_t *d = p.sq_sums + ((size_t)s * p.nblocks + sq_b) * 2;
+					atomicAdd(d, (uint32_t)a0); atomicAdd(d + 1, (uint32_t)a1);
 				}
-				do xs += N0; while (xs < lim);  // wave-uniform
+				if (sq_eb < Et) {
+					const int c0 = wave_inclusive_scan((int)sq_p1), c1 = wave_inclusive_scan((int)sq_t1);
+					if (lane == 63 && sq_b + 1 < p.nblocks) {
+						uint32_t *d = p.sq_sums + ((size_t)s * p.nblocks + sq_b + 1) * 2;
+						atomicAdd(d, (uint32_t)c0); atomicAdd(d + 1, (uint32_t)c1);
+					}
+				}
+			}
+		}
+		if (Et > 0) {
+			const int lim = Et * D - ph;
+			if (xs < lim) {
+				if (V != 1 && !EMIT && (V != 0 || p.mode == RTLFM_MODE_FM)) {
+					// fm_demod's first sample of a buffer is always polar_discriminant, whatever -A says
+					// (src/rtl_fm.c:935-937): redone here, behind the loop, instead of as a second discriminator under a
+					// per-lane condition inside it (where it cost every output of a -A fast run the std path's
+					// instructions as well).  Buffer b starts at run sample b N0 and its first output is output
+					// (p0 + b N0) / D of the run: lane c looks at the c-th buffer start that falls into this tile's range.
+					// (p0 + b N0) / D - kb = (ph + x) / D with x = b N0 - 4096 gt, the buffer start relative to this tile: small
+					// numbers, one multiply-high per buffer start (round 5; three 64-bit divisions per tile until then).
+					__builtin_amdgcn_wave_barrier();
+					for (int x = xs + lane * N0; x < lim; x += 64 * N0) {
+						const int e = D == 1 ? ph + x : (int)__umulhi((uint32_t)(ph + x), p.D_magic);
+						const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
+						const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
+						const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
+						const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
+						const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
+						pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v0;
+					}
+				}
+				do { xs += N0; sq_b++; } while (xs < lim);  // wave-uniform
 			}
 		}
 		xs -= kTileSamples;
@@ -579,6 +623,21 @@ inline bool supported(const rtlfm_cfg &c)
 	return supported_front(c);
 }
 
+// the power squelch / -L with the sums taken by the front end itself (SQ kernels) and k_squelch_apply behind it: one launch
+// over the input + a small one over the PCM, no emit mode.  Buffers of at least 8192 samples (a tile's outputs then
+// belong to two buffers at most); -M raw keeps the emit mode (the samples themselves are the output).
+inline bool supported_sq(const rtlfm_cfg &c)
+{
+	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
+		return false;
+	if (!c.squelch_level && !c.report_levels) return false;
+	if (c.block_len < 16384) return false;
+	// rms() looks at every step-th element once a buffer holds more than 32768 of them (src/rtl_fm.c:1090-1092): the sums
+	// taken here are over all of them
+	if (c.downsample < 1 || 2 * ((int)(c.block_len / 2) / c.downsample + 1) > 32768) return false;
+	return supported_front(c);
+}
+
 // emit mode: the launch stores the decimated IQ, and the squelch (src/rtl_fm.c:1204-1215), the -L levels
 // (:1217-1237) and mode_demod incl. -M raw (:1006-1009, 1256-1259) follow on 1 / D of the data
 inline bool supported_emit(const rtlfm_cfg &c)
@@ -589,11 +648,14 @@ inline bool supported_emit(const rtlfm_cfg &c)
 
 inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, int32_t *d_cnt, const state_t *sin, state_t *sout,
-                  hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0, const int2 *rdc_avg = nullptr)
+                  hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0, const int2 *rdc_avg = nullptr,
+                  uint32_t *sq_sums = nullptr)
 {
 	Params p{};
 	p.emit_iq = emit_iq; p.emit_iq_stride = emit_iq_stride;
 	p.rdc_avg = rdc_avg;
+	p.sq_sums = sq_sums;
+	if (sq_sums && emit_iq) return -EINVAL;
 	if (int r = fused::ensure_dummy_tile(ws)) return r;
 	p.dummy_tile = ws.dummy_tile;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;
@@ -615,15 +677,19 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.R = (p.q4096 + 1 + 63) / 64;
 	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0, emit_iq != nullptr) * 4;
 	const bool fast_fm = c.custom_atan == RTLFM_ATAN_FAST && c.mode == RTLFM_MODE_FM;
-	if (rdc_avg) {
-		if (emit_iq) hipLaunchKernelGGL((k_boxcar_scan<3, true>), dim3(waves), dim3(64), lds_bytes, q, p);
-		else if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1, true>), dim3(waves), dim3(64), lds_bytes, q, p);
-		else if (fast_fm) hipLaunchKernelGGL((k_boxcar_scan<2, true>), dim3(waves), dim3(64), lds_bytes, q, p);
-		else hipLaunchKernelGGL((k_boxcar_scan<0, true>), dim3(waves), dim3(64), lds_bytes, q, p);
-	} else if (emit_iq) hipLaunchKernelGGL((k_boxcar_scan<3>), dim3(waves), dim3(64), lds_bytes, q, p);
-	else if (std_fm) hipLaunchKernelGGL((k_boxcar_scan<1>), dim3(waves), dim3(64), lds_bytes, q, p);
-	else if (fast_fm) hipLaunchKernelGGL((k_boxcar_scan<2>), dim3(waves), dim3(64), lds_bytes, q, p);
-	else hipLaunchKernelGGL((k_boxcar_scan<0>), dim3(waves), dim3(64), lds_bytes, q, p);
+#define RTLFM_BOX_GO(VV, RR, SS) hipLaunchKernelGGL((k_boxcar_scan<VV, RR, SS>), dim3(waves), dim3(64), lds_bytes, q, p)
+	const int vsel = emit_iq ? 3 : std_fm ? 1 : fast_fm ? 2 : 0;
+	if (sq_sums) {
+		if (rdc_avg) { if (vsel == 1) RTLFM_BOX_GO(1, true, true); else if (vsel == 2) RTLFM_BOX_GO(2, true, true); else RTLFM_BOX_GO(0, true, true); }
+		else { if (vsel == 1) RTLFM_BOX_GO(1, false, true); else if (vsel == 2) RTLFM_BOX_GO(2, false, true); else RTLFM_BOX_GO(0, false, true); }
+	} else if (rdc_avg) {
+		if (vsel == 3) RTLFM_BOX_GO(3, true, false); else if (vsel == 1) RTLFM_BOX_GO(1, true, false);
+		else if (vsel == 2) RTLFM_BOX_GO(2, true, false); else RTLFM_BOX_GO(0, true, false);
+	} else {
+		if (vsel == 3) RTLFM_BOX_GO(3, false, false); else if (vsel == 1) RTLFM_BOX_GO(1, false, false);
+		else if (vsel == 2) RTLFM_BOX_GO(2, false, false); else RTLFM_BOX_GO(0, false, false);
+	}
+#undef RTLFM_BOX_GO
 	if (p.D > 256) hipLaunchKernelGGL(k_boxcar_partial32, dim3((nstreams + 63) / 64), dim3(64), 0, q, p);
 	return hipGetLastError() == hipSuccess ? 0 : -EIO;
 }

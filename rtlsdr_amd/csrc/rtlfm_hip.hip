@@ -90,6 +90,7 @@ struct rtlfm_gpu {
 	int last_nblocks = 0;
 	long long *d_sums = nullptr;      // [nstreams*cap_blocks*2]  dc_block_raw (front end's stream)
 	long long *d_adc_sums = nullptr;  // [nstreams*cap_blocks]    dc_block_audio (the tail's stream)
+	uint32_t *d_sq_sums = nullptr;    // [nstreams*cap_blocks*2]  rms()'s sums taken by the boxcar front end (SQ kernels)
 	int2 *d_rdc_avg = nullptr;        // [nstreams*cap_blocks]
 	int32_t *d_adc_avg = nullptr;
 	struct Ingest *ing = nullptr;     // the callback side (push / run / fetch), allocated on first use
@@ -107,7 +108,9 @@ struct rtlfm_gpu {
 	// A/B switches (rtlfm_gpu_set_option); none of them changes a result
 	struct Options {
 		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
-		int lpr_chunk = 2720;  // samples per lane of the one-pass deemph + low_pass_real kernel
+		int lpr_chunk = 5440;  // samples per lane of the one-pass deemph + low_pass_real kernel (round 5: 2720 -> 5440 with the outputs leaving through LDS)
+		int squelch_fused = 1; // 0: the squelch / -L behind the boxcar through the emit mode and k_squelch_rms / _hits / _zero / k_fm_demod (round 4) also where the front end can take rms()'s sums itself
+		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
 	} opt;
@@ -346,6 +349,7 @@ static int create_body(rtlfm_gpu *h)
 	HIP_TRY(hipMalloc(&h->d_sums, S * h->cap_blocks * 2 * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_adc_sums, S * h->cap_blocks * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_rdc_avg, S * h->cap_blocks * sizeof(int2)));
+	HIP_TRY(hipMalloc(&h->d_sq_sums, S * h->cap_blocks * 2 * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc(&h->d_adc_avg, S * h->cap_blocks * sizeof(int32_t)));
 	if (cfg->custom_atan == RTLFM_ATAN_LUT) {
 		// atan_lut_init(), src/rtl_fm.c:881-892 — built with the host libm, as
@@ -456,7 +460,7 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_arb_tab, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res_one_block ? nullptr : (void *)h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
-	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
+	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sq_sums, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	h->fws.release();
@@ -564,7 +568,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -938,12 +942,15 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				}
 				next_dst(&lpr_dst, &lpr_ds);
 				if (lpr_dst != final_dst) return -EFAULT;  // routing bug
-				// outputs leave in 16-byte groups where the rows allow it (staged_kernels.h, LprSink)
-				const int lpr_vec = (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
+				// outputs leave in 64-byte pieces through LDS (2; any row alignment), else in 16-byte groups where the rows allow
+				// it (1), else one by one (staged_kernels.h, LprSink)
+				int lpr_vec = (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
+				if (h->opt.lpr_ring && !h->opt.lpr_scalar_stores) lpr_vec = 2;
+				const size_t lpr_lds = lpr_vec == 2 ? (size_t)kSpecLprThreads * kLprRingStride * sizeof(int16_t) : 0;
 				// a workgroup owns whole streams: 256 / chunks of them, or one with a loop over its chunks
 				const int spw = mcsp >= kSpecLprThreads ? 1 : kSpecLprThreads / mcsp;
 				const unsigned gsp = (unsigned)((S + spw - 1) / spw);
-#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, kSpecLprThreads, 0, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
+#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, kSpecLprThreads, lpr_lds, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
 				c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, cnt_dst)
 				if (M == 2) RTLFM_SPEC_LPR(2); else if (M == 1) RTLFM_SPEC_LPR(1); else RTLFM_SPEC_LPR(0);
 #undef RTLFM_SPEC_LPR
@@ -1389,9 +1396,12 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
-	h->fws.tail_follows = tp.any();
+	const bool sq = c.squelch_level || c.report_levels;  // the front end takes rms()'s sums, k_squelch_apply decides (boxcar_kernel.h, SQ)
+	h->fws.tail_follows = tp.any() || sq;
 	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
-	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt[h->step & 1], sin, sout, q, nullptr, 0, rdc);
+	if (sq) HIP_TRY(hipMemsetAsync(h->d_sq_sums, 0, (size_t)S * nblocks * 2 * sizeof(uint32_t), q));
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, h->d_cnt[h->step & 1], sin, sout, q, nullptr, 0, rdc,
+	                     sq ? h->d_sq_sums : nullptr);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -1399,6 +1409,10 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	const int Tin = nblocks * N0;
 	const bool varcnt = (N0 % D) != 0;
 	const int T = varcnt ? Tin / D + 1 : Tin / D;
+	if (sq)
+		k_squelch_apply<<<(unsigned)S, 256, (size_t)nblocks * sizeof(int32_t), q>>>(
+		    h->d_sq_sums, dd, dds, N0, D, nblocks, S, c.squelch_level, c.dc_block_raw, c.mode == RTLFM_MODE_FM ? 1 : 0,
+		    varcnt ? h->d_cnt[h->step & 1] : nullptr, T, sin, sout, h->d_levels);
 	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, N0, D, d_out, out_stride, d_out_len);
 }
 
@@ -1480,7 +1494,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	if (mfma_only && fused::effective_engine(h->fws) != 1) can_fuse = false;
 	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
-	const bool can_box = boxfused::supported(h->cfg);
+	const bool can_box = boxfused::supported(h->cfg) || (h->opt.squelch_fused && boxfused::supported_sq(h->cfg));
 	const bool can_box_emit = boxfused::supported_emit(h->cfg);
 	const bool can_deep = fused::supported_emit(h->cfg) && !(mfma_only && fused::effective_engine(h->fws) != 1);
 	int r;
@@ -1819,6 +1833,7 @@ static rtlfm_gpu make_view(rtlfm_gpu *h, int s0, int ns, uint32_t block_len)
 	v.d_mute = h->d_mute + s0 * cb;
 	v.d_levels = h->d_levels + s0 * cb;
 	v.d_sums = h->d_sums + s0 * cb * 2;
+	v.d_sq_sums = h->d_sq_sums + s0 * cb * 2;
 	v.d_adc_sums = h->d_adc_sums + s0 * cb;
 	v.d_rdc_avg = h->d_rdc_avg + s0 * cb;
 	v.d_adc_avg = h->d_adc_avg + s0 * cb;

@@ -421,6 +421,65 @@ k_squelch_zero(uint32_t *__restrict__ X, size_t xstride, int N, int D, int nbloc
 	for (int t = t0 + (int)threadIdx.x; t < t1 && t < T; t += 256) x[t] = 0;
 }
 
+// The squelch behind a front end that has taken rms()'s sums itself (boxcar_kernel.h, SQ): a workgroup per stream.
+// sums[s][b] = (sum of squares, sum) of buffer b's decimated elements modulo 2^32; the level and the decision are
+// rms()'s and full_demod()'s (src/rtl_fm.c:1083-1112, 1204-1215), squelch_hits counts over the stream's buffers in
+// order, and a muted buffer's PCM is written as what the demodulators make of zeroed samples: zeros - and a zero for
+// the first output behind it too where fm_demod pairs it with the zeroed last sample (atan2(0, 0) = 0), which for the
+// run's last buffer is the carried pre_r / pre_j.
+__global__ void __launch_bounds__(256)
+k_squelch_apply(const uint32_t *__restrict__ sums, int16_t *__restrict__ R, size_t rstride, int N, int D, int nblocks, int nstreams,
+                int level, int omit_dc_fix, int fm, const int32_t *__restrict__ cnt, int T, const state_t *__restrict__ sin,
+                state_t *__restrict__ sout, int32_t *__restrict__ rms_out)
+{
+	extern __shared__ int32_t sq_mute[];  // [nblocks]
+	const size_t s = blockIdx.x;
+	const int p0 = D > 1 ? sin[s].prev_index : 0;
+	const int Ts = cnt ? cnt[s] : T;
+	for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+		const int t0 = dec_block_begin(b, N, D, p0), t1 = dec_block_begin(b + 1, N, D, p0);
+		const int len = 2 * (t1 - t0);
+		const uint32_t p = sums[(s * nblocks + b) * 2];
+		const int32_t t = (int32_t)sums[(s * nblocks + b) * 2 + 1];
+		int m = 2;  // 2: no decision (an empty buffer, or a level that is not a number)
+		int sr = INT32_MIN;
+		if (len > 0) {
+			double r;
+			if (omit_dc_fix) r = sqrt((double)p / len);
+			else {
+				const double dc = (double)t / (double)len;
+				const double err = t * 2 * dc - dc * dc * len;
+				r = sqrt((p - err) / len);
+			}
+			sr = r == r ? (int)r : INT32_MIN;  // (int)NaN is INT_MIN on the reference's machine: the squelch skips it (sr >= 0)
+			m = (sr >= 0 && sr < level) ? 1 : (sr >= 0 ? 0 : 2);
+		}
+		sq_mute[b] = level ? m : 0;
+		if (rms_out) rms_out[s * nblocks + b] = sr;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && level) {
+		int hits = sin[s].squelch_hits;
+		for (int b = 0; b < nblocks; b++) {
+			if (sq_mute[b] == 1) hits++;
+			else if (sq_mute[b] == 0) hits = 0;
+		}
+		sout[s].squelch_hits = hits;
+		if (fm && sq_mute[nblocks - 1] == 1 && dec_block_begin(nblocks, N, D, p0) > dec_block_begin(nblocks - 1, N, D, p0)) {
+			sout[s].pre_r = 0; sout[s].pre_j = 0;  // fm_demod kept the zeroed last sample (:955-956)
+		}
+	}
+	if (!level) return;
+	int16_t *r = R + s * rstride;
+	for (int b = 0; b < nblocks; b++) {
+		if (sq_mute[b] != 1) continue;
+		const int t0 = dec_block_begin(b, N, D, p0);
+		int t1 = dec_block_begin(b + 1, N, D, p0) + (fm ? 1 : 0);  // + the first output of the next buffer
+		if (t1 > Ts) t1 = Ts;
+		for (int t = t0 + (int)threadIdx.x; t < t1; t += blockDim.x) r[t] = 0;
+	}
+}
+
 // ------------------------------------------------------------------ demods ----
 // fm_demod (src/rtl_fm.c:932-959): output t pairs sample t with t-1 (or with
 // the carried pre_r/pre_j); the FIRST output of every block always uses
@@ -1040,6 +1099,12 @@ struct LprChunk {
 // last one go out one by one.  The first emission of a chunk other than the stream's first belongs
 // to an output that began in the chunk before: its value is put together by k_lpr_fixup from
 // head, what is stored for it here is overwritten there.
+// Round 5, `ring`: a lane's outputs wait in 64 entries of LDS that mirror the row's addresses, and whenever the lane
+// completes a 64-byte piece of its row (32 outputs, aligned in memory whatever the row's own alignment is) the piece
+// leaves as four 16-byte stores in a row - one burst per 64 bytes instead of four 16-byte pieces that a line collected
+// over ~20000 cycles (profiles/r04_pmc_wbfm_k_deemph_spec_lpr.txt: 407 MB written for 135 MB of audio).  The outputs in
+// front of the chunk's first piece boundary and behind its last go out one by one, as before.
+constexpr int kLprRing = 64, kLprRingStride = 72;  // int16 entries per lane / between lanes (144 bytes: 16-byte aligned rows)
 struct LprSink {
 	int16_t *bo;
 	int m, phi, sl, fa, first_full;
@@ -1047,11 +1112,17 @@ struct LprSink {
 	uint32_t p0, p1, p2, p3;  // the last eight outputs, oldest in the low half of p0
 	ConstDiv cdiv;
 	LprChunk out;
-	__device__ __forceinline__ LprSink(int16_t *bo_, int m_, int phi_, int slow, int fast, uint32_t acc_, bool vec)
+	int16_t *ring;            // this lane's kLprRing entries in LDS, or nullptr: the register form
+	int shift;                // (row address / 2) mod 32: output m sits at 64-byte offset 2 ((m + shift) mod 32)
+	__device__ __forceinline__ LprSink(int16_t *bo_, int m_, int phi_, int slow, int fast, uint32_t acc_, bool vec, int16_t *ring_ = nullptr)
 	    : bo(bo_), m(m_), phi(phi_), sl(slow), fa(fast), first_full(vec ? ((m_ + 7) & ~7) : INT32_MAX), acc(acc_), p0(0), p1(0),
-	      p2(0), p3(0), cdiv(fast / slow)
+	      p2(0), p3(0), cdiv(fast / slow), ring(ring_), shift(0)
 	{
 		out.mfirst = -1; out.head = 0; out.tail = 0;
+		if (ring) {
+			shift = (int)(((uintptr_t)bo_ >> 1) & 31);
+			first_full = m_ + ((32 - ((m_ + shift) & 31)) & 31);  // the chunk's first piece boundary
+		}
 	}
 	__device__ __forceinline__ void operator()(int y)
 	{
@@ -1060,13 +1131,25 @@ struct LprSink {
 		if (phi >= fa) {
 			if (out.mfirst < 0) { out.mfirst = m; out.head = acc; }
 			const uint32_t q = (uint32_t)cdiv((int)acc);
-			p0 = __builtin_amdgcn_alignbit(p1, p0, 16);
-			p1 = __builtin_amdgcn_alignbit(p2, p1, 16);
-			p2 = __builtin_amdgcn_alignbit(p3, p2, 16);
-			p3 = (p3 >> 16) | (q << 16);
-			if (m < first_full) bo[m] = (int16_t)q;
-			m++;
-			if ((m & 7) == 0 && m > first_full) *reinterpret_cast<uint4 *>(bo + m - 8) = make_uint4(p0, p1, p2, p3);
+			if (ring) {
+				ring[(m + shift) & (kLprRing - 1)] = (int16_t)q;
+				if (m < first_full) bo[m] = (int16_t)q;
+				m++;
+				if (((m + shift) & 31) == 0 && m > first_full) {
+					const uint4 *src = reinterpret_cast<const uint4 *>(ring + ((m - 32 + shift) & (kLprRing - 1)));
+					uint4 *dst = reinterpret_cast<uint4 *>(bo + (m - 32));
+					const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+					dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+				}
+			} else {
+				p0 = __builtin_amdgcn_alignbit(p1, p0, 16);
+				p1 = __builtin_amdgcn_alignbit(p2, p1, 16);
+				p2 = __builtin_amdgcn_alignbit(p3, p2, 16);
+				p3 = (p3 >> 16) | (q << 16);
+				if (m < first_full) bo[m] = (int16_t)q;
+				m++;
+				if ((m & 7) == 0 && m > first_full) *reinterpret_cast<uint4 *>(bo + m - 8) = make_uint4(p0, p1, p2, p3);
+			}
 			phi -= fa;
 			acc = 0;
 		}
@@ -1074,6 +1157,12 @@ struct LprSink {
 	__device__ __forceinline__ void finish()  // the outputs after the last full group
 	{
 		out.tail = acc;
+		if (ring) {
+			const int mb = m - ((m + shift) & 31);  // the last piece boundary
+			if (mb < first_full) return;            // the chunk never got past its first boundary: everything went out one by one
+			for (int j = mb; j < m; j++) bo[j] = ring[(j + shift) & (kLprRing - 1)];
+			return;
+		}
 		const int nrem = m & 7;
 		if (m - nrem < first_full) return;  // written one by one already (or `vec` is off)
 		const uint32_t p[4] = {p0, p1, p2, p3};
@@ -1202,7 +1291,9 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 	__builtin_amdgcn_s_setprio(RTLFM_TAIL_PRIO);
 #endif
 	__shared__ int unsettled[kSpecLprThreads];  // per stream of this workgroup
+	extern __shared__ __attribute__((aligned(16))) int16_t lpr_rings[];  // kLprRingStride entries per lane, or nothing (vec != 2)
 	const int nthreads = (int)blockDim.x, tid = (int)threadIdx.x;
+	int16_t *const my_ring = vec == 2 ? lpr_rings + (size_t)tid * kLprRingStride : nullptr;
 	const int spw = max_chunks >= nthreads ? 1 : nthreads / max_chunks;  // streams per workgroup
 	unsettled[tid] = 0;
 	__syncthreads();
@@ -1229,7 +1320,7 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 			deemph_chunk_range(c, n, head, L, begin, end);
 			const long long idx0 = p0 + (long long)begin * slow;
 			const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(idx0, fast) : (int)(idx0 / fast);
-			LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
+			LprSink sink(B + s * bstride, m0, (int)(idx0 - (long long)m0 * fast), slow, fast, c == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0, my_ring);
 			bool settled = true;
 			uint32_t v = (uint32_t)(carried + 32768);
 			if (begin > 0) {
@@ -1260,7 +1351,7 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 		int E, phase;
 		lpr_totals(p0, n, slow, fast, E, phase);
 		const int m0 = (p0 >= 0 && p0 < fast) ? (int)floor_div_pos(p0, fast) : (int)(p0 / fast);
-		LprSink sink(B + s * bstride, m0, (int)(p0 - (long long)m0 * fast), slow, fast, (uint32_t)sin[s].now_lpr, vec != 0);
+		LprSink sink(B + s * bstride, m0, (int)(p0 - (long long)m0 * fast), slow, fast, (uint32_t)sin[s].now_lpr, vec != 0, my_ring);
 		if (plain) {
 			sout[s].deemph_avg = deemph_plain(r, n, carried, (int)ds.a);
 			deemph_walk_sink<MAGIC>(r, n, 0u, ds, false, sink);

@@ -1661,13 +1661,17 @@ def test_boxcar_front_end_emit_mode(oracle_lib, ov, sig, L, nb, ns):
     for s in range(ns):  # shift the keying per stream, so that streams mute different buffers
         iq[s] = np.roll(iq[s], 2 * 3111 * s)
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
-    for path, splits in ((0, None), (0, [(0, 1), (1, nb)]), (1, None)):
-        outs, sts, used = gpu_run(cfg, iq, path=path, splits=splits)
+    # squelch_fused = 0: round 4's route (emit mode + k_squelch_rms / _hits / _zero + k_fm_demod) also where the front end
+    # takes rms()'s sums itself and k_squelch_apply writes the zeros (round 5; buffers of 16384 bytes and more)
+    for path, splits, opts in ((0, None, None), (0, [(0, 1), (1, nb)], None), (0, None, dict(squelch_fused=0)),
+                               (0, [(0, 1), (1, nb)], dict(squelch_fused=0, fused_tiles_per_seg=3)), (0, None, dict(fused_tiles_per_seg=1)),
+                               (1, None, None)):
+        outs, sts, used = gpu_run(cfg, iq, path=path, splits=splits, options=opts)
         assert used == (1 if path == 1 else 2), (ov, path, used)
         for s in range(ns):
-            assert len(outs[s]) == want_len[s], (ov, L, path, splits, s)
-            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{ov} L={L} path={path} splits={splits} [{s}]")
-            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, s)
+            assert len(outs[s]) == want_len[s], (ov, L, path, splits, opts, s)
+            assert_parity(outs[s], want[s, :want_len[s]], cfg, f"{ov} L={L} path={path} splits={splits} {opts} [{s}]")
+            assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), (ov, path, splits, opts, s)
 
 
 @pytest.mark.parametrize("ov", [dict(downsample=16, downsample_passes=4, report_levels=1),
