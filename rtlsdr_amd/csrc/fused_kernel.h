@@ -246,6 +246,10 @@ struct Params {
 	int seg_start[kMaxSegList + 1];
 	const uint32_t *mfma_taps;  // [64 lanes][4] A operand of the pass-0 MFMA (make_mfma_taps)
 	const int2 *rdc_avg;        // RDC kernels: [stream][nblocks] (avgI, avgQ) of dc_block_raw_filter, from k_rdc_sums / k_rdc_smooth
+	// the power squelch / -L without an emit mode (round 5): [stream][nblocks] (sum of squares, sum) of every buffer's
+	// decimated, FIR-compensated elements modulo 2^32, what rms() sums (src/rtl_fm.c:1093-1098); zeroed by the host, added
+	// to with two atomics per tile; k_squelch_apply (staged_kernels.h) makes the decisions.  nullptr: nothing is added
+	uint32_t *sq_sums;
 	int debug;  // timing experiments only (RTLFM_FUSED_DEBUG): 2 = clock stamps (printed per launch; +16 = 18:
 	            // only on timing_read, i.e. for the last launch of an uninterrupted run), 4 = reload one (cached) tile
 	unsigned long long *stamps;  // [waves][4] when debug & 2
@@ -523,6 +527,18 @@ struct AtanNodesLds {
 // common case and the one the roofline is quoted on); otherwise p.variant picks
 // fast / lut at run time.
 // MFMA0: pass 0 on the int8 matrix pipe instead of v_dot4 (see make_mfma_taps).
+// sum over the wave, valid in lane 63 (inclusive DPP scan)
+__device__ __forceinline__ int wave_sum_to_last(int x)
+{
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+	return x;
+}
+
 // RDC: dc_block_raw_filter (-E rdc, src/rtl_fm.c:1043-1065, 1330-1332) in front of the chain.  The
 // filter subtracts one (avgI, avgQ) per buffer - the block mean smoothed over the blocks, which a
 // pre-pass has to know before the first sample (k_rdc_sums / k_rdc_smooth: one more read of the
@@ -1138,6 +1154,23 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			}
 		}
 		RTLFM_MARK("fir_done");
+		if (p.sq_sums && emit) {  // wave-uniform
+			// rms()'s two sums over this tile's decimated elements (a tile lies inside one buffer)
+			const short2_t ones = {(short)1, (short)1};
+			int sq_p = 0, sq_t = 0;
+			if (!PT || lane < nlanes) {
+#pragma unroll
+				for (int k = 0; k < CZ; k++) {
+					sq_p = __builtin_amdgcn_sdot2(as_s2(V[k]), as_s2(V[k]), sq_p, false);
+					sq_t = __builtin_amdgcn_sdot2(as_s2(V[k]), ones, sq_t, false);
+				}
+			}
+			sq_p = wave_sum_to_last(sq_p); sq_t = wave_sum_to_last(sq_t);
+			if (lane == 63) {
+				uint32_t *d = p.sq_sums + ((size_t)s * p.nblocks + (size_t)(gt / tpb)) * 2;
+				atomicAdd(d, (uint32_t)sq_p); atomicAdd(d + 1, (uint32_t)sq_t);
+			}
+		}
 		// ------------------------------------------------------------ fm_demod ----
 		uint32_t pv;
 		{
@@ -1339,6 +1372,18 @@ inline bool supported_emit(const rtlfm_cfg &c)
 	return c.downsample_passes > kMaxP || c.mode == RTLFM_MODE_RAW || c.squelch_level != 0 || c.report_levels != 0;
 }
 
+// the power squelch / -L with rms()'s sums taken by the front end itself and k_squelch_apply behind it (as
+// boxfused::supported_sq): up to six passes, at most 32768 decimated elements per buffer (beyond that rms() looks at
+// every step-th element only, src/rtl_fm.c:1090-1092)
+inline bool supported_sq(const rtlfm_cfg &c)
+{
+	if (c.mode != RTLFM_MODE_FM && c.mode != RTLFM_MODE_AM && c.mode != RTLFM_MODE_USB && c.mode != RTLFM_MODE_LSB)
+		return false;
+	if (!c.squelch_level && !c.report_levels) return false;
+	if (c.downsample_passes < 1 || c.downsample_passes > kMaxP) return false;
+	return (c.block_len >> c.downsample_passes) <= 32768;
+}
+
 inline int ensure_dummy_tile(Workspace &ws)
 {
 	if (ws.dummy_tile) return 0;
@@ -1396,12 +1441,14 @@ static int launch_one(const Params &p, int waves, hipStream_t q)
 inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t *d_iq, size_t stream_stride,
                   int nblocks, int16_t *d_out, size_t out_stride, const state_t *sin, state_t *sout,
                   const int32_t *lut, hipStream_t q, uint32_t *emit_iq = nullptr, size_t emit_iq_stride = 0,
-                  const int2 *rdc_avg = nullptr)
+                  const int2 *rdc_avg = nullptr, uint32_t *sq_sums = nullptr)
 {
 	if (!emit_iq && (((uintptr_t)d_out & 15) || (out_stride & 7))) return -EINVAL;
+	if (emit_iq && sq_sums) return -EINVAL;
 	Params p{};
 	p.emit_iq = emit_iq; p.emit_iq_stride = emit_iq_stride;
 	p.rdc_avg = rdc_avg;
+	p.sq_sums = sq_sums;
 	if (int r = ensure_dummy_tile(ws)) return r;
 	p.dummy_tile = ws.dummy_tile;
 	p.iq = d_iq; p.stream_stride = stream_stride; p.block_len = c.block_len;

@@ -1286,11 +1286,20 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
 	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
-	h->fws.tail_follows = tp.any();
-	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q, nullptr, 0, rdc);
+	const bool sq = c.squelch_level || c.report_levels;  // the front end takes rms()'s sums, k_squelch_apply decides (fused_kernel.h)
+	h->fws.tail_follows = tp.any() || sq;
+	if (sq) HIP_TRY(hipMemsetAsync(h->d_sq_sums, 0, (size_t)S * nblocks * 2 * sizeof(uint32_t), q));
+	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q, nullptr, 0, rdc,
+	                  sq ? h->d_sq_sums : nullptr);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
+	if (sq) {
+		const int Nb = (int)((c.block_len / 2) >> c.downsample_passes);
+		k_squelch_apply<<<(unsigned)S, 256, (size_t)nblocks * sizeof(int32_t), q>>>(
+		    h->d_sq_sums, dd, dds, Nb, 1, nblocks, S, c.squelch_level, c.dc_block_raw, c.mode == RTLFM_MODE_FM ? 1 : 0, nullptr,
+		    nblocks * Nb, sin, sout, h->d_levels);
+	}
 	// bit 2 with bit 8: report the stamps of every launch (synchronises, so the GPU idles between
 	// launches and clocks up); bit 2 alone with bit 16: only when timing_read() asks, i.e. the last
 	// launch of an uninterrupted sequence
@@ -1488,7 +1497,9 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	HIP_TRY(hipSetDevice(h->device));
 	rtl_debug::poison_lds(h->stream);  // RTLFM_POISON=1 only
 	const size_t S = (size_t)h->nstreams;
-	bool can_fuse = fused::supported(h->cfg, nblocks);
+	// the squelch / -L with rms()'s sums taken by the front end itself (round 5) comes before the emit mode
+	const bool fuse_sq = h->opt.squelch_fused && fused::supported_sq(h->cfg);
+	bool can_fuse = fused::supported(h->cfg, nblocks) || fuse_sq;
 	// the raw DC block rides on the MFMA pass 0, and only that engine has the partial-tile kernels (-W n)
 	const bool mfma_only = h->cfg.dc_block_raw || fused::needs_partial_tiles(h->cfg);
 	if (mfma_only && fused::effective_engine(h->fws) != 1) can_fuse = false;
@@ -1519,7 +1530,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	} else if (h->path != 1 && can_box_emit) {
 		r = run_boxfused_emit(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
-	} else if (h->path != 1 && can_deep) {
+	} else if (h->path != 1 && can_deep && !(can_fuse && fuse_sq)) {
 		r = run_fused_emit(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
 		h->last_path = 2;
 	} else if (h->path != 1 && can_fuse) {

@@ -119,13 +119,25 @@ k_rdc_sums_wide(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L
 	const uint8_t *src = iq + s * stream_stride + (size_t)b * L;
 	unsigned si = 0, sq = 0;  // <= 262144 * 255 / 2: fits
 	const uint32_t n16 = L / 16;
-	for (uint32_t k = threadIdx.x; k < n16; k += 256) {
-		const uint4 v = reinterpret_cast<const uint4 *>(src)[k];
+	auto add16 = [&](const uint4 &v) {
 		si = __builtin_amdgcn_udot4(v.x, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.x, 0x01000100u, sq, false);
 		si = __builtin_amdgcn_udot4(v.y, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.y, 0x01000100u, sq, false);
 		si = __builtin_amdgcn_udot4(v.z, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.z, 0x01000100u, sq, false);
 		si = __builtin_amdgcn_udot4(v.w, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.w, 0x01000100u, sq, false);
+	};
+	// eight 16-byte loads of the lane in flight (2 KiB of whole lines per wave and instruction), non-temporal: the front
+	// end reads the same bytes again right behind this pass and nothing here is read twice
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	const v4u *src4 = reinterpret_cast<const v4u *>(src);
+	uint32_t k = threadIdx.x;
+	for (; k + 7 * 256 < n16; k += 8 * 256) {
+		v4u v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load(src4 + k + 256 * j);
+#pragma unroll
+		for (int j = 0; j < 8; j++) add16(make_uint4(v[j].x, v[j].y, v[j].z, v[j].w));
 	}
+	for (; k < n16; k += 256) add16(reinterpret_cast<const uint4 *>(src)[k]);
 	for (uint32_t k = n16 * 16 + threadIdx.x * 2; k < L; k += 512) { si += src[k]; sq += src[k + 1]; }
 	for (int off = 32; off > 0; off >>= 1) {
 		si += __shfl_down(si, off, 64);

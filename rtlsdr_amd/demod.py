@@ -62,6 +62,16 @@ class GpuDemod:
 
     run = full_demod
 
+    def run_begin(self) -> int:
+        """rtlfm_gpu_run_begin: take what the ring's filling half holds and flip the halves; returns buffers per stream taken."""
+        n = C.c_int()
+        check(self.lib.rtlfm_gpu_run_begin(self._h, C.byref(n)), "rtlfm_gpu_run_begin")
+        return n.value
+
+    def run_end(self):
+        """rtlfm_gpu_run_end: the transfer and the kernels of the run that _begin took."""
+        check(self.lib.rtlfm_gpu_run_end(self._h), "rtlfm_gpu_run_end")
+
     def fetch(self, stream: int = 0) -> np.ndarray:
         cap = capi.load().rtlfm_result_cap(C.byref(self.cfg)) * max(1, self.cfg.max_blocks) + 16
         out = np.empty(cap, dtype=np.int16)

@@ -150,11 +150,14 @@ def test_invalid_configurations_are_rejected():
     lib = capi.load()
     h = C.c_void_p()
     bad = [dict(block_len=1000), dict(downsample_passes=11), dict(downsample=0),
-           dict(comp_fir_size=5), dict(rate_out=16000, rate_out2=22050),  # ref divides by zero
-           dict(downsample_passes=10, downsample=1024, block_len=512)]
+           dict(comp_fir_size=5), dict(rate_out=16000, rate_out2=22050)]  # ref divides by zero
     for ov in bad:
         cfg = RtlfmCfg.default(**ov)
         assert lib.rtlfm_gpu_create(C.byref(cfg), 1, 0, C.byref(h)) < 0, ov
+    # ten passes on a 512-byte buffer (no -EINVAL since round 5: the reference runs it, and produces nothing)
+    cfg = RtlfmCfg.default(downsample_passes=10, downsample=1024, block_len=512)
+    assert lib.rtlfm_gpu_create(C.byref(cfg), 1, 0, C.byref(h)) == 0
+    lib.rtlfm_gpu_destroy(h)
 
 
 def test_state_get_set_roundtrip(oracle_lib):
@@ -426,7 +429,9 @@ def test_buffers_of_any_512n_bytes(oracle_lib, front, L):
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
     cut = nb // 2
     for splits, opts in ((None, None), ([(0, 1), (1, cut), (cut, nb)], dict(fused_tiles_per_seg=3)), (None, dict(fused_waves=1)),
-                         (None, dict(fused_tiles_per_seg=1))):
+                         (None, dict(fused_tiles_per_seg=1)), (None, dict(squelch_fused=0))):
+        if opts and "squelch_fused" in opts and "sq" not in front:
+            continue  # (the squelch through the emit mode, round 4's route: only where there is a squelch)
         outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
         assert used == 2, (front, L)
         for s_ in range(ns):
@@ -1331,23 +1336,65 @@ def test_two_runs_in_flight_fetch_the_one_before(oracle_lib, name):
         assert_parity(np.concatenate(got[s]), want[s, :want_len[s]], cfg, f"{name} stream {s}")
 
 
-def test_push_rejects_lengths_the_chain_cannot_take():
-    """A short buffer is demodulated as a buffer of that length; a length the configured chain cannot
-    take (here: 512 bytes through 10 fifth_order passes need a multiple of 2048) is refused by push()
-    itself, before anything is queued - not by the run that would have to undo half of its work."""
+def test_push_takes_short_buffers_the_passes_do_not_divide(oracle_lib):
+    """A short buffer is demodulated as a buffer of that length - also a length the configured fifth_order passes do not
+    divide (512 or 1536 bytes through 10 passes: the reference runs those, src/rtl_fm.c:1188-1191; until round 5 push()
+    answered -EINVAL): against the oracle run buffer by buffer, outputs and carried state.  What push() still refuses before
+    anything is queued: a length that is not whole 512-byte packets, or longer than the buffer."""
     from rtlsdr_amd.demod import GpuDemod
-    cfg = make_cfg(dict(downsample=1024, downsample_passes=10), 16384, 2)
-    with GpuDemod(cfg, 2, 0) as g:
-        buf = np.full(16384, 127, np.uint8)
-        g.rtlsdr_callback(buf, 0)
-        with pytest.raises(capi.RtlfmError) as e:
-            g.rtlsdr_callback(buf[:512], 0)
-        assert e.value.code == -22
-        g.rtlsdr_callback(buf[:4096], 0)   # a multiple of 2 << 10: fine
-        g.rtlsdr_callback(buf, 1); g.rtlsdr_callback(buf[:4096], 1)
+    cfg = make_cfg(dict(downsample=1024, downsample_passes=10, comp_fir_size=9), 16384, 3)
+    ns = 3
+    iq = synth.fm_iq_u8(ns, 8192 * 3, seed=99, fs=1.024e6, dev_hz=300.0)
+    lens = [[16384, 512, 4096], [16384, 1536, 4096], [16384, 512 * 5, 16384]]
+    blocks = [[iq[s, b * 16384:b * 16384 + lens[s][b]] for b in range(3)] for s in range(ns)]
+    want, wst = _oracle_ragged(oracle_lib, cfg, blocks)
+    with GpuDemod(cfg, ns, 0) as g:
+        for bad in (100, 16384 + 512):
+            with pytest.raises(capi.RtlfmError) as e:
+                g.rtlsdr_callback(np.full(bad, 127, np.uint8), 0)
+            assert e.value.code == -22
+        for b in range(3):
+            for s in range(ns):
+                g.rtlsdr_callback(blocks[s][b], s)
         g.full_demod()
         o, n = g.fetch_all()
-        assert list(n) == [10, 10]
+        sts = [g.state_get(s) for s in range(ns)]
+    for s in range(ns):
+        assert n[s] == len(want[s]), (s, n[s], len(want[s]))
+        assert_parity(o[s, :n[s]], want[s], cfg, f"stream {s}")
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), s
+
+
+def test_run_in_two_steps_lets_the_producers_go_on(oracle_lib):
+    """rtlfm_gpu_run_begin flips the ring's halves, rtlfm_gpu_run_end queues the transfer and the kernels: between the two
+    the producers already fill the other half (a caller that gates its producers holds the gate around _begin only).
+    Buffers pushed between _begin and _end belong to the NEXT run; the outputs are those of plain runs."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, ns, nb = 16384, 4, 6
+    cfg = make_cfg(dict(downsample=16, downsample_passes=4, deemph=1, deemph_a=12), L, 2)
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=4242, fs=2.4e6, dev_hz=75e3)
+    want, want_len, wst = oracle_lib.run_batch(make_cfg(dict(downsample=16, downsample_passes=4, deemph=1, deemph_a=12), L, nb), iq, nthreads=2)
+    got = [[] for _ in range(ns)]
+    with GpuDemod(cfg, ns, 0) as g:
+        with pytest.raises(capi.RtlfmError):
+            g.run_end()                       # nothing begun
+        for s in range(ns):
+            g.rtlsdr_callback(iq[s, 0:L], s)
+        for b in range(1, nb + 1):
+            assert g.run_begin() == 1
+            with pytest.raises(capi.RtlfmError):
+                g.run_begin()                 # one begun run at a time
+            if b < nb:
+                for s in range(ns):           # the producers go on while the run is only begun
+                    g.rtlsdr_callback(iq[s, b * L:(b + 1) * L], s)
+            g.run_end()
+            o, n = g.fetch_all()
+            for s in range(ns):
+                got[s].append(o[s, :n[s]].copy())
+        sts = [g.state_get(s) for s in range(ns)]
+    for s in range(ns):
+        assert_parity(np.concatenate(got[s]), want[s, :want_len[s]], cfg, f"stream {s}")
+        assert gu.state_dict(sts[s], False) == gu.state_dict(wst[s], False), s
 
 
 def test_caller_stream_orders_the_audio_tail(oracle_lib):
@@ -1413,8 +1460,8 @@ def test_placement_is_observable_and_bounded():
             g0.rtlsdr_callback(buf, s)
         assert g0.get_option("ring_apart") == 0 and g0.get_option("placement_walked_mb") == 0
         assert g0.get_option("deep_apart") == -1     # this configuration has no emit-mode buffer
-        # the buffer a front end's emit mode writes (here: the squelch behind four passes) is placed as well
-        ge = GpuDemod(make_cfg(dict(downsample=16, downsample_passes=4, squelch_level=50), L, 1), ns, 0)
+        # the buffer a front end's emit mode writes (here: -M raw behind four passes) is placed as well
+        ge = GpuDemod(make_cfg(dict(downsample=16, downsample_passes=4, mode=capi.MODE_RAW), L, 1), ns, 0)
         hs.append(ge)
         assert ge.get_option("deep_apart") == -1
         for s in range(ns):

@@ -2,12 +2,12 @@
 # tools/collect_profiles.sh — on the GPU box: for every measured workload the bench line, right
 # behind it the rocprofv3 kernel-trace stats of the same workload (the box drifts by a few per cent
 # over minutes at its power cap, so the two that have to agree are taken back to back), and PMC
-# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r04) (copy
+# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r05) (copy
 # what should be judged into profiles/ afterwards; the raw traces are deleted, they are large).
 # One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 top() { # csv title
@@ -25,7 +25,7 @@ PY
 }
 # long enough that the clock ramp of the first launches after idle does not weigh on the averages
 COMMON="--steps 400 --warmup 100 --no-cpu-baseline --check 0 --pmc 0 --sustain 0 --e2e 0 --ceiling 0 --also 0"
-for spec in "ns4096:" "c2:--workload c2" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "c4:--workload c4"; do
+for spec in "ns4096:" "c2:--workload c2" "c1:--workload c1" "box10_std:--boxcar 10" "box6_std:--boxcar 6" "c3:--workload c3" "wbfm:--workload wbfm" "scanner:--workload scanner" "c2_16k:--workload c2_16k" "c4:--workload c4"; do
   tag=${spec%%:*}; args=${spec#*:}
   if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $tag "; then continue; fi
   cd $ROOT
