@@ -109,6 +109,7 @@ struct rtlfm_gpu {
 	struct Options {
 		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
 		int lpr_chunk = 5440;  // samples per lane of the one-pass deemph + low_pass_real kernel (round 5: 2720 -> 5440 with the outputs leaving through LDS)
+		int adc_separate = 0;  // 1: dc_block_audio_filter as three kernels (sums, smoothing, subtraction) instead of two
 		int squelch_fused = 1; // 0: the squelch / -L behind the boxcar through the emit mode and k_squelch_rms / _hits / _zero / k_fm_demod (round 4) also where the front end can take rms()'s sums itself
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
@@ -568,7 +569,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -711,11 +712,20 @@ static inline int grid_for(size_t work, int block = 256, int cap = 256 * 16)
 // d_out_len (may be NULL).
 struct TailPlan {
 	bool post, deemph, adc, lpr, arb;
-	int oop() const { return (post ? 1 : 0) + ((lpr || arb) ? 1 : 0); }
+	bool deemph_spec;  // deemph_filter alone on a long run: the one-pass kernel, which works OUT of place (k_deemph_spec)
+	int oop() const { return (post ? 1 : 0) + (deemph_spec ? 1 : 0) + ((lpr || arb) ? 1 : 0); }
 	bool any() const { return post || deemph || adc || lpr || arb; }
 };
-static TailPlan plan_tail(const rtlfm_cfg &c)
+// the time-parallel forms of deemph_filter apply: a long run, a divisor whose contracted interval fits a wave
+static bool deemph_scans(const rtlfm_gpu *h, int T)
 {
+	const rtlfm_cfg &c = h->cfg;
+	return T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan && !h->opt.deemph_sequential;
+}
+// nblocks: the buffers of the run (the plan depends on how long a stream's run is)
+static TailPlan plan_tail(const rtlfm_gpu *h, int nblocks)
+{
+	const rtlfm_cfg &c = h->cfg;
 	TailPlan t{};
 	if (c.mode == RTLFM_MODE_RAW) return t;
 	t.post = c.post_downsample > 1;
@@ -723,6 +733,15 @@ static TailPlan plan_tail(const rtlfm_cfg &c)
 	t.adc = c.dc_block_audio != 0;
 	t.lpr = c.rate_out2 > 0 && c.resampler == RTLFM_RESAMPLE_LOW_PASS_REAL;
 	t.arb = c.rate_out2 > 0 && c.resampler == RTLFM_RESAMPLE_ARBITRARY;
+	if (t.deemph && !t.lpr && !t.arb && !h->opt.deemph_four_pass) {
+		// the demodulated samples of a stream's run, as run_tail() will be told (an upper bound behind a boxcar that does not
+		// divide the buffer)
+		const long long n0 = c.block_len / 2;
+		long long T = c.downsample_passes > 0 ? (long long)nblocks * (n0 >> c.downsample_passes)
+		                                      : ((long long)nblocks * n0) / c.downsample + ((n0 % c.downsample) ? 1 : 0);
+		if (t.post) T /= c.post_downsample;
+		t.deemph_spec = T < (1ll << 30) && deemph_scans(h, (int)T);
+	}
 	return t;
 }
 
@@ -745,8 +764,7 @@ static int one_pass_tail(const rtlfm_gpu *h, const TailPlan &tp, const int16_t *
 {
 	const rtlfm_cfg &c = h->cfg;
 	if (!tp.deemph || tp.post || tp.adc || h->opt.deemph_four_pass) return 0;
-	const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan &&
-	                  !h->opt.deemph_sequential;
+	const bool scan = deemph_scans(h, T);
 	if (!scan) return 0;
 	if (tp.lpr) return h->opt.lpr_separate ? 0 : 2;
 	if (!tp.arb) return 0;
@@ -810,7 +828,10 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	}
 	bool fuse_lpr = false;
 	int16_t *lpr_dst = nullptr; size_t lpr_ds = 0;
-	if (tp.deemph) {
+	if (tp.deemph && c.deemph_a == 1) {
+		// the filter is the identity on the samples and keeps the last one (staged_kernels.h)
+		k_deemph_identity<<<grid_for(S, 64), 64, 0, q>>>(cur, cur_stride, T, cnt, S, sout);
+	} else if (tp.deemph) {
 		DeemphStep st;
 		st.a = (uint32_t)c.deemph_a; st.half = (uint32_t)(c.deemph_a / 2);
 		const bool pow2 = c.deemph_a >= 1 && c.deemph_a <= 32768 && (c.deemph_a & (c.deemph_a - 1)) == 0;
@@ -822,11 +843,42 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		const unsigned grid = (unsigned)((S + 63) / 64);
 		// few, long streams: parallel over time (staged_kernels.h, k_deemph_scan_*); the interval
 		// of candidate states must fit a wave (2a + 2 <= kDeemphGap)
-		const bool scan = T >= 2048 && c.deemph_a >= 2 && 2 * c.deemph_a + 2 <= kDeemphGap && !h->no_deemph_scan &&
-		                  !h->opt.deemph_sequential;
+		const bool scan = deemph_scans(h, T);
 		const bool dbg_sync = h->opt.tail_sync != 0;
 #define RTLFM_DBG_SYNC(what) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(q); fprintf(stderr, "rtlfm_hip[tail]: %s done (%s)\n", what, hipGetErrorString(e_)); } } while (0)
-		if (scan) {
+		if (tp.deemph_spec) {
+			// deemph_filter with no resampler behind it, a long run: ONE pass, out of place (staged_kernels.h, k_deemph_spec)
+			int16_t *dd2; size_t dds2;
+			next_dst(&dd2, &dds2);
+			const int Ws = ((16 * c.deemph_a + 64 + 63) / 64) * 64;
+			const bool congruent = (((uintptr_t)cur ^ (uintptr_t)dd2) & 15) == 0 && ((cur_stride * 2) & 15) == ((dds2 * 2) & 15);
+			if (scan && congruent) {
+				int Lc = h->opt.lpr_chunk;
+				{
+					long long fit = (long long)S * T / 65536;
+					const long long lo = 6ll * Ws > 512 ? 6ll * Ws : 512;
+					if (fit < lo) fit = lo;
+					if (fit < Lc) Lc = (int)fit;
+				}
+				Lc = (Lc + 63) & ~63;  // whole 128-byte rounds
+				const int mcd = T / Lc + 2;
+				const int spw = mcd >= kSpecLprThreads ? 1 : kSpecLprThreads / mcd;
+				const unsigned gsp = (unsigned)((S + spw - 1) / spw);
+#define RTLFM_SPEC_ONLY(MM) k_deemph_spec<MM><<<gsp, kSpecLprThreads, 0, q>>>(cur, cur_stride, dd2, dds2, T, cnt, S, st, mcd, Lc, Ws, sin, sout)
+				if (M == 2) RTLFM_SPEC_ONLY(2); else if (M == 1) RTLFM_SPEC_ONLY(1); else RTLFM_SPEC_ONLY(0);
+#undef RTLFM_SPEC_ONLY
+				RTLFM_DBG_SYNC("one pass (deemph)");
+			} else {
+				// (the plan promised an out-of-place stage and the run turned out otherwise - rows that do not share their
+				// alignment, a run that is shorter than planned: the sequential filter in place, then a copy)
+				if (M == 2) k_deemph<2><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+				else if (M == 1) k_deemph<1><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+				else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
+				HIP_TRY(hipMemcpy2DAsync(dd2, dds2 * sizeof(int16_t), cur, cur_stride * sizeof(int16_t), (size_t)T * sizeof(int16_t), S,
+				                         hipMemcpyDeviceToDevice, q));
+			}
+			cur = dd2; cur_stride = dds2;
+		} else if (scan) {
 			// deemph_filter followed directly by low_pass_real (-M wbfm): the filtered samples go straight
 			// into the resampler's accumulator instead of back to memory (staged_kernels.h)
 			fuse_lpr = tp.lpr && !tp.adc && !h->opt.lpr_separate;
@@ -911,7 +963,17 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				// and a multiple of the resampler's period fast / gcd(fast, slow) where that is short - then all
 				// chunks of a stream start at the same phase, the lanes of a wave emit at the same samples and
 				// the emission branch is taken by whole waves instead of by a few lanes every sample
-				const int Lwant = h->opt.lpr_chunk;  // 256 .. 2^20 (rtlfm_gpu_set_option)
+				// `lpr_chunk` samples per lane where the run fills the GPU that way (-M wbfm at 1024 streams: 64 K lanes); with
+				// fewer samples in all, shorter chunks - about 64 K lanes again, never so short that the settling (W samples
+				// walked twice per chunk) outweighs the chunk (256 streams of rtl_fm -s 48k -r 24k -E deemp: 294 waves on 1024
+				// SIMDs took 1.45 ms for 102 M samples)
+				int Lwant = h->opt.lpr_chunk;  // 256 .. 2^20 (rtlfm_gpu_set_option)
+				{
+					long long fit = (long long)S * T / 65536;
+					const long long lo = 6ll * Ws > 512 ? 6ll * Ws : 512;
+					if (fit < lo) fit = lo;
+					if (fit < Lwant) Lwant = (int)fit;
+				}
 				int Ls = Lwant;
 				int mcsp;
 				{
@@ -1010,11 +1072,18 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 		else k_deemph<0><<<grid, 64, 0, q>>>(cur, cur_stride, T, cnt, S, st, sin, sout);
 	}
 	if (tp.adc) {
+		// dc_block_audio_filter (src/rtl_fm.c:1028-1041): sums per buffer, then the smoothing recurrence and the subtraction
+		// in one launch (staged_kernels.h, k_adc_smooth_apply); option adc_separate: round 4's three kernels
 		k_adc_sums<<<S * nblocks, 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, sin, h->d_adc_sums);
-		k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_adc_sums, Nblk, D, nblocks, S, c.adc_block_const, sin,
-		                                           sout, h->d_adc_avg);
-		k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, S, T, sin,
-		                                                  h->d_adc_avg);
+		if (!h->opt.adc_separate) {
+			k_adc_smooth_apply<<<S * nblocks, 256, (size_t)(nblocks + 1) * sizeof(int32_t), q>>>(cur, cur_stride, Nblk, D, nblocks, c.adc_block_const,
+			                                                                                  h->d_adc_sums, sin, sout);
+		} else {
+			k_adc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_adc_sums, Nblk, D, nblocks, S, c.adc_block_const, sin,
+			                                           sout, h->d_adc_avg);
+			k_adc_apply<<<grid_for((size_t)S * T), 256, 0, q>>>(cur, cur_stride, Nblk, D, nblocks, S, T, sin,
+			                                                  h->d_adc_avg);
+		}
 	}
 	if (tp.lpr && fuse_lpr) {
 		cur = lpr_dst; cur_stride = lpr_ds;
@@ -1075,7 +1144,7 @@ static int run_irregular_rest(rtlfm_gpu *h, const uint32_t *cur, size_t xstride,
 	const rtlfm_cfg &c = h->cfg;
 	const int S = h->nstreams;
 	hipStream_t q = h->stream;
-	TailPlan tp = plan_tail(c);
+	TailPlan tp = plan_tail(h, nblocks);
 	if (tp.any()) {
 		int r = ensure_res_buffers(h, d_iq, iq_bytes);
 		if (r < 0) return r;
@@ -1181,7 +1250,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 		                                                     h->d_mute);
 	}
 	// --- mode_demod (src/rtl_fm.c:1256-1259)
-	TailPlan tp = plan_tail(c);
+	TailPlan tp = plan_tail(h, nblocks);
 	if (tp.any()) {
 		r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
@@ -1275,7 +1344,7 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
-	TailPlan tp = plan_tail(c);
+	TailPlan tp = plan_tail(h, nblocks);
 	if (tp.any()) {
 		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
@@ -1327,11 +1396,15 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
-	{
+	// -M raw behind up to six passes, no squelch: the emitted IQ is the output, straight into the caller's rows where they
+	// take 16-byte stores (as run_boxfused_emit)
+	const bool raw_direct = c.mode == RTLFM_MODE_RAW && !c.squelch_level && !c.report_levels && c.downsample_passes <= fused::kMaxP &&
+	                        !((uintptr_t)d_out & 15) && !(out_stride & 7);
+	if (!raw_direct) {
 		int r0 = ensure_deep_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r0 < 0) return r0;
 	}
-	TailPlan tp = plan_tail(c);
+	TailPlan tp = plan_tail(h, nblocks);
 	if (tp.any()) {
 		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
@@ -1340,11 +1413,15 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
 	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);  // -E rdc in front of -M raw, the squelch, 7-10 passes
-	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, sin, sout, h->d_lut, q, h->deepA,
-	                  h->deep_stride, rdc);
+	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, sin, sout, h->d_lut, q,
+	                  raw_direct ? reinterpret_cast<uint32_t *>(d_out) : h->deepA, raw_direct ? out_stride / 2 : h->deep_stride, rdc);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
+	if (raw_direct) {
+		if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * nblocks * (N0 >> c.downsample_passes));
+		return 0;
+	}
 	uint32_t *cur = h->deepA, *oth = h->deepB;
 	const int first_irr = first_irregular_pass(c);
 	for (int p = level; p < c.downsample_passes && p < first_irr; p++) {
@@ -1395,7 +1472,7 @@ static int run_boxfused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride,
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
-	TailPlan tp = plan_tail(c);
+	TailPlan tp = plan_tail(h, nblocks);
 	if (tp.any()) {
 		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
@@ -1436,9 +1513,12 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 	hipStream_t q = h->stream;
 	const state_t *sin = h->st[h->st_cur];
 	state_t *sout = h->st[(h->st_cur + 1) % 3];
-	int r = ensure_deep_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
+	// -M raw without the squelch: what the launch emits IS the output (raw_demod() copies lowpassed[], src/rtl_fm.c:1002-1009)
+	// - it goes straight into the caller's rows (round 5; a copy kernel over 429 M samples cost more than the decimator)
+	const bool raw_direct = c.mode == RTLFM_MODE_RAW && !c.squelch_level && !c.report_levels;
+	int r = raw_direct ? 0 : ensure_deep_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 	if (r < 0) return r;
-	TailPlan tp = plan_tail(c);
+	TailPlan tp = plan_tail(h, nblocks);
 	if (tp.any()) {
 		r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
@@ -1446,10 +1526,12 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	r = timing_begin(h, ev);
 	if (r < 0) return r;
-	h->fws.tail_follows = true;  // kernels follow on this stream and, with a tail, on the tail's
+	h->fws.tail_follows = !raw_direct;  // kernels follow on this stream and, with a tail, on the tail's
 	int32_t *dcnt = h->d_cnt[h->step & 1];
 	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
-	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, dcnt, sin, sout, q, h->deepA, h->deep_stride, rdc);
+	uint32_t *emit_to = raw_direct ? reinterpret_cast<uint32_t *>(d_out) : h->deepA;
+	const size_t emit_stride = raw_direct ? out_stride / 2 : h->deep_stride;
+	r = boxfused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, dcnt, sin, sout, q, emit_to, emit_stride, rdc);
 	if (r < 0) return r;
 	r = timing_end(h, ev);
 	if (r < 0) return r;
@@ -1457,6 +1539,17 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 	const int Tin = nblocks * N0;
 	const bool varcnt = (N0 % D) != 0;
 	const int T = varcnt ? Tin / D + 1 : Tin / D;
+	if (raw_direct) {
+		if (d_out_len) {
+			if (varcnt) {
+				HIP_TRY(hipMemcpyAsync(d_out_len, dcnt, S * sizeof(int32_t), hipMemcpyDeviceToDevice, q));
+				k_scale_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2, 1);
+			} else {
+				k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T);
+			}
+		}
+		return 0;
+	}
 	uint32_t *cur = h->deepA;
 	if (c.squelch_level || c.report_levels)
 		k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, N0, D, nblocks, sin, c.squelch_level, c.dc_block_raw,
@@ -1503,7 +1596,7 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	// the raw DC block rides on the MFMA pass 0, and only that engine has the partial-tile kernels (-W n)
 	const bool mfma_only = h->cfg.dc_block_raw || fused::needs_partial_tiles(h->cfg);
 	if (mfma_only && fused::effective_engine(h->fws) != 1) can_fuse = false;
-	if (can_fuse && plan_tail(h->cfg).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
+	if (can_fuse && plan_tail(h, nblocks).oop() == 0 && (((uintptr_t)d_out & 15) || (out_stride & 7)))
 		can_fuse = false;  // the fused kernel stores 16-byte vectors straight into d_out
 	const bool can_box = boxfused::supported(h->cfg) || (h->opt.squelch_fused && boxfused::supported_sq(h->cfg));
 	const bool can_box_emit = boxfused::supported_emit(h->cfg);

@@ -204,12 +204,17 @@ k_fifth(const uint32_t *__restrict__ X, uint32_t *__restrict__ Y, size_t xstride
         int nstreams, int p, const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
 	const int M = N / 2;
-	const size_t total = (size_t)nstreams * nblocks * M;
-	RTLFM_GRID_STRIDE(g, total) {
-		int m = (int)(g % M);
-		size_t sb = g / M;
-		int b = (int)(sb % nblocks);
-		size_t s = sb / nblocks;
+	// a workgroup takes 256 consecutive outputs of one (stream, buffer): its place is found once per workgroup with
+	// 32-bit divisions of wave-uniform numbers (round 5: two 64-bit divisions per OUTPUT made this kernel and k_fir9
+	// cost 0.22 ms per step of a seven-pass chain - on 1 / 64 of the data)
+	const unsigned chunks = (unsigned)(M + 255) / 256u;
+	const unsigned long long nwg = (unsigned long long)nstreams * nblocks * chunks;
+	for (unsigned long long wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
+		const unsigned sb = (unsigned)(wg / chunks), ch = (unsigned)(wg - (unsigned long long)sb * chunks);
+		const int b = (int)(sb % (unsigned)nblocks);
+		const size_t s = sb / (unsigned)nblocks;
+		const int m = (int)(ch * 256u + threadIdx.x);
+		if (m >= M) continue;
 		const uint32_t *Xs = X + s * xstride;
 		iq16 e[6];
 		if (m >= 3) {
@@ -241,10 +246,12 @@ __global__ void __launch_bounds__(256)
 k_fir9(const uint32_t *__restrict__ X, uint32_t *__restrict__ Y, size_t xstride, int T, int nstreams,
        int passes, const state_t *__restrict__ sin, state_t *__restrict__ sout)
 {
-	const size_t total = (size_t)nstreams * T;
-	RTLFM_GRID_STRIDE(g, total) {
-		int t = (int)(g % T);
-		size_t s = g / T;
+	const unsigned chunks = (unsigned)(T + 255) / 256u;
+	const unsigned long long nwg = (unsigned long long)nstreams * chunks;
+	for (unsigned long long wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
+		const size_t s = (size_t)(wg / chunks);
+		const int t = (int)((unsigned)(wg - (unsigned long long)s * chunks) * 256u + threadIdx.x);
+		if (t >= T) continue;
 		const uint32_t *Xs = X + s * xstride;
 		int hi[9], hq[9];
 #pragma unroll
@@ -537,10 +544,11 @@ __global__ void __launch_bounds__(256)
 k_simple_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restrict__ R, size_t rstride,
                int T, int nstreams, int mode, int output_scale, const int32_t *__restrict__ cnt)
 {
-	const size_t total = (size_t)nstreams * T;
-	RTLFM_GRID_STRIDE(g, total) {
-		int t = (int)(g % T);
-		size_t s = g / T;
+	const unsigned chunks = (unsigned)(T + 255) / 256u;
+	const unsigned long long nwg = (unsigned long long)nstreams * chunks;
+	for (unsigned long long wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
+		const size_t s = (size_t)(wg / chunks);
+		const int t = (int)((unsigned)(wg - (unsigned long long)s * chunks) * 256u + threadIdx.x);
 		const int Ts = cnt ? cnt[s] : T;
 		if (t >= Ts) continue;
 		uint32_t w = X[s * xstride + t];
@@ -799,6 +807,18 @@ k_deemph(int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restri
 	}
 	const uint32_t avgb = deemph_walk<MAGIC, true>(r, n, (uint32_t)(sin[s].deemph_avg + 32768), ds);
 	sout[s].deemph_avg = (int)avgb - 32768;
+}
+
+// a == 1 (rate_out up to 13 kHz with 75 us: rtl_fm -s 12k -E deemp): avg += (x - avg) / 1 makes avg = x - the filter
+// hands every sample on unchanged and keeps the last one.  Until round 5 this took the one-lane-per-stream walk like
+// any other divisor that the time-parallel form does not cover: 2.16 ms of a 2.2 ms step at 256 streams x 65536 samples.
+__global__ void k_deemph_identity(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
+                                  state_t *__restrict__ sout)
+{
+	RTLFM_GRID_STRIDE(s, nstreams) {
+		const int n = cnt ? cnt[s] : T;
+		if (n > 0) sout[s].deemph_avg = R[(size_t)s * rstride + n - 1];
+	}
 }
 
 // ---- the same filter for few, long streams: exact parallelisation over time ------------------
@@ -1405,6 +1425,132 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 	}
 }
 
+// ---- deemph_filter alone, in one pass (round 5) ---------------------------------------------------------------
+// `rtl_fm -M fm -s 24k -E deemp` - the everyday narrow-band line - ends in deemph_filter with nothing behind it, and took
+// the four passes of the time-parallel form (A1, A2, B, C: the run read three times, written once, 0.77 ms of kernel time
+// per step of 256 streams x 200 K samples beside a 0.77 ms front end).  The same speculation as k_deemph_spec_lpr: a lane
+// per chunk settles its incoming state over the W samples before the chunk (two walks from the two extreme states: where
+// they have met, that is the state) and then filters its chunk - OUT of place (the neighbour's settling reads this
+// chunk's unfiltered samples): 128 bytes in, 128 bytes out per lane and round, the stores of a line back to back.  A
+// stream that cannot settle (silence) or whose carried state lies outside int16 is redone by its workgroup's first lane
+// with the reference's loop.  src and dst rows share their alignment modulo 16 bytes (the host checks).
+template <int MAGIC>
+__device__ __forceinline__ uint32_t deemph_walk_copy(const int16_t *r, int16_t *d, int n, uint32_t avgb, const DeemphStep &ds)
+{
+	auto one = [&](int k) {
+		avgb = ds.step<MAGIC>((uint32_t)(uint16_t)r[k] ^ 0x8000u, avgb);
+		d[k] = (int16_t)(uint16_t)(avgb ^ 0x8000u);
+	};
+	int k = 0;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	for (; k < head && k < n; k++) one(k);
+	auto group = [&](uint4 &g) {
+		uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const uint32_t b = w[j] ^ 0x80008000u;
+			avgb = ds.step<MAGIC>(b & 0xffffu, avgb);
+			const uint32_t lo = avgb;
+			avgb = ds.step<MAGIC>(b >> 16, avgb);
+			w[j] = ((lo & 0xffffu) | (avgb << 16)) ^ 0x80008000u;
+		}
+		g = make_uint4(w[0], w[1], w[2], w[3]);
+	};
+	if (k + 64 <= n) {
+		uint4 cur[8], nxt[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) cur[j] = reinterpret_cast<const uint4 *>(r + k)[j];
+		for (; k + 64 <= n; k += 64) {
+			const bool more = k + 128 <= n;
+			const uint4 *np = reinterpret_cast<const uint4 *>(r + (more ? k + 64 : k));
+#pragma unroll
+			for (int j = 0; j < 8; j++) nxt[j] = np[j];
+#pragma unroll
+			for (int j = 0; j < 8; j++) group(cur[j]);
+#pragma unroll
+			for (int j = 0; j < 8; j++) reinterpret_cast<uint4 *>(d + k)[j] = cur[j];
+#pragma unroll
+			for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+		}
+	}
+	for (; k + 8 <= n; k += 8) {
+		uint4 g = *reinterpret_cast<const uint4 *>(r + k);
+		group(g);
+		*reinterpret_cast<uint4 *>(d + k) = g;
+	}
+	for (; k < n; k++) one(k);
+	return avgb;
+}
+
+template <int MAGIC>
+__global__ void __launch_bounds__(kSpecLprThreads)
+k_deemph_spec(const int16_t *R, size_t rstride, int16_t *__restrict__ B, size_t bstride, int T, const int32_t *__restrict__ cnt,
+              int nstreams, DeemphStep ds, int max_chunks, int L, int W, const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+#if RTLFM_TAIL_PRIO >= 0
+	__builtin_amdgcn_s_setprio(RTLFM_TAIL_PRIO);
+#endif
+	__shared__ int unsettled[kSpecLprThreads];  // per stream of this workgroup
+	const int nthreads = (int)blockDim.x, tid = (int)threadIdx.x;
+	const int spw = max_chunks >= nthreads ? 1 : nthreads / max_chunks;  // streams per workgroup
+	unsettled[tid] = 0;
+	__syncthreads();
+	const int sl = spw == 1 ? 0 : tid / max_chunks;
+	const size_t s = (size_t)blockIdx.x * spw + sl;
+	const bool live = sl < spw && s < (size_t)nstreams;
+	int n = 0, nc = 0, head = 0, carried = 0;
+	const int16_t *r = nullptr;
+	int16_t *d = nullptr;
+	bool plain = false;
+	if (live) {
+		n = cnt ? cnt[s] : T;
+		r = R + s * rstride;
+		d = B + s * bstride;
+		head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+		nc = deemph_chunks(n, head, L);
+		carried = sin[s].deemph_avg;
+		plain = (uint32_t)(carried + 32768) > 65535u;
+	}
+	const int c_first = spw == 1 ? tid : tid - sl * max_chunks, c_step = spw == 1 ? nthreads : max_chunks;
+	if (live && !plain) {
+		for (int c = c_first; c < nc; c += c_step) {
+			int begin, end;
+			deemph_chunk_range(c, n, head, L, begin, end);
+			bool settled = true;
+			uint32_t v = (uint32_t)(carried + 32768);
+			if (begin > 0) {
+				if (begin <= W) {
+					uint32_t v2 = v;
+					deemph_walk_pair<MAGIC>(r, begin, v, v2, ds);  // close to the start of the run: from the carried state itself
+				} else {
+					uint32_t lo = 0, hi = 65535;
+					deemph_walk_pair<MAGIC>(r + begin - W, W, lo, hi, ds);
+					settled = lo == hi;
+					v = lo;
+				}
+			}
+			if (!settled) { unsettled[sl] = 1; continue; }
+			const int v_end = (int)deemph_walk_copy<MAGIC>(r + begin, d + begin, end - begin, v, ds) - 32768;
+			if (c == nc - 1) sout[s].deemph_avg = v_end;
+		}
+	}
+	__syncthreads();
+	if (!live || c_first != 0 || !(plain || unsettled[sl])) return;
+	// the reference's loop over the whole run, on the stream's first lane (deemph_filter, src/rtl_fm.c:1011-1026)
+	if (plain) {
+		int avg = carried;
+		const int a = (int)ds.a, half = a / 2;
+		for (int k = 0; k < n; k++) {
+			const int dd = r[k] - avg;
+			avg += dd > 0 ? (dd + half) / a : (dd - half) / a;
+			d[k] = (int16_t)avg;
+		}
+		sout[s].deemph_avg = avg;
+	} else {
+		sout[s].deemph_avg = (int)deemph_walk_copy<MAGIC>(r, d, n, (uint32_t)(carried + 32768), ds) - 32768;
+	}
+}
+
 // the outputs that straddle chunk boundaries, the carried accumulator and the output count
 __global__ void __launch_bounds__(64)
 k_lpr_fixup(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams, int max_chunks,
@@ -1454,16 +1600,14 @@ k_adc_sums(const int16_t *__restrict__ R, size_t rstride, int N, int D, int nblo
 	const int p0 = D > 1 ? sin[s].prev_index : 0;
 	const int t0 = dec_block_begin(b, N, D, p0), t1 = dec_block_begin(b + 1, N, D, p0);
 	const int16_t *r = R + s * rstride + t0;
-	long long acc = 0;
+	int acc = 0;  // at most 2^17 samples of 16 bits per lane: 32 bits hold it
 	for (int k = threadIdx.x; k < t1 - t0; k += blockDim.x) acc += r[k];
-	__shared__ long long red[256];
-	red[threadIdx.x] = acc;
+	long long a64 = acc;
+	for (int off = 32; off > 0; off >>= 1) a64 += __shfl_down(a64, off, 64);
+	__shared__ long long red[4];
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a64;
 	__syncthreads();
-	for (int off = 128; off > 0; off >>= 1) {
-		if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) sums[sb] = red[0];
+	if (threadIdx.x == 0) sums[sb] = red[0] + red[1] + red[2] + red[3];
 }
 // ... the smoothing recurrence sequentially per stream ...
 __global__ void k_adc_smooth(const long long *__restrict__ sums, int N, int D, int nblocks, int nstreams,
@@ -1498,6 +1642,42 @@ k_adc_apply(int16_t *__restrict__ R, size_t rstride, int N, int D, int nblocks, 
 		int16_t *r = R + s * rstride + t;
 		*r = (int16_t)(*r - avg[s * nblocks + b]);
 	}
+}
+
+// Round 5: the smoothing and the subtraction in ONE launch behind the sums, a workgroup per (stream, buffer).  The
+// recurrence avg_b = (mean_b + k avg_{b-1}) / (k + 1) over a stream's buffers is two integer operations per buffer, so
+// every workgroup simply runs it from the carried dc_avg up to its own buffer (k_adc_smooth did that in a launch of its
+// own, one lane per stream), and the subtraction knows its buffer's extent instead of finding every sample's buffer with a
+// 64-bit division (k_adc_apply).  The last buffer's workgroup leaves dc_avg.  Same integers.
+// (A first form - one workgroup per stream doing all three steps - was SLOWER at 256 streams x 64 buffers: 256 workgroups
+// do not fill the GPU; rtl_fm -M am -s 12k -E dc 0.82 -> 0.90 ms per step.)
+__global__ void __launch_bounds__(256)
+k_adc_smooth_apply(int16_t *__restrict__ R, size_t rstride, int N, int D, int nblocks, int k, const long long *__restrict__ sums,
+                   const state_t *__restrict__ sin, state_t *__restrict__ sout)
+{
+	extern __shared__ int32_t adc_means[];  // [nblocks] block means, then the workgroup's average in adc_means[nblocks]
+	const int sb = blockIdx.x;
+	const int b = sb % nblocks;
+	const size_t s = sb / nblocks;
+	const int p0 = D > 1 ? sin[s].prev_index : 0;
+	// the means of buffers 0 .. b, a lane each (the 64-bit division of a sum by its count is the expensive part: in
+	// parallel), then the recurrence on one lane: two 32-bit operations per buffer
+	for (int j = threadIdx.x; j <= b; j += 256) {
+		const int len = dec_block_begin(j + 1, N, D, p0) - dec_block_begin(j, N, D, p0);
+		adc_means[j] = (int)(sums[s * nblocks + j] / len);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int avg = sin[s].dc_avg;
+		for (int j = 0; j <= b; j++) avg = (adc_means[j] + avg * k) / (k + 1);
+		adc_means[nblocks] = avg;
+		if (b == nblocks - 1) sout[s].dc_avg = avg;
+	}
+	__syncthreads();
+	const int avg = adc_means[nblocks];
+	const int t0 = dec_block_begin(b, N, D, p0), t1 = dec_block_begin(b + 1, N, D, p0);
+	int16_t *r = R + s * rstride;
+	for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) r[t] = (int16_t)(r[t] - avg);
 }
 
 // low_pass_real (src/rtl_fm.c:755-775) in closed form over the stream's run:

@@ -534,6 +534,29 @@ def test_fifth_order_on_buffers_its_passes_do_not_divide(oracle_lib, front, L):
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, path, splits, s_)
 
 
+@pytest.mark.parametrize("ov", [dict(downsample=42, rate_out=24000, dc_block_audio=1),
+                                dict(downsample=84, rate_out=12000, mode=1, output_scale=3, dc_block_audio=1, adc_block_const=3),
+                                dict(downsample=16, downsample_passes=4, dc_block_audio=1, deemph=1, deemph_a=12),
+                                dict(downsample=6, rate_out=170000, custom_atan=1, deemph=1, deemph_a=13, dc_block_audio=1, rate_out2=32000, resampler=1)])
+@pytest.mark.parametrize("L,nb,ns", [(16384, 9, 5), (262144, 3, 2), (512 * 23, 6, 3)])
+def test_dc_block_audio_in_one_launch(oracle_lib, ov, L, nb, ns):
+    """dc_block_audio_filter (-E dc, src/rtl_fm.c:1028-1041) as the sums + ONE kernel for the smoothing recurrence and the
+    subtraction (k_adc_smooth_apply: a workgroup per buffer runs the recurrence up to its own buffer) and as round 4's three
+    kernels (adc_separate = 1):
+    the oracle's output and carried dc_avg either way, behind boxcars that do not divide the buffer, deemph in front of it,
+    low_pass_real behind it, runs split over launches."""
+    cfg = make_cfg(ov, L, nb)
+    amp = 20.0 if ov.get("custom_atan") == 1 else 50.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=L + nb, fs=1.008e6, dev_hz=3e3, amplitude=amp)
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=2)
+    for splits, opts in ((None, None), ([(0, 1), (1, nb)], None), (None, dict(adc_separate=1))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_], (ov, L, splits, opts, s_)
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"{ov} L={L} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (ov, L, splits, opts, s_)
+
+
 def test_options_by_name():
     """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
     from rtlsdr_amd.demod import GpuDemod
@@ -1460,8 +1483,8 @@ def test_placement_is_observable_and_bounded():
             g0.rtlsdr_callback(buf, s)
         assert g0.get_option("ring_apart") == 0 and g0.get_option("placement_walked_mb") == 0
         assert g0.get_option("deep_apart") == -1     # this configuration has no emit-mode buffer
-        # the buffer a front end's emit mode writes (here: -M raw behind four passes) is placed as well
-        ge = GpuDemod(make_cfg(dict(downsample=16, downsample_passes=4, mode=capi.MODE_RAW), L, 1), ns, 0)
+        # the buffer a front end's emit mode writes (here: the /64 IQ of a seven-pass chain) is placed as well
+        ge = GpuDemod(make_cfg(dict(downsample=128, downsample_passes=7), L, 1), ns, 0)
         hs.append(ge)
         assert ge.get_option("deep_apart") == -1
         for s in range(ns):
