@@ -548,32 +548,25 @@ def _timed(job, warm, K):
 
 
 class ColocatedRows:
-    """int16 [rows, cols] device memory that SHARES its class of the HBM with `other` - what a caller who knows nothing of
-    the placement often gets.  Plain allocations of several sizes are classified with rtlfm_gpu_placement_probe until one
-    is co-located (probe: 0); `colocated` says whether one was found, `tries` how many allocations it took."""
+    """int16 [rows, cols] device memory that SHARES its class of the HBM with its input - what a caller who knows nothing of
+    the placement often gets: ONE allocation holds a copy of the input and, behind it, the output rows (offsets inside an
+    allocation do not change the class).  `colocated`: what rtlfm_gpu_placement_probe says about the two."""
 
-    def __init__(self, rows, cols, other_ptr, other_bytes, device):
+    def __init__(self, rows, cols, iq, dev):
         import ctypes as C
-        from rtlsdr_amd.capi import check, load
+        import torch
+        from rtlsdr_amd.capi import load
         self.lib = load()
         self.rows, self.cols = rows, cols
-        need = rows * cols * 2
-        held, self.ptr, self.colocated, self.tries = [], None, False, 0
-        for gib in (0, 0, 1, 2, 4, 1, 2, 4):
-            p = C.c_void_p()
-            if self.lib.rtlfm_gpu_malloc(device, max(need, gib << 30), C.byref(p)) != 0:
-                break
-            self.tries += 1
-            rd, rw = C.c_double(), C.c_double()
-            r = self.lib.rtlfm_gpu_placement_probe(device, other_ptr, other_bytes, p, need, C.byref(rd), C.byref(rw))
-            if r == 0:
-                self.ptr, self.colocated = p.value, True
-                break
-            held.append(p.value)
-        if self.ptr is None:  # every allocation came out apart: the last one serves, and the leg says so
-            self.ptr = held.pop()
-        for q in held:
-            self.lib.rtlfm_gpu_free(q)
+        nin = (iq.numel() + 255) & ~255
+        self.buf = torch.empty(nin + rows * cols * 2, dtype=torch.uint8, device=dev)
+        self.buf[:iq.numel()].view(iq.shape).copy_(iq)
+        torch.cuda.synchronize()
+        self.iq_ptr = self.buf.data_ptr()
+        self.ptr = self.iq_ptr + nin
+        rd, rw = C.c_double(), C.c_double()
+        r = self.lib.rtlfm_gpu_placement_probe(dev.index or 0, self.iq_ptr, iq.numel(), self.ptr, rows * cols * 2, C.byref(rd), C.byref(rw))
+        self.colocated = r == 0
         self.apart = not self.colocated
 
     def data_ptr(self):
@@ -583,9 +576,8 @@ class ColocatedRows:
         return self.cols if dim == 0 else 1
 
     def free(self):
-        if self.ptr:
-            self.lib.rtlfm_gpu_free(self.ptr)
-            self.ptr = None
+        self.buf = None
+        self.ptr = None
 
 
 def _leg_entry(name, job, launch_ms, step_ms, K, ceiling):
@@ -630,8 +622,12 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
             self.g = GpuDemod(cfg, S, local_rank)
             cap = self.g.result_cap(nb)
             have = job.out.rows * job.out.cols if isinstance(job.out, ApartRows) else 0
+            self.iq_ptr = job.iq.data_ptr()
             if colocated:
-                self.o = ColocatedRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
+                # input and output in ONE allocation: the same class of the HBM by construction (offsets inside an allocation
+                # do not matter: LAB.md II 3.1) - a copy of the input, the output rows behind it
+                self.o = ColocatedRows(S, cap, job.iq, dev)
+                self.iq_ptr = self.o.iq_ptr
             elif S * cap <= have:
                 # the default workload's own output buffer, whose placement is known, under this leg's row length
                 outer = job.out
@@ -649,14 +645,14 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
                         pass
                 self.o = View()
             else:
-                self.o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank)
+                self.o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank, 64)
             self.output_apart = self.o.apart
             self.n = torch.zeros(S, dtype=torch.int32, device=dev)
             self.samples = S * nb * self.L // 2
             self.alg_bytes_per_sample = job.alg_bytes_per_sample
 
         def step(self):
-            self.g.run_device(job.iq.data_ptr(), self.per_stream, self.nb, self.o.data_ptr(), self.o.stride(0), self.n.data_ptr())
+            self.g.run_device(self.iq_ptr, self.per_stream, self.nb, self.o.data_ptr(), self.o.stride(0), self.n.data_ptr())
 
         def sync(self):
             self.g.sync()
@@ -685,11 +681,12 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
                 e["waves_per_stream"] = len(st) // S
             if colo:
                 e["colocated"] = r.o.colocated
-                e["colocated_tries"] = r.o.tries
+                e["how"] = "a copy of the input and the output rows inside ONE allocation"
             out[name] = e
             r.close()
     for name in ("c3", "c1", "wbfm", "scanner", "c4"):
         b = workload_args(a, name)
+        b.crowded = True  # this process holds the default workload's buffers (and what the legs before left behind)
         j = None
         try:
             j = (PowerJob if b.tail == "power" else FmJob)(b, dev, local_rank, rank)
@@ -785,7 +782,7 @@ class FmJob:
         else:
             self.iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=a.fs, dev_hz=75e3 if a.fs > 2e6 or a.tail == "wbfm" else 5e3,
                                            amplitude=amp, first_stream=rank * S)
-        self.g = GpuDemod(self.cfg, S, local_rank)
+        self.g = GpuDemod(self.cfg, S, local_rank, options=({"apart_budget_gb": 64} if getattr(a, "crowded", False) else None))
         self.g.set_path(a.path)
         cap = self.g.result_cap(NB) + int(os.environ.get("RTLFM_BENCH_ROW_PAD", "0"))  # experiments: rows off the 128-byte lines
         # the output a quarter of the HBM away from the input (data layout); --colocate 1 = wherever torch puts it
@@ -799,7 +796,9 @@ class FmJob:
             # (r04: a first search walked 152 GB in 4.7 s and found nothing; with the input moved the first candidate was apart.
             # Round 5: the search itself is bounded - eight candidates of different sizes, 16 GiB held at most)
             tries = []
-            for attempt, budget_gb in enumerate((16, 16, 16)):
+            # the default workload (a fresh process) searches within the library's bound; the `also` legs run in a process that
+            # already holds tens of GB, where a run of one class can be longer than 16 GB: they may walk further
+            for attempt, budget_gb in enumerate((16, 16, 16) if not getattr(a, "crowded", False) else (16, 64, 150)):
                 self.out = ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank, budget_gb)
                 tries.append({"apart": self.out.apart, "search_ms": self.out.search_ms, "walked_mb": self.out.walked_mb})
                 if self.out.apart or attempt == 2 or a.pmc_child:
