@@ -109,6 +109,7 @@ struct rtlfm_gpu {
 	struct Options {
 		int deemph_sequential = 0, deemph_four_pass = 0, lpr_separate = 0, lpr_scalar_stores = 0, tail_sync = 0;
 		int lpr_chunk = 5440;  // samples per lane of the one-pass deemph + low_pass_real kernel (round 5: 2720 -> 5440 with the outputs leaving through LDS)
+		int deep_rest = 1;     // 0: the passes beyond six, generic_fir and the demodulator as a launch each (round 4) instead of k_deep_rest
 		int adc_separate = 0;  // 1: dc_block_audio_filter as three kernels (sums, smoothing, subtraction) instead of two
 		int squelch_fused = 1; // 0: the squelch / -L behind the boxcar through the emit mode and k_squelch_rms / _hits / _zero / k_fm_demod (round 4) also where the front end can take rms()'s sums itself
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
@@ -569,7 +570,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -1424,6 +1425,50 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 	}
 	uint32_t *cur = h->deepA, *oth = h->deepB;
 	const int first_irr = first_irregular_pass(c);
+	// seven and more passes on buffers they divide: the passes beyond six, generic_fir and (without a squelch) the
+	// demodulator in ONE launch, a workgroup per (stream, buffer) in LDS (staged_kernels.h, k_deep_rest)
+	if (c.downsample_passes > level && first_irr >= c.downsample_passes && h->opt.deep_rest) {
+		int kk[6];
+		deep_rest_tails(c.downsample_passes, c.comp_fir_size == 9, kk);
+		const int n6 = N0 >> level, nF = N0 >> c.downsample_passes;
+		if (n6 >= 2 * kk[0] && nF - kk[c.downsample_passes - level] >= 3) {
+			const bool demod_here = !c.squelch_level && !c.report_levels && c.mode != RTLFM_MODE_RAW;
+			DeepRestParams dp{};
+			dp.X = cur; dp.xstride = h->deep_stride; dp.n6 = n6; dp.nblocks = nblocks; dp.nstreams = S; dp.passes = c.downsample_passes;
+			dp.fir = c.comp_fir_size == 9 ? 1 : 0; dp.kt = kk[0];
+			dp.mode = c.mode; dp.variant = c.custom_atan; dp.output_scale = c.output_scale; dp.lut = h->d_lut;
+			dp.sin = sin; dp.sout = sout;
+			const int T2 = nblocks * nF;
+			int16_t *dd2; size_t dds2;
+			tail_route(h, tp, d_out, out_stride, &dd2, &dds2);
+			if (demod_here) { dp.R = dd2; dp.rstride = dds2; }
+			else { dp.Y = oth; dp.ystride = h->deep_stride; }
+			const size_t lds_b = (size_t)2 * (kk[0] + n6 + 8) * sizeof(uint32_t);
+			k_deep_rest<<<(unsigned)((size_t)S * nblocks), 256, lds_b, q>>>(dp);
+			if (demod_here) return run_tail(h, tp, dd2, dds2, T2, false, nblocks, nF, 1, d_out, out_stride, d_out_len);
+			std::swap(cur, oth);
+			// the squelch, -L, -M raw on the final level, as below
+			const int Nblk2 = nF;
+			if (c.squelch_level || c.report_levels)
+				k_squelch_rms<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, Nblk2, 1, nblocks, sin, c.squelch_level,
+				                                         c.dc_block_raw, h->d_mute, h->d_levels);
+			if (c.squelch_level) {
+				k_squelch_hits<<<grid_for(S, 64), 64, 0, q>>>(h->d_mute, nblocks, S, sin, sout);
+				k_squelch_zero<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, Nblk2, 1, nblocks, S, T2, sin, h->d_mute);
+			}
+			if (c.mode == RTLFM_MODE_FM)
+				k_fm_demod<<<S * nblocks, 256, 0, q>>>(cur, h->deep_stride, dd2, dds2, T2, S, Nblk2, 1, nblocks, c.custom_atan,
+				                                         h->d_lut, nullptr, sin, sout);
+			else
+				k_simple_demod<<<grid_for((size_t)S * T2), 256, 0, q>>>(cur, h->deep_stride, dd2, dds2, T2, S, c.mode,
+				                                                      c.output_scale, nullptr);
+			if (c.mode == RTLFM_MODE_RAW) {
+				if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, 2 * T2);
+				return 0;
+			}
+			return run_tail(h, tp, dd2, dds2, T2, false, nblocks, Nblk2, 1, d_out, out_stride, d_out_len);
+		}
+	}
 	for (int p = level; p < c.downsample_passes && p < first_irr; p++) {
 		const int N = N0 >> p;
 		k_fifth<<<grid_for((size_t)S * nblocks * (N / 2)), 256, 0, q>>>(cur, oth, h->deep_stride, N, nblocks, S, p,

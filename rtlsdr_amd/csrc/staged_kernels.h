@@ -560,6 +560,136 @@ k_simple_demod(const uint32_t *__restrict__ X, size_t xstride, int16_t *__restri
 	}
 }
 
+// ---- passes 6 .. P-1, generic_fir and mode_demod behind the six-pass front end, in ONE launch (round 5) --------
+// `rtl_fm -s 12k -F 9` plans seven passes, `-s 3k -F 9` nine: k_fused<6> emits the /64 IQ and round 4 finished with one
+// k_fifth launch per pass, k_fir9 and k_fm_demod - 0.2 ms per step on 1 / 64 of the data.  Here a workgroup takes one
+// (stream, buffer): the buffer's /64 samples and the last `kt` of the buffer before go into LDS, every pass runs there
+// (level by level, ping-pong), then the filter and the demodulator.  What a buffer needs of its predecessor - the
+// fifth_order history of every pass (x[N-7 .. N-2] of that level: the archive never holds x[N-1], src/rtl_fm.c:800-805),
+// generic_fir's nine samples, fm_demod's previous sample - is RECOMPUTED from the predecessor's tail: outputs at negative
+// indices, the general formula, no state of the predecessor's own start involved (the host checks that the tail is short
+// against the buffer).  Buffer 0 takes them from the carried state, the last buffer leaves them there.
+struct DeepRestParams {
+	const uint32_t *X; size_t xstride;  // level 6, packed (I, Q): n6 samples per buffer, a stream's buffers back to back
+	int n6, nblocks, nstreams, passes;  // passes: 7 .. 10 (6 .. passes - 1 run here)
+	int fir, kt;                        // generic_fir behind them; samples of the buffer before taken along at level 6
+	uint32_t *Y; size_t ystride;        // the decimated, FIR-compensated IQ (squelch, -L, -M raw behind it), or
+	int16_t *R; size_t rstride;         // ... the PCM: fm / am / usb / lsb demodulated here (Y == nullptr)
+	int mode, variant, output_scale;
+	const int32_t *lut;
+	const state_t *sin; state_t *sout;
+};
+// tail lengths per level for `passes` (index 0 = level 6): what the next level, the filter and the demodulator reach back
+__host__ __device__ inline void deep_rest_tails(int passes, int fir, int k[6])
+{
+	const int L = passes - 6;
+	k[L] = fir ? 10 : 1;
+	for (int j = L - 1; j >= 0; j--) {
+		k[j] = 2 * k[j + 1] + 5;
+		if (k[j] < 6) k[j] = 6;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_deep_rest(const DeepRestParams p)
+{
+	extern __shared__ uint32_t dr_lds[];
+	const int sb = blockIdx.x;
+	const int b = sb % p.nblocks;
+	const size_t s = sb / p.nblocks;
+	const int tid = threadIdx.x;
+	const state_t &in = p.sin[s];
+	const bool first = b == 0, last = b == p.nblocks - 1;
+	int kk[6];
+	deep_rest_tails(p.passes, p.fir, kk);
+	const int L = p.passes - 6;
+	const int cap = p.kt + p.n6 + 8;
+	uint32_t *A = dr_lds, *B = dr_lds + cap;
+	// level 6: samples [-k, n6) of this buffer (negative: the buffer before), at A[i + k]
+	int k = first ? 0 : kk[0], n = p.n6;
+	{
+		const uint32_t *x = p.X + s * p.xstride + (size_t)b * p.n6;
+		for (int i = tid - k; i < n; i += 256) A[i + k] = x[i];
+	}
+	__syncthreads();
+	for (int j = 0; j < L; j++) {
+		const int pass = 6 + j;
+		const int k2 = first ? 0 : kk[j + 1], n2 = n / 2;
+		// sample idx of the level going in, as fifth_order sees it from output m >= 0 of this buffer: behind the buffer's
+		// start the archive of the buffer before, x[N-1+idx] (the last sample is never kept)
+		auto fetch = [&](int idx) -> iq16 {
+			if (idx >= 0) return unpack_iq(A[idx + k]);
+			if (!first) return unpack_iq(A[idx - 1 + k]);
+			iq16 r; r.i = in.lp_i_hist[pass][6 + idx]; r.q = in.lp_q_hist[pass][6 + idx];
+			return r;
+		};
+		for (int m = tid - k2; m < n2; m += 256) {
+			iq16 e[6];
+			if (m >= 3) {
+#pragma unroll
+				for (int q = 0; q < 6; q++) e[q] = unpack_iq(A[2 * m - 5 + q + k]);
+			} else if (m >= 0) {
+#pragma unroll
+				for (int q = 0; q < 6; q++) e[q] = fetch(2 * m - 5 + q);
+			} else {
+				// an output of the buffer before (its own samples, no archive in between)
+#pragma unroll
+				for (int q = 0; q < 6; q++) e[q] = unpack_iq(A[2 * m - 5 + q + k]);
+			}
+			const int yi = fifth_tap(e[0].i, e[1].i, e[2].i, e[3].i, e[4].i, e[5].i);
+			const int yq = fifth_tap(e[0].q, e[1].q, e[2].q, e[3].q, e[4].q, e[5].q);
+			B[m + k2] = pack_iq((int16_t)yi, (int16_t)yq);
+			if (last && m == n2 - 1) {
+#pragma unroll
+				for (int q = 0; q < 6; q++) { p.sout[s].lp_i_hist[pass][q] = e[q].i; p.sout[s].lp_q_hist[pass][q] = e[q].q; }
+			}
+		}
+		__syncthreads();
+		uint32_t *t = A; A = B; B = t;
+		k = k2; n = n2;
+	}
+	// A: the last level, samples [-k, n).  generic_fir (src/rtl_fm.c:808-831): output t = taps over samples t-9 .. t-1
+	if (p.fir) {
+		auto xs = [&](int idx) -> iq16 {
+			if (idx >= 0 || !first) return unpack_iq(A[idx + k]);
+			iq16 r; r.i = in.droop_i_hist[9 + idx]; r.q = in.droop_q_hist[9 + idx];
+			return r;
+		};
+		const int t_lo = first ? 0 : -1;  // (the output in front of the buffer: fm_demod's previous sample)
+		for (int t = tid + t_lo; t < n; t += 256) {
+			int hi[9], hq[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++) { const iq16 v = xs(t - 9 + q); hi[q] = v.i; hq[q] = v.q; }
+			B[t + 1] = pack_iq((int16_t)fir9_tap(hi, k_cic9[p.passes]), (int16_t)fir9_tap(hq, k_cic9[p.passes]));
+			if (last && t == n - 1) {
+				const iq16 cur = unpack_iq(A[t + k]);
+				for (int q = 0; q < 8; q++) { p.sout[s].droop_i_hist[q] = (int16_t)hi[q + 1]; p.sout[s].droop_q_hist[q] = (int16_t)hq[q + 1]; }
+				p.sout[s].droop_i_hist[8] = cur.i; p.sout[s].droop_q_hist[8] = cur.q;
+			}
+		}
+		__syncthreads();
+		uint32_t *t = A; A = B; B = t;
+		k = 1;  // A[t + 1] = filtered sample t, t >= -1
+	}
+	// A[t + k]: what full_demod() hands to the squelch and mode_demod()
+	if (p.Y) {
+		uint32_t *y = p.Y + s * p.ystride + (size_t)b * n;
+		for (int t = tid; t < n; t += 256) y[t] = A[t + k];
+		return;
+	}
+	int16_t *r = p.R + s * p.rstride + (size_t)b * n;
+	for (int t = tid; t < n; t += 256) {
+		const uint32_t w = A[t + k];
+		if (p.mode != RTLFM_MODE_FM) { r[t] = simple_demod(p.mode, w, p.output_scale); continue; }
+		const iq16 cur = unpack_iq(w);
+		int br, bj;
+		if (t > 0 || !first) { const iq16 pv = unpack_iq(A[t - 1 + k]); br = pv.i; bj = pv.q; }
+		else { br = in.pre_r; bj = in.pre_j; }
+		// fm_demod (:932-959): the first output of a buffer is always polar_discriminant
+		r[t] = (int16_t)(t == 0 ? disc_std(cur.i, cur.q, br, bj) : discriminate(p.variant, cur.i, cur.q, br, bj, p.lut));
+		if (last && t == n - 1) { p.sout[s].pre_r = cur.i; p.sout[s].pre_j = cur.q; }
+	}
+}
+
 // ---- fifth_order on lengths its passes do not divide (round 5) -------------------------------------------------
 // `rtl_fm -W n -F 9` with nine or ten passes and n odd (n % 4 != 0 for ten) is something the reference runs
 // (src/rtl_fm.c:1188-1191): pass 8 (or 9) is then called with a length that is not a multiple of four elements - it

@@ -917,14 +917,17 @@ def test_fused_deep_passes(oracle_lib, passes, fir9, atan, mode, L, nb, ns):
     amp = 20.0 if atan == 1 else 55.0
     iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=3000 + passes, fs=1.024e6, dev_hz=2.5e3, amplitude=amp)
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
-    fo, fst, used = gpu_run(cfg, iq, path=2, splits=[(0, 1), (1, nb)])
-    assert used == 2
     so, sst, used1 = gpu_run(cfg, iq, path=1)
     assert used1 == 1
-    for s in range(ns):
-        assert np.array_equal(fo[s], so[s]), (passes, s)
-        assert_parity(fo[s], want[s, :want_len[s]], cfg, f"deep P={passes}[{s}]")
-        assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False)
+    # deep_rest = 0: the passes beyond six, generic_fir and the demodulator as a launch each (round 4) instead of k_deep_rest
+    # (a workgroup per (stream, buffer) in LDS, the buffer before's tail recomputed; round 5)
+    for splits, opts in (([(0, 1), (1, nb)], None), (None, None), ([(0, 1), (1, nb)], dict(deep_rest=0)), (None, dict(fused_tiles_per_seg=3))):
+        fo, fst, used = gpu_run(cfg, iq, path=2, splits=splits, options=opts)
+        assert used == 2
+        for s in range(ns):
+            assert np.array_equal(fo[s], so[s]), (passes, splits, opts, s)
+            assert_parity(fo[s], want[s, :want_len[s]], cfg, f"deep P={passes} {splits} {opts} [{s}]")
+            assert gu.state_dict(fst[s], False) == gu.state_dict(wst[s], False), (passes, splits, opts, s)
 
 
 @pytest.mark.parametrize("ov", [
