@@ -594,6 +594,10 @@ def _leg_entry(name, job, launch_ms, step_ms, K, ceiling):
         e["output_apart"] = job.output_apart
     if ceiling and job.a.tail != "power":
         e["frac_of_ceiling"] = round(ach / ceiling["read_write"], 4)
+    if job.a.tail != "power" and hasattr(job.g, "get_option"):
+        # where the handle put its OWN buffers (the audio tail's work buffers, the emit-mode buffer): 1 = apart from the
+        # input, 0 = searched and not found, -1 = this configuration has none
+        e["handle_placement"] = {k: job.g.get_option(k) for k in ("res_apart", "deep_apart", "placement_ms", "placement_walked_mb")}
     return e
 
 
@@ -1181,6 +1185,8 @@ def main():
                 "prewarm_steps": prewarm,
                 "output_apart": getattr(job, "output_apart", None),
                 "output_placement": getattr(job, "placement", None),
+                "handle_placement": ({k: job.g.get_option(k) for k in ("res_apart", "deep_apart", "placement_ms", "placement_walked_mb")}
+                                     if a.tail != "power" else None),
                 "device": torch.cuda.get_device_name(local_rank),
             },
             "roofline": roof,

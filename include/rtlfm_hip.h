@@ -280,12 +280,20 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   fused_tiles_per_seg  > 0: exactly this segment length (tests)
  *   pass0_engine         -1 compiled default, 0 v_dot4, 1 int8 MFMA (as rtlfm_gpu_set_path 3 / 4)
  *   tail_serial          1: audio tail on the front end's stream, no overlap with the next step
+ *   tail_priority        -1 (default) / 0 / 1: the tail's own stream at the lowest / default / highest HIP priority.  Not a
+ *                        scheduling hint: streams of one priority share four hardware queues, and a tail that shares the
+ *                        front end's queue runs behind the next step instead of beside it; another priority = another pool
  *   deemph_sequential    1: deemph_filter one lane per stream, never parallel over time
  *   deemph_four_pass     1: no one-pass (speculative) deemph kernels
  *   lpr_separate         1: low_pass_real as a kernel of its own behind deemph_filter
  *   lpr_scalar_stores    1: the resampler's outputs one by one
- *   lpr_chunk            samples per lane of the one-pass deemph + low_pass_real kernel (default 2720; 256 ... 2^20,
- *                        anything else -EINVAL)
+ *   lpr_chunk            most samples per lane of the one-pass deemph + low_pass_real kernel (default 5440; 256 ... 2^20,
+ *                        anything else -EINVAL); shorter runs get shorter chunks so that about 64 K lanes work
+ *   lpr_ring             1 (default): that kernel's outputs leave through LDS in aligned 64-byte pieces; 0: 16 bytes per lane
+ *   squelch_fused        1 (default): rms()'s sums per buffer inside the front end + k_squelch_apply; 0: emit mode + k_squelch_*
+ *   adc_separate         1: dc_block_audio as sums / smooth / apply kernels (round 4) instead of sums + k_adc_smooth_apply
+ *   deep_rest            1 (default): passes 6 ... 9, generic_fir and the demodulator behind k_fused<6>'s emit mode in ONE
+ *                        kernel per step (k_deep_rest); 0: one staged kernel per stage
  *   apart_budget_gb      most device memory (GiB, default 16, never more than half of what is free) a placement
  *                        search may hold in candidate allocations; 0 = no search, plain allocations
  *   arb_span             1: config 3's one-kernel tail as k_deemph_arb_span (the span linear in LDS, 16-byte table entries,

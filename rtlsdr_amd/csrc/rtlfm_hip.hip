@@ -80,6 +80,7 @@ struct rtlfm_gpu {
 	int st_cur = 0;
 	unsigned step = 0;                      // parity selects res[] / d_cnt[] / the events
 	hipStream_t tail_stream = nullptr;
+	int tail_priority = 0;
 	hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
 	bool tail_pending[2] = {false, false};  // ev_tail[p] has been recorded and not yet waited for
 	bool tail_overlap = true;
@@ -335,7 +336,16 @@ static int create_body(rtlfm_gpu *h)
 	// (default priority: the highest and the lowest one were both tried - round 3: highest 1 % slower; round 4,
 	// three alternations on one box: c3 0.883 / 0.881 / 0.883 ms, wbfm 1.381 / 1.381 / 1.379 for default / lowest /
 	// highest - the dispatcher does not seem to look at it between two compute queues)
-	HIP_TRY(hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+	// Round 5: the LOWEST priority, and not for the dispatcher's sake: HIP maps the streams of one priority onto four
+	// hardware queues in turn, and in a process that has created one or two other streams the tail's stream and the front
+	// end's came to share one - the tail then runs behind the next front end instead of beside it (-M wbfm 1.31 -> 1.47 ms;
+	// tools/queue_share_probe.py, profiles/r05_queue_share.txt).  A stream of another priority takes its queue from another pool.
+	{
+		int lo = 0, hi = 0;
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+		HIP_TRY(hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, lo));
+		h->tail_priority = -1;
+	}
 	h->tail_overlap = true;
 	{
 		// what mode_demod() can leave per stream and run: the decimated count (+1 per buffer behind a
@@ -587,6 +597,20 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 		h->tail_serial_asked = value != 0;
 		return 0;
 	}
+	if (!strcmp(name, "tail_priority")) {
+		// the tail's stream re-created with a priority of its own: -1 lowest, 0 default, 1 highest (a stream of another
+		// priority never shares a hardware queue with the front end's: LAB.md I.8)
+		if (value < -1 || value > 1) return -EINVAL;
+		HIP_TRY(sync_all(h));
+		int lo = 0, hi = 0;
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = the numerically greatest = lowest priority
+		hipStream_t q = nullptr;
+		HIP_TRY(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, value < 0 ? lo : value > 0 ? hi : 0));
+		if (h->tail_stream) hipStreamDestroy(h->tail_stream);
+		h->tail_stream = q;
+		h->tail_priority = (int)value;
+		return 0;
+	}
 	int *slot = option_slot(h, name);
 	if (!slot) return -ENOENT;
 	// every range check first: a refused value must leave the handle as it was
@@ -609,6 +633,7 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 {
 	if (!h || !name || !value) return -EINVAL;
 	if (!strcmp(name, "tail_serial")) { *value = h->tail_overlap ? 0 : 1; return 0; }
+	if (!strcmp(name, "tail_priority")) { *value = h->tail_priority; return 0; }
 	// read-only: where the write streams' buffers ended up (rtlfm_gpu_malloc_apart_ex) and what finding out cost
 	if (!strcmp(name, "ring_apart")) { *value = h->place.ring_apart; return 0; }
 	if (!strcmp(name, "poison")) { *value = rtl_debug::poison_on() ? 1 : 0; return 0; }  // RTLFM_POISON=1 (debug_poison.h)
