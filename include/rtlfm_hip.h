@@ -292,6 +292,10 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   lpr_ring             1 (default): that kernel's outputs leave through LDS in aligned 64-byte pieces; 0: 16 bytes per lane
  *   squelch_fused        1 (default): rms()'s sums per buffer inside the front end + k_squelch_apply; 0: emit mode + k_squelch_*
  *   adc_separate         1: dc_block_audio as sums / smooth / apply kernels (round 4) instead of sums + k_adc_smooth_apply
+ *   box_store            how k_boxcar_scan's outputs leave: -1 (default) by the launch's output size - beyond 192 MiB (what the
+ *                        256 MiB Infinity Cache cannot keep anyway) as whole 128-byte lines with non-temporal stores, the
+ *                        rest of a tile's last line waiting in LDS for the next tile; below, plain stores -, 0 / 1 = always
+ *                        plain / always lines
  *   deep_rest            1 (default): passes 6 ... 9, generic_fir and the demodulator behind k_fused<6>'s emit mode in ONE
  *                        kernel per step (k_deep_rest); 0: one staged kernel per stage
  *   apart_budget_gb      most device memory (GiB, default 16, never more than half of what is free) a placement

@@ -62,6 +62,12 @@ struct Params {
 	// buffer's decimated elements, both modulo 2^32 as rms() has them (src/rtl_fm.c:1093-1098) - zeroed by the host, added
 	// to with atomics (a buffer's outputs come from several waves); k_squelch_apply makes the decisions
 	uint32_t *sq_sums;
+	// how the outputs leave (round 5, tools/write_share_probe.hip): 0 = plain stores, whatever a tile has; 1 = whole 128-byte
+	// lines only, non-temporal - what is left of a tile's last line waits in LDS for the next tile.  For outputs that do
+	// not fit the 256 MiB Infinity Cache anyway (the launch writes more than that): the skeleton of this kernel with 816 /
+	// 1360 bytes per tile (/10, /6) takes 0.868 / 0.960 ms per 4 GiB with plain stores and 0.795 / 0.882 this way.
+	int store_lines_nt;
+	unsigned long long *stamps;  // RTLFM_BOX_PHASES builds (tools/box_phases.py): [waves][4] shader cycles by phase of the tile loop
 };
 
 // Per 8 KiB tile (round 1 walked every window: O(D/2) LDS gathers and dot products per output and
@@ -100,7 +106,8 @@ struct ScanLds {
 	// the tile's outputs waiting for their aligned 16-byte stores: int16 PCM, or (emit mode) packed IQ dwords
 	__host__ __device__ static int total(int out_cap, bool has_first, bool emit = false)
 	{
-		return pcm(has_first) + (emit ? out_cap + 8 : (out_cap + 16) / 2);
+		// + the piece of a line carried from tile to tile (store_lines_nt): fewer than 128 bytes
+		return pcm(has_first) + (emit ? out_cap + 8 + 32 : (out_cap + 16 + 64) / 2);
 	}
 };
 
@@ -155,6 +162,15 @@ __device__ __forceinline__ int row_at(int d)
 
 __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) + fused::as_s2(b)); }
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fused::as_u32(fused::as_s2(a) - fused::as_s2(b)); }
+
+// Measurement builds only (tools/build_variant.sh box_phases -DRTLFM_BOX_PHASES): every wave adds up the shader cycles
+// it spends in the four phases of the tile loop - 0 stage + flush + issue of the next tile's loads (incl. the wait for this
+// tile's), 1 the running sums, 2 scan + prefixes back to LDS, 3 the output loop and what follows it.
+#ifdef RTLFM_BOX_PHASES
+#define BOX_PHASE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_t[k] += now_ - ph_tp; ph_tp = now_; } while (0)
+#else
+#define BOX_PHASE(k) do { } while (0)
+#endif
 
 #ifndef RTLFM_BOXSCAN_WAVES_PER_SIMD
 #define RTLFM_BOXSCAN_WAVES_PER_SIMD 4
@@ -260,37 +276,64 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	};
 	load_tile(gt_begin);
 
-	// The PCM of a tile waits in LDS at index ((al + kb) & 7) + e, al = the row's element offset
-	// inside its 16-byte line: LDS group j of eight then is one aligned 16-byte piece of d_out and
-	// leaves as one dwordx4 per lane (all groups read first, then stored); the partial groups at
-	// both ends go element by element.
-	const int al = EMIT ? (int)(((uintptr_t)emit_base >> 2) & 3) : (int)(((uintptr_t)out_base >> 1) & 7);
-	int flush_n = 0, flush_kb = 0;
+	// The outputs of a tile wait in LDS and leave at the top of the next iteration (before the loads of the tile after it).
+	// LDS element i mirrors row element lbase + i, and lbase is chosen so that 16-byte pieces of the LDS area are aligned
+	// 16-byte pieces of the row: they leave as one dwordx4 per lane (all read first, then stored), the partial pieces at
+	// both ends element by element.  store_lines_nt: lbase is a line boundary of the row, a flush only stores whole
+	// 128-byte lines (non-temporal) and moves what is left - the beginning of a line the next tile will complete - to the
+	// front of the area; only a segment's first and last flush have partial lines (plain stores).
+	constexpr int ES = EMIT ? 4 : 2;        // bytes per element: packed IQ dwords / int16 PCM
+	constexpr int PE = 16 / ES, LE = 128 / ES;  // elements per 16-byte piece, per line
+	const bool lines_nt = p.store_lines_nt != 0;
+	const uint32_t row_el = (uint32_t)((EMIT ? (uintptr_t)emit_base : (uintptr_t)out_base) / ES);  // the row's address in elements (low bits)
+	int lbase = 0;      // the row element LDS element 0 stands for
+	int done = -1;      // row elements below this one are stored (-1: the segment has not begun)
+	int flush_end = 0;  // row elements below this one are in LDS
+	bool flush_last = false;
+	auto pcm_idx = [&](int e) -> int { return kb - lbase + e; };
+	auto store16 = [&](void *g, const uint4 v) {
+		typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+		const u32x4v vv = {v.x, v.y, v.z, v.w};
+		if (lines_nt) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(g), "v"(vv) : "memory");
+		else *reinterpret_cast<uint4 *>(g) = v;
+	};
 	auto flush = [&]() {
-		if (flush_n <= 0) return;
-		if (EMIT) {
-			// the same with 4-byte elements: LDS group j of four dwords is one aligned 16-byte piece of the row
-			const int a = (al + flush_kb) & 3, last = a + flush_n;
-			uint32_t *g32 = emit_base + ((ptrdiff_t)flush_kb - a);
-			const uint4 *e128 = reinterpret_cast<const uint4 *>(lds + pcm_at);
-			const int j0 = (a + 3) >> 2, j1 = last >> 2;
-			for (int j = j0 + lane; j < j1; j += 64) reinterpret_cast<uint4 *>(g32)[j] = e128[j];
-			const int lead_end = 4 * j0 < last ? 4 * j0 : last;
-			if (lane < 4 && a + lane < lead_end) g32[a + lane] = lds[pcm_at + a + lane];
-			const int t = 4 * j1 + (lane - 4);
-			if (lane >= 4 && lane < 8 && j1 >= j0 && t < last) g32[t] = lds[pcm_at + t];
-			return;
-		}
-		const int a = (al + flush_kb) & 7, last = a + flush_n;
-		int16_t *g16 = out_base + ((ptrdiff_t)flush_kb - a);
+		if (done < 0 || flush_end <= done) return;
+		uint8_t *rowb = EMIT ? reinterpret_cast<uint8_t *>(emit_base) : reinterpret_cast<uint8_t *>(out_base);
 		typedef uint4 __attribute__((may_alias)) u128_alias;  // the PCM is written as uint16
-		const u128_alias *pcm128 = reinterpret_cast<const u128_alias *>(lds + pcm_at);
-		const int j0 = (a + 7) >> 3, j1 = last >> 3;
-		for (int j = j0 + lane; j < j1; j += 64) reinterpret_cast<uint4 *>(g16)[j] = pcm128[j];
-		const int lead_end = 8 * j0 < last ? 8 * j0 : last;
-		if (lane < 8 && a + lane < lead_end) g16[a + lane] = (int16_t)pcm[a + lane];
-		const int t = 8 * j1 + (lane - 8);
-		if (lane >= 8 && lane < 16 && j1 >= j0 && t < last) g16[t] = (int16_t)pcm[t];
+		const u128_alias *l128 = reinterpret_cast<const u128_alias *>(lds + pcm_at);
+		const int gran = lines_nt && !flush_last ? LE : 1;
+		// [done, upto) leaves now; whole pieces [h, u) of it as 16-byte stores
+		const int upto = gran == 1 ? flush_end : flush_end - (int)((row_el + (uint32_t)flush_end) & (LE - 1));
+		const bool leaves = upto > done;  // (lines: a tile may complete no line - / 334 has 24 bytes per tile)
+		if (leaves) {
+			int h = done + (int)((0u - (row_el + (uint32_t)done)) & (PE - 1));
+			if (h > upto) h = upto;
+			const int u = h + ((upto - h) & ~(PE - 1));
+			const int j0 = (h - lbase) / PE, j1 = (u - lbase) / PE;  // lbase is a piece boundary
+			for (int j = j0 + lane; j < j1; j += 64) store16(rowb + ((size_t)lbase + (size_t)j * PE) * ES, l128[j]);
+			// the partial pieces: fewer than PE elements each
+			if (lane < PE && done + lane < h) {
+				if (EMIT) reinterpret_cast<uint32_t *>(rowb)[done + lane] = lds[pcm_at + done - lbase + lane];
+				else reinterpret_cast<int16_t *>(rowb)[done + lane] = (int16_t)pcm[done - lbase + lane];
+			}
+			if (lane >= PE && lane < 2 * PE && u + (lane - PE) < upto) {
+				const int k = u + (lane - PE);
+				if (EMIT) reinterpret_cast<uint32_t *>(rowb)[k] = lds[pcm_at + k - lbase];
+				else reinterpret_cast<int16_t *>(rowb)[k] = (int16_t)pcm[k - lbase];
+			}
+			done = upto;
+		}
+		if (gran > 1 && leaves) {  // done is a line boundary now
+			// the beginning of the next line to the front: at most eight pieces
+			const int pieces = (flush_end - done + PE - 1) / PE, from = (done - lbase) / PE;
+			uint4 keep = make_uint4(0, 0, 0, 0);
+			if (lane < pieces) keep = l128[from + lane];
+			__builtin_amdgcn_wave_barrier();
+			if (lane < pieces) *reinterpret_cast<uint4 *>(lds + pcm_at + 4 * lane) = keep;
+			__builtin_amdgcn_wave_barrier();
+			lbase = done;
+		}
 	};
 
 	// (RDC) the buffer tile gt's first sample lies in and that sample's place inside it, carried from tile to tile
@@ -312,6 +355,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		sq_b = (int)bb0 - 1;
 	}
 	fused::ProgressPrio prio(gt_end - gt_begin, 0);
+#ifdef RTLFM_BOX_PHASES
+	unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_tp = __builtin_amdgcn_s_memtime();
+#endif
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		prio.at(gt - gt_begin);
 		const bool emit = gt >= gt_first;
@@ -370,7 +416,14 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			__builtin_amdgcn_wave_barrier();
 		}
 		flush();
+		// where this tile's outputs wait in LDS
+		if (!emit) lbase = kb;  // the warm-up tile: nothing leaves
+		else if (done < 0) {    // the segment's first tile with outputs
+			done = kb;
+			lbase = kb - (int)((row_el + (uint32_t)kb) & (uint32_t)((lines_nt ? LE : PE) - 1));
+		} else if (!lines_nt) lbase = kb - (int)((row_el + (uint32_t)kb) & (uint32_t)(PE - 1));  // (everything before kb has left)
 		load_tile(gt + 1);  // unconditional: behind the segment's last tile it reads the dummy tile (fused_kernel.h)
+		BOX_PHASE(0);
 
 		// ---- 2. the lane's running sum = exclusive prefix before each of its dwords
 		uint32_t pk[32];
@@ -391,6 +444,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 		}
 		chain_settle(accI, accQ);
+		BOX_PHASE(1);
 		// ---- 3. exclusive scan of the lane totals, prefixes back to the lane's row
 		const int incI = wave_inclusive_scan(accI), incQ = wave_inclusive_scan(accQ);
 		const uint32_t off = __builtin_amdgcn_perm((uint32_t)(incQ - accQ), (uint32_t)(incI - accI), 0x05040100u);
@@ -405,6 +459,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		}
 		if (lane == 0) lds[ScanLds::rows + row_at(2048)] = tot;  // P2[2048]
 		__builtin_amdgcn_wave_barrier();
+		BOX_PHASE(2);
 
 		// ---- 4. lane l takes the R consecutive outputs e = l R .. l R + R - 1: the window's other end
 		// P(n_{e-1}) and the previous output are the lane's own values of the iteration before, and for
@@ -465,7 +520,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			const uint32_t z = pk_sub16(curP, prevP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
 			if (EMIT) {
 				if (e < Et) {
-					lds[pcm_at + ((al + kb) & 3) + e] = z;
+					lds[pcm_at + pcm_idx(e)] = z;
 					if (e == Et - 1) { lds[ScanLds::scratch] = curP; lds[ScanLds::scratch + 1] = z; }
 				}
 			} else if (e < Et) {
@@ -485,7 +540,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				else if (V == 2) v = fast_atan2_q14(cj, cr);
 				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
 				else v = lut_atan2_q14_direct(cj, cr, nodes);
-				pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v;
+				pcm[pcm_idx(e)] = (uint16_t)(int16_t)v;
 				if (e == Et - 1) {  // the last complete output: its boundary and its value
 					lds[ScanLds::scratch] = curP;
 					lds[ScanLds::scratch + 1] = z;
@@ -530,7 +585,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 						const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
 						const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
 						const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
-						pcm[((al + kb) & 7) + e] = (uint16_t)(int16_t)v0;
+						pcm[pcm_idx(e)] = (uint16_t)(int16_t)v0;
 					}
 				}
 				do { xs += N0; sq_b++; } while (xs < lim);  // wave-uniform
@@ -546,11 +601,14 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			carry_r = part.i; carry_j = part.q;
 		}
 		__builtin_amdgcn_wave_barrier();
-		flush_n = emit ? Et : 0;
-		flush_kb = kb;
+		if (emit) { flush_end = kb + Et; flush_last = gt + 1 == gt_end; }
 		kb += Et;
 		ph = ph_next;
+		BOX_PHASE(3);
 	}
+#ifdef RTLFM_BOX_PHASES
+	if (p.stamps && lane == 0) for (int k = 0; k < 4; k++) p.stamps[(size_t)wave * 4 + k] = ph_t[k];
+#endif
 	flush();
 	if (writes_state && lane == 0) {
 		if constexpr (RDC) {  // dc_block_raw_filter keeps the averages of the buffer it saw last (src/rtl_fm.c:1062-1063)
@@ -672,8 +730,21 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
 	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;
+#ifdef RTLFM_BOX_PHASES
+	if (ws.want_stamps) {
+		if (ws.stamp_waves < waves) { if (ws.stamps) hipFree(ws.stamps); ws.stamps = nullptr; ws.stamp_waves = 0; if (hipMalloc(&ws.stamps, (size_t)waves * 32 * 2) != hipSuccess) return -ENOMEM; ws.stamp_waves = waves; }
+		p.stamps = ws.stamps + (size_t)(ws.stamp_seq & 1) * ws.stamp_waves * 4;
+		ws.stamp_seq++;
+		ws.stamp_last = waves;
+	}
+#endif
 	const bool std_fm = c.custom_atan == RTLFM_ATAN_STD && c.mode == RTLFM_MODE_FM;
 	p.has_first = (p.D & 1) ? 1 : 0;
+	{
+		// outputs that cannot stay in the Infinity Cache anyway leave as whole lines, non-temporal (Params::store_lines_nt)
+		const double out_bytes = (double)nstreams * (double)(run_bytes / 2) / p.D * (emit_iq ? 4.0 : 2.0);
+		p.store_lines_nt = ws.box_store >= 0 ? (ws.box_store ? 1 : 0) : (out_bytes > 192.0 * 1048576.0 ? 1 : 0);
+	}
 	p.R = (p.q4096 + 1 + 63) / 64;
 	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0, emit_iq != nullptr) * 4;
 	const bool fast_fm = c.custom_atan == RTLFM_ATAN_FAST && c.mode == RTLFM_MODE_FM;

@@ -1272,6 +1272,7 @@ struct Workspace {
 	bool plan_by_caller = false;                  // fused_waves / fused_min_tiles were set: the planner's own rules of thumb stand back
 	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
 	int gss_x10 = 0;                              // guided segment lengths: remaining / (gss R) per round, x10 (0 = equal segments)
+	int box_store = -1;                           // k_boxcar_scan's output stores: -1 by the launch's output size, 0 plain, 1 whole lines + nt
 	int debug = 0;                                // fused_debug: 2 = clock stamps per launch (+16: only on timing_read), 4 = reload a cached tile, 32 = stamp HW_ID / XCC_ID instead of the shader clock
 	void release()
 	{

@@ -685,6 +685,15 @@ def test_fused_boxcar_vs_oracle_and_staged(oracle_lib, D, atan, offs, L, nb, ns)
     for s in range(ns):
         assert np.array_equal(fo2[s], fo[s])
         assert gu.state_dict(fs2[s], False) == gu.state_dict(fs_[s], False)
+    # box_store = 1: the outputs leave as whole 128-byte lines (non-temporal), the rest of a tile's last line waiting in
+    # LDS for the next tile - what launches that write more than the Infinity Cache holds do by themselves (round 5)
+    for splits, opts in ((None, dict(box_store=1)), ([(0, 1), (1, nb)], dict(box_store=1, fused_tiles_per_seg=3)),
+                         (None, dict(box_store=1, fused_tiles_per_seg=1)), (None, dict(box_store=0))):
+        fo3, fs3, used3 = gpu_run(cfg, iq, path=2, splits=splits, options=opts)
+        assert used3 == 2
+        for s in range(ns):
+            assert np.array_equal(fo3[s], fo[s]), (opts, splits, s)
+            assert gu.state_dict(fs3[s], False) == gu.state_dict(fs_[s], False)
 
 
 @pytest.mark.parametrize("D", [6, 10, 13])
@@ -1738,6 +1747,8 @@ def test_boxcar_front_end_emit_mode(oracle_lib, ov, sig, L, nb, ns):
     # takes rms()'s sums itself and k_squelch_apply writes the zeros (round 5; buffers of 16384 bytes and more)
     for path, splits, opts in ((0, None, None), (0, [(0, 1), (1, nb)], None), (0, None, dict(squelch_fused=0)),
                                (0, [(0, 1), (1, nb)], dict(squelch_fused=0, fused_tiles_per_seg=3)), (0, None, dict(fused_tiles_per_seg=1)),
+                               (0, None, dict(box_store=1)), (0, [(0, 1), (1, nb)], dict(box_store=1, squelch_fused=0, fused_tiles_per_seg=3)),
+                               (0, None, dict(box_store=1, squelch_fused=0, fused_tiles_per_seg=1)),
                                (1, None, None)):
         outs, sts, used = gpu_run(cfg, iq, path=path, splits=splits, options=opts)
         assert used == (1 if path == 1 else 2), (ov, path, used)
