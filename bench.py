@@ -616,7 +616,7 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
     class Reuse:
         """the resident bytes through the default chain under another (streams, buffers) shape"""
 
-        def __init__(self, S, nb, per_stream, block_len=None, colocated=False):
+        def __init__(self, S, nb, per_stream, block_len=None, colocated=False, two_outputs=False):
             self.a = a
             self.S, self.nb, self.per_stream = S, nb, per_stream
             self.L = block_len or L
@@ -651,24 +651,37 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
             else:
                 self.o = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank, 64)
             self.output_apart = self.o.apart
+            # two_outputs: the launches alternate between two output buffers - what a consumer that double-buffers sees.  ONE
+            # 256 MiB output rewritten by every launch stays in the 256 MiB Infinity Cache from launch to launch (LAB.md I.12)
+            self.o2 = ApartRows(S, cap, job.iq.data_ptr(), job.iq.numel(), local_rank, 64) if two_outputs else None
+            if self.o2 is not None:
+                self.output_apart = bool(self.o.apart and self.o2.apart)
+            self.flip = 0
             self.n = torch.zeros(S, dtype=torch.int32, device=dev)
             self.samples = S * nb * self.L // 2
             self.alg_bytes_per_sample = job.alg_bytes_per_sample
 
         def step(self):
-            self.g.run_device(self.iq_ptr, self.per_stream, self.nb, self.o.data_ptr(), self.o.stride(0), self.n.data_ptr())
+            o = self.o
+            if self.o2 is not None:
+                self.flip ^= 1
+                o = self.o2 if self.flip else self.o
+            self.g.run_device(self.iq_ptr, self.per_stream, self.nb, o.data_ptr(), o.stride(0), self.n.data_ptr())
 
         def sync(self):
             self.g.sync()
 
         def describe(self):
-            return (f"{self.S} streams/GPU x {self.nb} buffer(s) x {self.L} B per launch, the default workload's chain and bytes")
+            return (f"{self.S} streams/GPU x {self.nb} buffer(s) x {self.L} B per launch, the default workload's chain and bytes"
+                    + (", two output buffers in turn" if self.o2 is not None else ""))
 
         def kernel_name(self):
             return job.kernel_name()
 
         def close(self):
             self.g.close(); self.o.free()
+            if self.o2 is not None:
+                self.o2.free()
 
     if a.workload == "ns4096" and not a.boxcar and total == 4096 * 4 * L:
         # ns4096_colocated: the headline launch with its output where input and output SHARE a class of the HBM (what a
@@ -676,8 +689,9 @@ def also_legs(a, job, dev, local_rank, rank, ceiling, valu_insts=None):
         # c2_16k: configs[1] on the reference's own 16384-byte buffers (src/rtl_fm.c:1605)
         for name, S, nb, per, bl, colo in (("ns4096x1", 4096, 1, total // 4096, L, False), ("c2", 256, 64, total // 256, L, False),
                                            ("ns4096_colocated", 4096, 4, total // 4096, L, True),
+                                           ("ns4096_two_outputs", 4096, 4, total // 4096, L, False),
                                            ("c2_16k", 256, total // 256 // 16384, total // 256, 16384, False)):
-            r = Reuse(S, nb, per, bl, colo)
+            r = Reuse(S, nb, per, bl, colo, two_outputs=name == "ns4096_two_outputs")
             launch_ms, step_ms = _timed(r, 400 if nb == 1 else 100, 4 * K if nb == 1 else K)
             e = _leg_entry(name, r, launch_ms, step_ms, 4 * K if nb == 1 else K, ceiling)
             r.g.clock_probe(True); r.step(); st = r.g.clock_stamps(); r.g.clock_probe(False); r.sync()

@@ -61,6 +61,14 @@ constexpr int kMaxSegList = 128;
 #else
 #define RTLFM_MARK(name) do { } while (0)
 #endif
+// Measurement builds only (tools/build_variant.sh fused_phases -DRTLFM_FUSED_PHASES, tools/box_phases.py): with clock stamps on,
+// a wave leaves the shader cycles it spent per phase of the tile loop - 0 until the tile has arrived and is staged, 1 pass 0,
+// 2 the other passes (+ FIR), 3 discriminator and the rest - in place of its start / end stamps.
+#ifdef RTLFM_FUSED_PHASES
+#define FUSED_PHASE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_t[k] += now_ - ph_tp; ph_tp = now_; } while (0)
+#else
+#define FUSED_PHASE(k) do { } while (0)
+#endif
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
 
@@ -502,6 +510,7 @@ struct AtanNodesLds {
 	__device__ __forceinline__ double operator()(int i) const { return t[i]; }
 };
 
+
 #ifndef RTLFM_DPP_EXCHANGE
 #define RTLFM_DPP_EXCHANGE 1  // lane-to-lane hand-offs of the first passes and the discriminator through DPP + SGPR carries instead of LDS
 #endif
@@ -747,6 +756,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 	};
 
 	ProgressPrio prio(gt_end - gt_begin, __builtin_amdgcn_readfirstlane(p.debug & 128));  // 128: an audio tail follows
+#ifdef RTLFM_FUSED_PHASES
+	unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_tp = __builtin_amdgcn_s_memtime();
+#endif
 	for (int gt = gt_begin; gt < gt_end; gt++) {
 		const bool more = gt + 1 < gt_end;
 		const int tib = gt % tpb;
@@ -762,6 +774,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		const bool archive = last && writes_state && lane == last_lane;
 
 		RTLFM_MARK("tile_begin");
+		FUSED_PHASE(3);  // (what follows the discriminator: the hold of the PCM, the loop's own bookkeeping)
 		prio.at(gt - gt_begin);
 		if constexpr (RDC) {
 			if (bs || gt == gt_begin) {
@@ -819,6 +832,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 				if (k == 7) last = v;
 			}
 			__builtin_amdgcn_wave_barrier();
+			FUSED_PHASE(0);  // the tile has arrived and is staged
 			if constexpr (PT) {
 				const int nv = tile_bytes >> 4;  // valid 16-byte chunks: a multiple of 32
 				if (nv < 512) {
@@ -1036,6 +1050,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 
 		const int lz = lane;
 		RTLFM_MARK("pass0_special_done");
+		FUSED_PHASE(1);
 		// ------------------------------------------------------------ passes 1.. ----
 		uint32_t Z[CZ];  // output of the last pass
 		if constexpr (P == 1) {
@@ -1093,6 +1108,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 
 		RTLFM_MARK("passes_done");
+		FUSED_PHASE(2);
 		// --------------------------------------------------------- generic_fir ----
 		uint32_t V[CZ];  // what fm_demod sees
 		if constexpr (FIR9) {
@@ -1216,6 +1232,7 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 		(void)q0;
 		RTLFM_MARK("demod_done");
+		FUSED_PHASE(3);
 		if (emit && (!PT || lane < nlanes)) {
 			held_dst = PT ? out_base + (size_t)(gt / tpb) * out_per_buffer + (size_t)tib * out_per_tile + lane * CZ
 			              : out_base + (size_t)gt * out_per_tile + lane * CZ;
@@ -1239,6 +1256,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 		}
 		p.stamps[(size_t)wave * 4 + 0] = st_clk; p.stamps[(size_t)wave * 4 + 1] = e_clk;
 		p.stamps[(size_t)wave * 4 + 2] = st_rt; p.stamps[(size_t)wave * 4 + 3] = e_rt;
+#ifdef RTLFM_FUSED_PHASES
+		for (int k = 0; k < 4; k++) p.stamps[(size_t)wave * 4 + k] = ph_t[k];
+#endif
 	}
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where a wave of k_boxcar_scan spends its cycles, by phase of the tile loop (a build with -DRTLFM_BOX_PHASES:
-tools/build_variant.sh box_phases -DRTLFM_BOX_PHASES).  256 streams x 64 x 262144 B, boxcar / D, -A std | fast."""
+"""Where a wave of the front ends spends its cycles, by phase of the tile loop (a build with both stamp sets:
+tools/build_variant.sh phases -DRTLFM_BOX_PHASES -DRTLFM_FUSED_PHASES).  256 streams x 64 x 262144 B: k_fused with 4 / 5 / 6
+fifth_order passes, k_boxcar_scan / D with -A std | fast."""
 import os
 import sys
 
@@ -19,11 +20,14 @@ def main():
     dev = torch.device("cuda:0")
     S, NB, L = 256, 64, 262144
     iq = synth.fm_iq_u8_torch(S, NB * L // 2, dev, fs=2.4e6, dev_hz=75e3, amplitude=40.0)
-    lib = os.path.join(ROOT, "build_ablate", "lib_box_phases.so")
+    lib = os.path.join(ROOT, "build_ablate", "lib_phases.so")
     names = ("stage + flush + loads", "running sums", "scan + prefixes to LDS", "output loop + rest")
-    for D in (84, 10, 6):
-        for atan in (ATAN_STD, ATAN_FAST):
-            cfg = RtlfmCfg.default(downsample=D, downsample_passes=0, rate_out=int(2.4e6 / D), custom_atan=atan, block_len=L, max_blocks=NB)
+    shapes = [(1 << P, P, ATAN_STD, fir) for P, fir in ((4, 0), (5, 0), (6, 9))] + [(D, 0, atan, 0) for D in (84, 10, 6) for atan in (ATAN_STD, ATAN_FAST)]
+    fnames = ("tile arrived + staged", "pass 0 (MFMA)", "other passes (+ FIR)", "discriminator + rest")
+    if True:
+        for D, P, atan, fir in shapes:
+            cfg = RtlfmCfg.default(downsample=D, downsample_passes=P, rate_out=int(2.4e6 / D), custom_atan=atan, block_len=L, max_blocks=NB, comp_fir_size=fir)
+            nm = fnames if P else names
             with GpuDemod(cfg, S, 0, lib_path=lib) as g:
                 cap = g.result_cap(NB)
                 out = torch.empty((S, cap), dtype=torch.int16, device=dev)
@@ -43,9 +47,9 @@ def main():
                 tiles = S * NB * L / 8192
                 tot = st.sum(axis=0).astype(np.float64)
                 per_tile = tot / (tiles * (1 + 1.0 / 16))  # + warm-up tiles, roughly
-                print(f"/{D} -A {'std' if atan == ATAN_STD else 'fast'}: {ms / cnt:.4f} ms per launch (unstamped), {len(st)} waves; wave cycles per tile by phase:")
+                print(f"{'fifth_order x ' + str(P) + (' + FIR9' if fir else '') if P else 'boxcar'} /{D} -A {'std' if atan == ATAN_STD else 'fast'}: {ms / cnt:.4f} ms per launch (unstamped), {len(st)} waves; wave cycles per tile by phase:")
                 for k in range(4):
-                    print(f"    {names[k]:26s} {per_tile[k]:8.0f}  ({100 * tot[k] / tot.sum():4.1f} %)")
+                    print(f"    {nm[k]:26s} {per_tile[k]:8.0f}  ({100 * tot[k] / tot.sum():4.1f} %)")
                 print(f"    {'sum':26s} {per_tile.sum():8.0f}", flush=True)
 
 
