@@ -57,7 +57,8 @@ def main():
         with GpuDemod(cfg, S, 0) as g:
             cap = g.result_cap(NB)
             far, apart = C.c_void_p(), C.c_int()
-            assert lib.rtlfm_gpu_malloc_apart(0, S * cap * 2, iq.data_ptr(), iq.numel(), C.byref(far), C.byref(apart)) == 0
+            # (a process that has allocated and freed as much as this one may need to look further than the library's own 16 GiB)
+            assert lib.rtlfm_gpu_malloc_apart_ex(0, S * cap * 2, iq.data_ptr(), iq.numel(), 96 << 30, C.byref(far), C.byref(apart), None, None) == 0
             n = torch.zeros(S, dtype=torch.int32, device=dev)
             for _ in range(30):
                 g.run_device(iq.data_ptr(), iq.stride(0), NB, far.value, cap, n.data_ptr())
