@@ -814,11 +814,12 @@ class FmJob:
             # (r04: a first search walked 152 GB in 4.7 s and found nothing; with the input moved the first candidate was apart.
             # Round 5: the search itself is bounded - eight candidates of different sizes, 16 GiB held at most)
             tries = []
-            # the default workload (a fresh process) searches within the library's bound; the `also` legs run in a process that
-            # already holds tens of GB, where a run of one class can be longer than 16 GB: they may walk further
-            for attempt, budget_gb in enumerate((16, 16, 16) if not getattr(a, "crowded", False) else (16, 64, 150)):
+            # (round 5's last sessions met a box where 15.6 GB of candidates all shared the input's class, twice in a row: the
+            # harness, which has the GPU to itself, lets the first search walk up to 64 GiB - `walked_mb` says what it took -
+            # before it moves anything; the library's own default for a handle's buffers stays 16 GiB)
+            for attempt, budget_gb in enumerate((64, 64, 150)):
                 self.out = ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank, budget_gb)
-                tries.append({"apart": self.out.apart, "search_ms": self.out.search_ms, "walked_mb": self.out.walked_mb})
+                tries.append({"apart": self.out.apart, "search_ms": self.out.search_ms, "walked_mb": self.out.walked_mb, "budget_gb": budget_gb})
                 if self.out.apart or attempt == 2 or a.pmc_child:
                     break
                 self.out.free()
