@@ -125,6 +125,11 @@ int rtlpower_gpu_release_to(rtlpower_gpu *h, void *consumer_stream);
  * tests, the results are the same integers; "scan_frames" = 0 likewise for reads that hold several frames (the general
  * in-LDS kernel instead of k_power_scan_frames); "dec_fast" = 0 likewise for decimated scans (src/rtl_power.c:466-480, :671-691:
  * one launch per fifth_order pass and the general in-LDS kernel instead of k_power_downsample_iq + k_power_scan_frames<13, true>).
+ * "staged_pipe": the batches of a fine-bin scan (one frame per read beyond 16384 points) as a two-stream pipeline - the in-LDS
+ * transform on the handle's stream, the comb gather of the next batch and the passes over HBM of the one before beside it on
+ * a stream of the handle's own; the scan is complete on the handle's stream either way.  0 (default): never - one batch after the
+ * other; 1: from 2^18 bins on and for scans of several batches; 2: wherever it applies.  (Measured: the kernels overlap, the
+ * scan gains 4-5 % at 2^19 .. 2^21 bins in two sessions of three and loses 1-3 % at 2^15 .. 2^17.)  "staged_batch" = n > 0: at most n reads per batch (tests).
  * -ENOENT for an unknown name.  get_option reads them back, and "last_kernel" (read-only): which transform the last
  * scan took, one of RTLPOWER_KERNEL_*. */
 int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long value);

@@ -57,6 +57,17 @@ struct rtlpower_gpu {
 	bool attr_frames16 = false;
 	int last_kernel = 0;  // option "last_kernel" (read-only): which transform kernel the last scan took (RTLPOWER_KERNEL_*)
 	int staged_fast = 1;  // option "staged_fast": 0 = the general kernels also where the fast ones apply (A/B, tests)
+	// Fine bins (one frame per read beyond 16384 points), round 5: the batches of a scan as a two-stream pipeline.  The
+	// transform in LDS (k_power_scan_big<14, true>: issue-bound, 71 registers, one workgroup per CU) runs on the handle's
+	// stream; what only moves bytes - the comb gather of the NEXT batch, the passes over HBM and the accumulation of the
+	// one BEFORE - runs beside it on `aux` (their waves fit next to the transform's on every CU).  Two sets of work buffers.
+	int staged_pipe = 0;  // option "staged_pipe": 0 (default) = one batch after the other on one stream, 1 = the pipeline from 2^18 bins on, 2 = wherever it applies
+	int staged_batch = 0; // option "staged_batch": reads per batch, 0 = by the work buffer's size (tests: several batches of a small scan)
+	struct Pipe {
+		hipStream_t aux = nullptr;
+		hipEvent_t start = nullptr, prep[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr}, done = nullptr;
+	} pipe;
+	bool work_two = false;  // d_work / d_ave / d_tbuf / d_part hold two batches
 	size_t work_reads = 0;                 // reads the work buffer holds per stream
 	bool attr_lds = false;
 	bool want_stamps = false;              // rtlpower_gpu_clock_probe
@@ -339,6 +350,10 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 	void *ptrs[] = {h->d_window, h->d_window16, h->d_tw, h->d_avg, h->d_samples, h->d_decA, h->d_decB, h->d_one, h->d_stamps, h->d_work, h->d_ave, h->d_window16T, h->d_tbuf, h->d_part, h->d_dec32};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
+	if (h->pipe.aux) (void)hipStreamSynchronize(h->pipe.aux);
+	for (hipEvent_t e : {h->pipe.start, h->pipe.prep[0], h->pipe.prep[1], h->pipe.scanned[0], h->pipe.scanned[1], h->pipe.done})
+		if (e) (void)hipEventDestroy(e);
+	if (h->pipe.aux) (void)hipStreamDestroy(h->pipe.aux);
 	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 	delete h;
 	return 0;
@@ -408,6 +423,16 @@ extern "C" int rtlpower_gpu_set_option(rtlpower_gpu *h, const char *name, long v
 		h->dec_fast = value != 0;
 		return 0;
 	}
+	if (!strcmp(name, "staged_pipe")) {
+		if (value < 0 || value > 2) return -EINVAL;
+		h->staged_pipe = (int)value;
+		return 0;
+	}
+	if (!strcmp(name, "staged_batch")) {
+		if (value < 0 || value > (1 << 20)) return -EINVAL;
+		h->staged_batch = (int)value;
+		return 0;
+	}
 	if (!strcmp(name, "scan_frames")) {
 		h->scan_frames = value != 0;
 		return 0;
@@ -421,6 +446,8 @@ extern "C" int rtlpower_gpu_get_option(rtlpower_gpu *h, const char *name, long *
 	if (!strcmp(name, "groups")) { *value = h->groups; return 0; }
 	if (!strcmp(name, "staged_fast")) { *value = h->staged_fast; return 0; }
 	if (!strcmp(name, "dec_fast")) { *value = h->dec_fast; return 0; }
+	if (!strcmp(name, "staged_pipe")) { *value = h->staged_pipe; return 0; }
+	if (!strcmp(name, "staged_batch")) { *value = h->staged_batch; return 0; }
 	if (!strcmp(name, "scan_frames")) { *value = h->scan_frames; return 0; }
 	if (!strcmp(name, "last_kernel")) { *value = h->last_kernel; return 0; }
 	return -ENOENT;
@@ -616,21 +643,35 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		// bin_e 15 .. 21 (or frames beyond one workgroup's LDS): the same stages over a work buffer in HBM,
 		// a batch of reads at a time (at most ~1 GiB of work buffer)
 		const size_t M = (size_t)h->chunks * h->N;
-		size_t batch = ((size_t)1 << 28) / ((size_t)S * M);
+		const bool fast_shape = c.bin_e > 14 && !dec && h->chunks == 1;
+		// the pipeline holds two batches: half the points each, and at least four batches where each still fills the GPU
+		// (measured, profiles/r05_power_big_pipe.txt: 2^19 .. 2^21 bins - two passes over HBM per batch - 4-5 % faster in two
+		// sessions and 6 % slower in a third; 2^15 .. 2^17 1-3 % SLOWER: the kernels do run at the same time, but beside the
+		// transform the accumulating pass takes three times as long as alone and becomes the longer chain; a scan of one batch
+		// only pays for the events.  Not the default.)
+		const bool two = fast_shape && h->staged_fast && (h->staged_pipe == 2 || (h->staged_pipe == 1 && c.bin_e >= 18));
+		size_t batch = ((size_t)1 << (two ? 27 : 28)) / ((size_t)S * M);
 		if (batch < 1) batch = 1;
 		if (batch > (size_t)nreads) batch = (size_t)nreads;
-		if (h->work_reads < batch) {
+		if (two && ((size_t)nreads + batch - 1) / batch < 4) {
+			const size_t want = nreads < 4 ? (size_t)nreads : 4, b2 = ((size_t)nreads + want - 1) / want;
+			if (((size_t)S * b2) << (c.bin_e - 14) >= 2048) batch = b2;  // (eight combs per CU and batch: 512 made a one-stream scan of 2^21 bins 1.6 x slower)
+		}
+		if (h->staged_batch > 0 && (size_t)h->staged_batch < batch) batch = (size_t)h->staged_batch;
+		if (h->work_reads < batch || (two && !h->work_two)) {
 			HIP_TRY(hipStreamSynchronize(q));
+			if (h->pipe.aux) HIP_TRY(hipStreamSynchronize(h->pipe.aux));
 			if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_ave); h->d_work = nullptr; h->d_ave = nullptr; }
 			if (h->d_tbuf) { (void)hipFree(h->d_tbuf); (void)hipFree(h->d_part); h->d_tbuf = nullptr; h->d_part = nullptr; }
-			h->work_reads = 0;
-			HIP_TRY(hipMalloc(&h->d_work, (size_t)S * batch * M * sizeof(uint32_t)));
-			HIP_TRY(hipMalloc(&h->d_ave, (size_t)S * batch * sizeof(int2)));
-			if (c.bin_e > 14 && !dec && h->chunks == 1) {
-				HIP_TRY(hipMalloc(&h->d_tbuf, (size_t)S * batch * M * 2));
-				HIP_TRY(hipMalloc(&h->d_part, (size_t)S * batch * (M / 8192) * sizeof(int2)));
+			h->work_reads = 0; h->work_two = false;
+			const size_t sets = two ? 2 : 1;
+			HIP_TRY(hipMalloc(&h->d_work, sets * S * batch * M * sizeof(uint32_t)));
+			HIP_TRY(hipMalloc(&h->d_ave, sets * S * batch * sizeof(int2)));
+			if (fast_shape) {
+				HIP_TRY(hipMalloc(&h->d_tbuf, sets * S * batch * M * 2));
+				HIP_TRY(hipMalloc(&h->d_part, sets * S * batch * (M / 8192) * sizeof(int2)));
 			}
-			h->work_reads = batch;
+			h->work_reads = batch; h->work_two = two;
 		}
 		// rtl_power's own fine-bin shape - an undecimated read is exactly one frame - takes the kernels written for it
 		const bool fast = h->staged_fast && h->d_tbuf && c.bin_e > 14 && !dec && h->chunks == 1 && h->len_dec == 2 * h->N &&
@@ -653,26 +694,64 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 			else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
 			HIP_TRY(hipEventRecord(ev.first, q));
 		}
-		for (int r0 = 0; r0 < nreads; r0 += (int)batch) {
+		const bool piped = fast && two && h->work_two && (h->staged_pipe == 2 || (size_t)nreads > batch);
+		if (piped && !h->pipe.aux) {
+			int lo = 0, hi = 0;
+			HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+			HIP_TRY(hipStreamCreateWithPriority(&h->pipe.aux, hipStreamNonBlocking, lo));  // (a priority of its own: a hardware queue of its own)
+			for (hipEvent_t *e : {&h->pipe.start, &h->pipe.prep[0], &h->pipe.prep[1], &h->pipe.scanned[0], &h->pipe.scanned[1], &h->pipe.done})
+				HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+		}
+		hipStream_t qa = piped ? h->pipe.aux : q;  // where the byte-moving kernels go
+		// the sets of work buffers (piped: batch k uses set k & 1; the handle's allocation holds work_reads reads per set)
+		const size_t set_work = (size_t)S * h->work_reads * M, set_ave = (size_t)S * h->work_reads;
+		const size_t set_tbuf = set_work * 2, set_part = (size_t)S * h->work_reads * (M / 8192);
+		auto comb_of = [&](int r0, int nb, int set) {  // the comb gather + remove_dc's averages of one batch, on qa
+			const size_t frames = (size_t)S * nb, tiles = frames << (c.bin_e - 13);
+			k_power_comb_bytes<<<grid_for(tiles, 1, 256 * 32), 256, 0, qa>>>(d_iq + (size_t)r0 * c.buf_len, stream_stride, nb, (int)c.buf_len, c.bin_e, tiles,
+			                                                                   h->d_tbuf + set * set_tbuf, h->d_part + set * set_part);
+			k_power_dc_fin<<<grid_for(frames, 64), 64, 0, qa>>>(h->d_part + set * set_part, 1 << (c.bin_e - 13), h->len_dec, frames, h->d_ave + set * set_ave);
+		};
+		if (piped && nreads > 0) {
+			// aux starts behind what the caller has queued on q (the producer of d_iq, an earlier scan's accumulation)
+			HIP_TRY(hipEventRecord(h->pipe.start, q));
+			HIP_TRY(hipStreamWaitEvent(qa, h->pipe.start, 0));
+			comb_of(0, nreads < (int)batch ? nreads : (int)batch, 0);
+			HIP_TRY(hipEventRecord(h->pipe.prep[0], qa));
+		}
+		int kb = 0;
+		for (int r0 = 0; r0 < nreads; r0 += (int)batch, kb++) {
 			const int nb = nreads - r0 < (int)batch ? nreads - r0 : (int)batch;
+			const int set = piped ? (kb & 1) : 0;
 			StagedParams sp{};
 			sp.iq8 = dec ? nullptr : d_iq + (size_t)r0 * c.buf_len; sp.stride8 = stream_stride;
 			sp.dec = dec ? dec + (size_t)r0 * drs : nullptr; sp.dec_stream_stride = dss; sp.dec_read_stride = drs; sp.dec_elems = h->dec_elems;
 			sp.nreads = nb; sp.buf_len = (int)c.buf_len; sp.len_dec = h->len_dec; sp.bin_e = c.bin_e; sp.chunks = h->chunks;
 			sp.ds = c.downsample; sp.peak_hold = c.peak_hold; sp.window = h->d_window; sp.tw = h->d_tw;
-			sp.ave = h->d_ave; sp.work = h->d_work; sp.avg = h->d_avg; sp.samples = h->d_samples; sp.nstreams = S;
+			sp.ave = h->d_ave + set * set_ave; sp.work = h->d_work + set * set_work; sp.avg = h->d_avg; sp.samples = h->d_samples; sp.nstreams = S;
 			const size_t frames = (size_t)S * nb * h->chunks;
 			if (fast) {
-				const uint8_t *src = d_iq + (size_t)r0 * c.buf_len;
-				const size_t tiles = frames << (c.bin_e - 13);
-				k_power_comb_bytes<<<grid_for(tiles, 1, 256 * 32), 256, 0, q>>>(src, stream_stride, nb, (int)c.buf_len, c.bin_e, tiles, h->d_tbuf, h->d_part);
-				k_power_dc_fin<<<grid_for(frames, 64), 64, 0, q>>>(h->d_part, 1 << (c.bin_e - 13), h->len_dec, frames, h->d_ave);
+				if (!piped) comb_of(r0, nb, 0);
+				else HIP_TRY(hipStreamWaitEvent(q, h->pipe.prep[set], 0));  // this batch's combs and averages are there (and, aux being
+				                                                            // in order, the batch before the last has left this set)
 				ScanParams cp{};
-				cp.iq8 = h->d_tbuf; cp.window16 = h->d_window16T; cp.tw = h->d_tw; cp.ave = h->d_ave; cp.work = h->d_work;
+				cp.iq8 = h->d_tbuf + set * set_tbuf; cp.window16 = h->d_window16T; cp.tw = h->d_tw; cp.ave = sp.ave; cp.work = sp.work;
 				cp.comb_c = c.bin_e - 14; cp.comb_blocks = frames << cp.comb_c;
 				const size_t lds_big = ((size_t)skewed_size(16384) + 16384) * 4;
 				const unsigned wgs = (unsigned)(cp.comb_blocks < 256 ? cp.comb_blocks : 256);
 				hipLaunchKernelGGL((k_power_scan_big<14, true>), dim3(wgs), dim3(kThreads), lds_big, q, cp);
+				if (piped) {
+					HIP_TRY(hipEventRecord(h->pipe.scanned[set], q));
+					// beside this batch's transform: the next batch's combs into the other set (its last user, batch kb - 1's
+					// passes over HBM, is already queued on aux in front of them) ...
+					if (r0 + (int)batch < nreads) {
+						const int r1 = r0 + (int)batch, nb1 = nreads - r1 < (int)batch ? nreads - r1 : (int)batch;
+						comb_of(r1, nb1, set ^ 1);
+						HIP_TRY(hipEventRecord(h->pipe.prep[set ^ 1], qa));
+					}
+					// ... then, once the transform is through, this batch's stages beyond 13 and its accumulation
+					HIP_TRY(hipStreamWaitEvent(qa, h->pipe.scanned[set], 0));
+				}
 			} else {
 				k_power_dc<<<(unsigned)((size_t)S * nb), 256, 0, q>>>(sp);
 				if (c.bin_e >= 12) k_power_place_tiled<<<grid_for(frames << (c.bin_e - 12), 1, 256 * 64), 256, 0, q>>>(sp);
@@ -685,17 +764,21 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 				const int R = c.bin_e - st >= 3 ? 3 : c.bin_e - st;
 				if (st + R == c.bin_e) {
 					const int g = grid_for((size_t)S << (c.bin_e - R), 256, 256 * 64);
-					if (R == 3) k_power_fft_gl_acc<3><<<g, 256, 0, q>>>(sp, st);
-					else if (R == 2) k_power_fft_gl_acc<2><<<g, 256, 0, q>>>(sp, st);
-					else k_power_fft_gl_acc<1><<<g, 256, 0, q>>>(sp, st);
+					if (R == 3) k_power_fft_gl_acc<3><<<g, 256, 0, qa>>>(sp, st);
+					else if (R == 2) k_power_fft_gl_acc<2><<<g, 256, 0, qa>>>(sp, st);
+					else k_power_fft_gl_acc<1><<<g, 256, 0, qa>>>(sp, st);
 				} else {
 					const int g = grid_for(frames << (c.bin_e - R), 256, 256 * 64);
-					k_power_fft_gl<3><<<g, 256, 0, q>>>(h->d_work, h->d_tw, c.bin_e, st, frames);
+					k_power_fft_gl<3><<<g, 256, 0, qa>>>(sp.work, h->d_tw, c.bin_e, st, frames);
 				}
 				st += R;
 			}
 			if (c.bin_e <= 14) k_power_accum<<<grid_for((size_t)S * h->N, 256, 256 * 64), 256, 0, q>>>(sp);
 			h->last_kernel = fast ? RTLPOWER_KERNEL_STAGED_FAST : RTLPOWER_KERNEL_STAGED;
+		}
+		if (piped) {  // the scan is complete on q when aux is through
+			HIP_TRY(hipEventRecord(h->pipe.done, qa));
+			HIP_TRY(hipStreamWaitEvent(q, h->pipe.done, 0));
 		}
 		HIP_TRY(hipGetLastError());
 		if (h->timing) {
@@ -794,7 +877,7 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	view.d_avg = h->d_avg + (size_t)stream * h->N;
 	view.d_samples = h->d_samples + stream;
 	view.d_decA = view.d_decB = nullptr; view.dec_cap_reads = 0;
-	view.d_work = nullptr; view.d_ave = nullptr; view.work_reads = 0;
+	view.d_work = nullptr; view.d_ave = nullptr; view.work_reads = 0; view.work_two = false;
 	view.d_tbuf = nullptr; view.d_part = nullptr;
 	view.d_dec32 = nullptr; view.dec32_cap = 0;
 	view.want_stamps = false;  // (the stamp buffer would be the view's: one leak per scan, and nothing for rtlpower_gpu_clock_read to find)
@@ -804,6 +887,7 @@ extern "C" int rtlpower_gpu_scan(rtlpower_gpu *h, int stream, const uint8_t *buf
 	h->attr_set = view.attr_set; h->attr_big = view.attr_big; h->attr_lds = view.attr_lds; h->attr_comb = view.attr_comb;
 	h->attr_frames = view.attr_frames; h->attr_frames16 = view.attr_frames16;
 	h->last_kernel = view.last_kernel;
+	h->pipe = view.pipe;  // (created by whoever needed it first)
 	const hipError_t e = hipStreamSynchronize(h->stream);
 	if (view.d_decA) { (void)hipFree(view.d_decA); (void)hipFree(view.d_decB); }  // also when the sync failed
 	if (view.d_work) { (void)hipFree(view.d_work); (void)hipFree(view.d_ave); }

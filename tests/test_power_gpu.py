@@ -253,6 +253,15 @@ def test_power_one_frame_per_read_every_size(oracle_lib, bin_e):
         for s in range(ns):
             assert res[s][1] == wn[s], (bin_e, s, fast)
             assert np.array_equal(res[s][0], want[s]), (bin_e, s, fast)
+    # the batches of a scan as a two-stream pipeline (round 5): one read per batch - three batches through the two sets of work
+    # buffers -, and the same on one stream
+    for opts in (dict(staged_batch=1, staged_pipe=2), dict(staged_batch=1, staged_pipe=0), dict(staged_batch=2, staged_pipe=2), dict(staged_pipe=2),
+                 dict(staged_batch=1)):
+        for split in (None, 2):
+            res = gpu_scan(cfg, iq, split=split, options=opts)
+            for s in range(ns):
+                assert res[s][1] == wn[s], (bin_e, s, opts, split)
+                assert np.array_equal(res[s][0], want[s]), (bin_e, s, opts, split)
     if bin_e <= 17:
         from rtlsdr_amd.power import GpuPower
         wide = torch.zeros((ns, L * nr + 8), dtype=torch.uint8, device="cuda")

@@ -16,14 +16,18 @@ def main():
     dev = torch.device("cuda:0")
     total = 1 << 30  # bytes per launch
     shapes = ((14, 1024), (15, 512), (17, 128), (19, 32), (20, 16), (21, 8), (17, 1), (21, 1))
-    if len(sys.argv) > 1:  # only these bin sizes (for a short rocprofv3 --kernel-trace --stats run)
-        shapes = tuple(x for x in shapes if str(x[0]) in sys.argv[1:] and x[1] > 1)
+    opts = dict((a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a)  # name=value: handle options (staged_pipe=0)
+    only = [a for a in sys.argv[1:] if "=" not in a]
+    if only:  # only these bin sizes (for a short rocprofv3 --kernel-trace --stats run)
+        shapes = tuple(x for x in shapes if str(x[0]) in only and x[1] > 1)
     for bin_e, streams in shapes:
         L = 2 << bin_e
         nreads = max(1, total // (streams * L)) if streams > 1 else 16
         cfg = RtlpowerCfg.default(bin_e=bin_e, window=1, buf_len=L)
         iq = torch.randint(0, 256, (streams, nreads * L), dtype=torch.uint8, device=dev)
         with GpuPower(cfg, streams, 0) as g:
+            for k, v in opts.items():
+                g.set_option(k, v)
             for _ in range(3):
                 g.scan_device(iq.data_ptr(), iq.stride(0), nreads)
             g.sync()
