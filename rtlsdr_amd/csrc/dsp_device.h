@@ -206,6 +206,26 @@ __device__ __forceinline__ int fast_atan2_q14(int y, int x)
 	const uint32_t ay = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
 	const bool neg = x < 0;
 	const uint32_t ax = neg ? 0u - (uint32_t)x : (uint32_t)x;
+#if !defined(RTLFM_FAST_ATAN_GENERAL_ONLY)
+	// Round 5 (LAB.md I.12, I.15).  Where nothing wraps - |x|, |y| < 2^18, i.e. everywhere the reference's own arithmetic is still what it was meant to
+	// be (4096 (x - yabs) overflows from 2^19 on) - the quotient is at most 4096 and the division is a float reciprocal plus
+	// an exact remainder on the 24-bit multiplier: 13 instructions, no fp64 reciprocal, against the 22 of sdiv_trunc.  Both
+	// arms are +-(|x| - yabs) over |x| + yabs.  Wave-uniform: one lane outside the range sends the wave through the general
+	// form below (the parity suite's full-scale inputs do).  While k_boxcar_scan waited for memory this bought nothing
+	// (-0.7 % at /10, 0 at /6); since its outputs leave as whole lines the /6 kernel is bound by its output loop:
+	// 1.007 -> 0.929 ms per 4 GiB, the -M wbfm step 1.274 -> 1.19-1.21 (profiles/r05_ab_fast_atan_f32.txt).
+	if (__builtin_amdgcn_ballot_w64((ax | ay) >= (1u << 18)) == 0) {
+		const int dif = (int)ax - (int)ay;
+		const uint32_t un12 = (uint32_t)(dif < 0 ? -dif : dif) << 12, den = ax + ay;
+		uint32_t q = (uint32_t)((float)un12 * __builtin_amdgcn_rcpf((float)den));  // off by at most one either way
+		const int rem = (int)(un12 - __umul24(q, den));
+		q = q - (rem < 0 ? 1u : 0u) + (rem >= (int)den ? 1u : 0u);
+		const int sq = ((dif < 0) != neg) ? -(int)q : (int)q;
+		const int angle = (neg ? 12288 : 4096) - sq;
+		const int r = y < 0 ? -angle : angle;
+		return (x | y) == 0 ? 0 : r;
+	}
+#endif
 	const int num = (int)((uint32_t)x + (neg ? ay : 0u - ay));
 	const int den = (int)(ax + ay);
 	const int prod = (int)(4096u * (uint32_t)num);
