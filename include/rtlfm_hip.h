@@ -296,6 +296,9 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        256 MiB Infinity Cache cannot keep anyway) as whole 128-byte lines with non-temporal stores, the
  *                        rest of a tile's last line waiting in LDS for the next tile; below, plain stores -, 0 / 1 = always
  *                        plain / always lines
+ *   fused_store          the fifth_order front end's PCM stores with 1-3 passes (4 / 2 / 1 KiB of PCM per 8 KiB tile): -1 (default)
+ *                        non-temporal with three passes (whole lines per instruction) when the launch writes more than
+ *                        192 MiB, 0 / 1 = never / always (with one or two passes non-temporal stores are slower: tests only)
  *   deep_rest            1 (default): passes 6 ... 9, generic_fir and the demodulator behind k_fused<6>'s emit mode in ONE
  *                        kernel per step (k_deep_rest); 0: one staged kernel per stage
  *   apart_budget_gb      most device memory (GiB, default 16, never more than half of what is free) a placement

@@ -737,13 +737,16 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			int16_t *dst = held_dst;
 			if constexpr (CZ >= 8) {
 				// 1-3 passes: the PCM is 12-50 % of the bytes, and written through it costs (P = 2: +16 %)
+				// (debug bit 256: non-temporal - set by the host for outputs that do not fit the Infinity Cache, LAB.md I.12)
 				uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+				const bool nt = (p.debug & 256) != 0;
 #pragma unroll
 				for (int k = 0; k < CZ / 8; k++) {
-					uint4 w;
+					u32x4_t w;
 					w.x = pack_iq(held[8 * k], held[8 * k + 1]); w.y = pack_iq(held[8 * k + 2], held[8 * k + 3]);
 					w.z = pack_iq(held[8 * k + 4], held[8 * k + 5]); w.w = pack_iq(held[8 * k + 6], held[8 * k + 7]);
-					d4[k] = w;
+					if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(d4 + k), "v"(w) : "memory");
+					else d4[k] = make_uint4(w.x, w.y, w.z, w.w);
 				}
 			} else if constexpr (CZ == 4) {
 				store_out8(dst, pack_iq(held[0], held[1]), pack_iq(held[2], held[3]));
@@ -1292,6 +1295,7 @@ struct Workspace {
 	bool plan_by_caller = false;                  // fused_waves / fused_min_tiles were set: the planner's own rules of thumb stand back
 	int tiles_per_seg = 0;                        // > 0: exactly this (tests)
 	int gss_x10 = 0;                              // guided segment lengths: remaining / (gss R) per round, x10 (0 = equal segments)
+	int fused_store = -1;                         // k_fused's PCM stores with 1-3 passes: -1 by the launch's output size, 0 plain, 1 non-temporal
 	int box_store = -1;                           // k_boxcar_scan's output stores: -1 by the launch's output size, 0 plain, 1 whole lines + nt
 	int debug = 0;                                // fused_debug: 2 = clock stamps per launch (+16: only on timing_read), 4 = reload a cached tile, 32 = stamp HW_ID / XCC_ID instead of the shader clock
 	void release()
@@ -1498,6 +1502,14 @@ inline int launch(Workspace &ws, const rtlfm_cfg &c, int nstreams, const uint8_t
 		p.mfma_taps = t;
 	}
 	p.debug = ws.debug | (ws.tail_follows ? 128 : 0);
+	if (!emit_iq && c.downsample_passes <= 3) {
+		// Three passes write 1 KiB of PCM per 8 KiB tile, 16 bytes per lane: whole lines per instruction.  Beyond what the
+		// Infinity Cache keeps they leave non-temporal (1.041 -> 1.008 ms per 4 GiB).  With two passes or one a lane holds 32
+		// or 64 bytes and an instruction writes every second or fourth 16-byte piece of a line: non-temporal that is 3 %
+		// and 2.4 x SLOWER (profiles/r05_ab_fused_store.txt) - only the option forces it there (tests).
+		const double out_bytes = (double)nstreams * nblocks * (double)(c.block_len / 2) / (double)(1 << c.downsample_passes) * 2.0;
+		if (ws.fused_store >= 0 ? ws.fused_store != 0 : (c.downsample_passes == 3 && out_bytes > 192.0 * 1048576.0)) p.debug |= 256;
+	}
 	if (ws.want_stamps) p.debug |= 2;
 	if (needs_partial_tiles(c) && engine != 1) return -ENOTSUP;
 	const SegPlan sp = plan_segments(ws, nstreams, nblocks * (int)((c.block_len + kTileBytes - 1) / kTileBytes), true);

@@ -580,7 +580,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -618,7 +618,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if (!strcmp(name, "pass0_engine") && (value < -1 || value > 1)) return -EINVAL;
 	if ((!strcmp(name, "fused_min_tiles") || !strcmp(name, "fused_tiles_per_seg")) && value < 0) return -EINVAL;
 	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
-	if (!strcmp(name, "box_store") && (value < -1 || value > 1)) return -EINVAL;
+	if ((!strcmp(name, "box_store") || !strcmp(name, "fused_store")) && (value < -1 || value > 1)) return -EINVAL;
 	// the chunk tables of the one-pass deemph + low_pass_real kernel are sized from it: keep it in a sane range
 	if (!strcmp(name, "lpr_chunk") && (value < 256 || value > (1 << 20))) return -EINVAL;
 	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;

@@ -217,6 +217,13 @@ def test_fused_kernel_vs_oracle_and_staged(oracle_lib, passes, fir9, atan, offs,
         for s in range(ns):
             assert np.array_equal(fo2[s], fo[s])
             assert gu.state_dict(fs2[s], False) == gu.state_dict(fs_[s], False)
+    if passes <= 3:
+        # fused_store = 1: the PCM of 1-3 passes leaves with non-temporal stores (what launches that write more than the
+        # Infinity Cache holds do by themselves, round 5)
+        fo3, fs3, _ = gpu_run(cfg, iq, path=engine, options=dict(fused_store=1))
+        for s in range(ns):
+            assert np.array_equal(fo3[s], fo[s])
+            assert gu.state_dict(fs3[s], False) == gu.state_dict(fs_[s], False)
 
 
 @pytest.mark.parametrize("engine", ENGINES)
