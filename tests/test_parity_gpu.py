@@ -1025,8 +1025,16 @@ def test_fast_atan2_against_oracle(oracle_lib):
     orc.orc_fast_atan2.restype = C.c_int
     rng = np.random.default_rng(4242)
     parts = []
-    for scale in (8, 300, 5000, 1 << 17, 1 << 19, 1 << 20, 1 << 24, 1 << 29):
+    # (round 5: below 2^18 on both components a wave takes the float-reciprocal division, with one lane at or beyond it the
+    # general one - whole blocks on either side of that line, and blocks that mix the two inside every wave)
+    for scale in (8, 300, 5000, 1 << 17, (1 << 18) - 1, 1 << 19, 1 << 20, 1 << 24, 1 << 29):
         parts.append(rng.integers(-scale, scale + 1, size=(400000, 2)))
+    mixed = rng.integers(-(1 << 17), (1 << 17) + 1, size=(200000, 2))
+    mixed[::37] = rng.integers(-(1 << 21), 1 << 21, size=mixed[::37].shape)
+    parts.append(mixed)
+    edge = (1 << 18) - 1
+    parts.append(np.array([[edge, edge], [edge, -edge], [-edge, edge], [edge, 0], [0, edge], [1, edge], [edge, 1], [edge - 1, edge],
+                           [edge + 1, 3], [3, edge + 1], [edge, edge - 7], [-edge, -edge]] * 16))
     base = rng.integers(-(1 << 21), 1 << 21, size=(300000, 1))
     parts.append(np.concatenate([base + rng.integers(-3, 4, size=base.shape), base], axis=1))    # |y| ~ |x|
     parts.append(np.concatenate([base, -base + rng.integers(-2, 3, size=base.shape)], axis=1))
