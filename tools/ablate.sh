@@ -3,14 +3,15 @@
 # The ablation points are NOT in the product headers: tools/ablate.patch adds them to a copy of
 # rtlsdr_amd/csrc under build_ablate/src (git-ignored), which is then built once per variant with
 # -DRTLFM_ABLATE=<bits>.  Analysis only - results are wrong by construction, bench runs with --check 0.
-# Bits: k_fused 1 no atan2, 2 / 4 / 8 no passes 1-3 / pass 0 / hand-offs, 16 no PCM stores, 32 PCM
-# stores to the same few lines (no write traffic leaves L2); k_boxcar_scan 1 no atan2, 2 no PCM
-# stores, 4 no outputs at all, 8 PCM stores to the same few lines.  For pairs of builds measured in
-# one process: tools/ab_engines.py --libs ....  If the patch no longer applies after a
-# kernel change, re-create the ablation points by hand in build_ablate/src and `diff -u` them back.
+# Bits (round 5: the patch was re-cut for the current kernels and keeps the one point that is still asked about): 1 = no
+# discriminator - atan2_q14 and fast_atan2 return a cheap function of both operands - in every front end.  (Rounds 2-4 also
+# cut passes, hand-offs and the PCM stores out; those questions are answered in LAB.md II 4.2 / 4.4b, and the store side is
+# what tools/write_share_probe.hip measures without a kernel around it.)  For pairs of builds measured in one process:
+# tools/ab_engines.py --libs ... (LAB.md I.13).  If the patch no longer applies after a change to dsp_device.h, re-create
+# the point by hand in build_ablate/src and `diff -u` it back.
 set -e
 cd "$(dirname "$0")/.."
-VARIANTS=${VARIANTS:-"0 1 2 4 8 3 6 7 15 16 32"}
+VARIANTS=${VARIANTS:-"0 1"}
 if [ "$1" = build ]; then
   rm -rf build_ablate/src && mkdir -p build_ablate/src/rtlsdr_amd && cp -r rtlsdr_amd/csrc build_ablate/src/rtlsdr_amd/csrc && cp -r include build_ablate/src/include
   (cd build_ablate/src && patch -p1 < ../../tools/ablate.patch)
