@@ -2671,7 +2671,8 @@ extern "C" const char *rtlfm_gpu_strerror(int err)
 	case -EAGAIN: return "streams have unequal / zero queued blocks, or a producer still holds an acquired slot";
 	case -EBUSY: return "the stream's previous slot is still open (rtlfm_gpu_acquire without rtlfm_gpu_commit)";
 	case -ENOTSUP: return "configuration not supported on this path";
-	case -EDOM: return "rate_out2 > rate_out with low_pass_real: the reference divides by zero here";
+	case -EDOM: return "outside the reference's own domain: a boxcar longer than the buffer (fm_demod reads lowpassed[-2]), low_pass_simple on a "
+	                   "count its step does not divide (src/rtl_fm.c:740), or rate_out2 > rate_out with low_pass_real (division by zero, :769)";
 	case -E2BIG: return "more blocks than cfg.max_blocks";
 	case -ENOBUFS: return "output buffer too small";
 	case -EIO: return "HIP runtime error";
