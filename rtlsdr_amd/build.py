@@ -86,7 +86,10 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
         for src in SOURCES:
             if not (force or _unit_stale(src, extra)):
                 continue
-            cmd = [_hipcc()] + FLAGS + ["-c", "-o", _obj(src) + tag, os.path.join(CSRC, src)] + (extra or [])
+            # -cuid: the compilation unit's id is otherwise a hash that takes the (temporary, per-process) output name in -
+            # two builds of the same sources then differ in their symbol names and the library in its bytes
+            cmd = ([_hipcc()] + FLAGS + [f"-cuid={os.path.splitext(src)[0]}", "-c", "-o", _obj(src) + tag, os.path.join(CSRC, src)]
+                   + (extra or []))
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, cmd, subprocess.Popen(cmd)))
