@@ -310,6 +310,8 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  * Read-only (rtlfm_gpu_get_option):
  *   ring_apart           1 / 0: the result buffers behind rtlfm_gpu_push() / _run() are / are not a quarter of the HBM
  *                        away from the ring's device input; -1 before the ring exists (it is built by the first push)
+ *   ring_tries           searches the ring's placement took: 2 = the first found every candidate in the input's class and the
+ *                        ring's own device inputs were moved once (the handle owns both sides there)
  *   res_apart            the same for the audio tail's work buffers against the first run's input (-1: none yet;
  *                        0 also on a caller-owned stream (rtlfm_gpu_set_stream), where no search is made - the search
  *                        times launches on the null stream and synchronises the device; a caller on its own stream

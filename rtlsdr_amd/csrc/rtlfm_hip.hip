@@ -99,6 +99,7 @@ struct rtlfm_gpu {
 	// placement of the write streams (rtlfm_gpu_malloc_apart_ex): what the searches found and what they cost
 	struct Placement {
 		int budget_gb = 16;             // option apart_budget_gb: most a search may hold in candidates; 0 = no search
+		int ring_tries = 0;             // searches the ring's placement took (2: the device inputs were moved once)
 		int ring_apart = -1;            // -1: not allocated yet; 0 / 1: the ring's result buffers (both halves) are a quarter away from d_in
 		int res_apart = -1;             // the same for the audio tail's work buffers against the first run's input
 		int deep_apart = -1;            // ... and for what a front end's emit mode writes (deepA)
@@ -637,6 +638,7 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 	if (!strcmp(name, "tail_priority")) { *value = h->tail_priority; return 0; }
 	// read-only: where the write streams' buffers ended up (rtlfm_gpu_malloc_apart_ex) and what finding out cost
 	if (!strcmp(name, "ring_apart")) { *value = h->place.ring_apart; return 0; }
+	if (!strcmp(name, "ring_tries")) { *value = h->place.ring_tries; return 0; }
 	if (!strcmp(name, "poison")) { *value = rtl_debug::poison_on() ? 1 : 0; return 0; }  // RTLFM_POISON=1 (debug_poison.h)
 	if (!strcmp(name, "res_apart")) { *value = h->place.res_apart; return 0; }
 	if (!strcmp(name, "deep_apart")) { *value = h->place.deep_apart; return 0; }
@@ -1826,6 +1828,30 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 		if (r < 0) return r;
 		h->place.search_ms += ms;
 		if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+		h->place.ring_tries = 1;
+		if (!apart && walked > 0) {
+			// A search was made and every candidate within its bound shared the input's class (round 5 met boxes where one class
+			// runs on for more than 16 GB).  Here the handle owns the OTHER side as well: the ring's device inputs move - new ones
+			// are allocated while the old ones are still held, so that they come from somewhere else - and the search runs once
+			// more against them.  One retry; whatever it finds is what the ring gets.
+			void *n0 = nullptr, *n1 = nullptr;
+			if (hipMalloc(&n0, bytes) == hipSuccess && hipMalloc(&n1, bytes) == hipSuccess) {
+				(void)hipFree(p);
+				p = nullptr;
+				int apart2 = 0;
+				r = rtlfm_gpu_malloc_apart_ex(h->device, 2 * one, n0, bytes, budget, &p, &apart2, &ms, &walked);
+				if (r < 0) { (void)hipFree(n0); (void)hipFree(n1); return r; }
+				h->place.search_ms += ms;
+				if (walked > h->place.walked_peak) h->place.walked_peak = walked;
+				h->place.ring_tries = 2;
+				(void)hipFree(in->d_in[0]); (void)hipFree(in->d_in[1]);
+				in->d_in[0] = (uint8_t *)n0; in->d_in[1] = (uint8_t *)n1;
+				apart = apart2;
+			} else {
+				if (n0) (void)hipFree(n0);
+				(void)hipGetLastError();
+			}
+		}
 		in->d_result[0] = (int16_t *)p;
 		in->d_result[1] = (int16_t *)((char *)p + one);
 		in->result_one_block = true;
