@@ -294,7 +294,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 	auto store16 = [&](void *g, const uint4 v) {
 		typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 		const u32x4v vv = {v.x, v.y, v.z, v.w};
-		if (lines_nt) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(g), "v"(vv) : "memory");
+		// (s_nop: a VALU write to the data registers of a store of more than 64 bits must stay one wait state behind it, and
+		// the compiler does not know that this line is one)
+		if (lines_nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" : : "v"(g), "v"(vv) : "memory");
 		else *reinterpret_cast<uint4 *>(g) = v;
 	};
 	auto flush = [&]() {

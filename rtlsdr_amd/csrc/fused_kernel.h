@@ -218,9 +218,10 @@ __device__ __forceinline__ void store_out4(void *p, uint32_t a)
 // hipcc otherwise emits v_mov 0 + the accumulate-in-place VOP2 form.
 __device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
 {
-	int r;
-	asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(taps));
-	return r;
+	// (round 5: the builtin, not a line of assembly.  gfx950 does NOT interlock a VALU read of a v_dot4_i32_i8 result: read
+	// at once or one wait state later it is wrong every time, three later it is right - tools/dot_hazard_probe.hip -, and the
+	// compiler only keeps that distance for dots it has emitted itself.  v_dot2_i32_i16 has no such window: dot2_first stays.)
+	return __builtin_amdgcn_sdot4((int)a, taps, 0, false);
 }
 __device__ __forceinline__ int dot2_first(uint32_t a, uint32_t b)
 {
@@ -745,7 +746,9 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 					u32x4_t w;
 					w.x = pack_iq(held[8 * k], held[8 * k + 1]); w.y = pack_iq(held[8 * k + 2], held[8 * k + 3]);
 					w.z = pack_iq(held[8 * k + 4], held[8 * k + 5]); w.w = pack_iq(held[8 * k + 6], held[8 * k + 7]);
-					if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(d4 + k), "v"(w) : "memory");
+					// (s_nop: a store of more than 64 bits reads its data over two cycles, and a VALU write to those registers must
+					// stay one wait state behind it - the compiler keeps that distance for stores it knows, not for this line)
+					if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" : : "v"(d4 + k), "v"(w) : "memory");
 					else d4[k] = make_uint4(w.x, w.y, w.z, w.w);
 				}
 			} else if constexpr (CZ == 4) {

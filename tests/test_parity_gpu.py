@@ -31,9 +31,10 @@ def assert_parity(got, want, cfg, what=""):
         return
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     nbad = int((diff != 0).sum())
-    assert _float_sensitive(cfg), f"{what}: {nbad} mismatches in an integer-only chain"
+    where = np.flatnonzero(diff)[:12].tolist()
+    assert _float_sensitive(cfg), f"{what}: {nbad} mismatches in an integer-only chain, first at {where} of {len(got)}"
     # tolerance for the fp64 atan2 / double interpolation stages: <= 1 LSB on <= 1e-4 of samples
-    assert diff.max() <= 1, f"{what}: max diff {diff.max()}"
+    assert diff.max() <= 1, f"{what}: max diff {diff.max()}, {nbad} mismatches, first at {where} of {len(got)}"
     assert nbad <= max(1, int(1e-4 * got.size)), f"{what}: {nbad}/{got.size} differ by 1 LSB"
 
 
