@@ -218,10 +218,14 @@ __device__ __forceinline__ void store_out4(void *p, uint32_t a)
 // hipcc otherwise emits v_mov 0 + the accumulate-in-place VOP2 form.
 __device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
 {
-	// (round 5: the builtin, not a line of assembly.  gfx950 does NOT interlock a VALU read of a v_dot4_i32_i8 result: read
-	// at once or one wait state later it is wrong every time, three later it is right - tools/dot_hazard_probe.hip -, and the
-	// compiler only keeps that distance for dots it has emitted itself.  v_dot2_i32_i16 has no such window: dot2_first stays.)
-	return __builtin_amdgcn_sdot4((int)a, taps, 0, false);
+	// (round 5: with its own wait states.  gfx950 does NOT interlock a VALU read of a v_dot4_i32_i8 result: read at once or one
+	// wait state later it is wrong every time, three later it is right - tools/dot_hazard_probe.hip -, and the compiler only
+	// keeps that distance for dots it has emitted itself, not for a line of assembly.  Until now the consumers of this one
+	// were three or more slots away by the scheduler's grace.  The builtin instead (v_mov 0 + v_dot4c) moves the v_dot4
+	// engine's P = 1 kernels' tile loads: tools/check_prefetch.py.  v_dot2_i32_i16 has no such window: dot2_first stays.)
+	int r;
+	asm("v_dot4_i32_i8 %0, %1, %2, 0\n\ts_nop 2" : "=v"(r) : "v"(a), "s"(taps));
+	return r;
 }
 __device__ __forceinline__ int dot2_first(uint32_t a, uint32_t b)
 {
