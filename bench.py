@@ -1030,10 +1030,11 @@ def main():
     if a.check and rank == 0 and not a.no_cpu_baseline and world == 1:
         gate = job.gate()
 
-    # Untimed: after idle the GPU needs ~50 launches (~50 ms) to reach its steady clock.  If the
-    # caller asks for fewer warm-up steps than that, the difference is run first and reported
-    # as config.prewarm_steps, so that the K timed steps always measure the steady state.
-    prewarm = 0 if a.pmc_child else max(0, 100 - a.warmup)
+    # Untimed: after idle the GPU needs ~50 launches (~50 ms) to reach its steady clock - on most boxes; round 5's last
+    # driver-shaped run met one where 20 timed steps behind 100 untimed ones still read 2.4 % under the 2-second sustained
+    # figure of the same invocation (0.7225 against 0.7405).  If the caller asks for fewer warm-up steps than 400 (0.3 s), the
+    # difference is run first and reported as config.prewarm_steps, so that the K timed steps measure the steady state.
+    prewarm = 0 if a.pmc_child else max(0, 400 - a.warmup)
     for _ in range(prewarm + a.warmup):
         step()
     fence()
