@@ -324,6 +324,7 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        allocation of both libraries is filled with 0xA5 and every run / scan first leaves 0xA5 in all of
  *                        every CU's LDS, so that nothing read before it is written goes unnoticed (debug_poison.h;
  *                        tests/test_poison_gpu.py runs the parity suites that way)
+ *   ring_force_retry     1: the ring's first placement search counts as failed (tests: the path that moves the device inputs)
  *   tail_sync            1: synchronise and report after every tail kernel (debugging)
  *   fused_debug          clock-stamp experiments (2 / 18 / 4, see fused_kernel.h)
  * Returns -ENOENT for an unknown name, -EINVAL for a value out of range.

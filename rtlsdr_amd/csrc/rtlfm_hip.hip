@@ -99,6 +99,7 @@ struct rtlfm_gpu {
 	// placement of the write streams (rtlfm_gpu_malloc_apart_ex): what the searches found and what they cost
 	struct Placement {
 		int budget_gb = 16;             // option apart_budget_gb: most a search may hold in candidates; 0 = no search
+		int force_retry = 0;            // option ring_force_retry (tests): the ring's first search counts as failed
 		int ring_tries = 0;             // searches the ring's placement took (2: the device inputs were moved once)
 		int ring_apart = -1;            // -1: not allocated yet; 0 / 1: the ring's result buffers (both halves) are a quarter away from d_in
 		int res_apart = -1;             // the same for the audio tail's work buffers against the first run's input
@@ -580,7 +581,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"pass0_engine", &h->fws.pass0_engine},
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
-		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb},
+		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
 		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
 	};
 	for (auto &t : tab)
@@ -1829,7 +1830,7 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 		h->place.search_ms += ms;
 		if (walked > h->place.walked_peak) h->place.walked_peak = walked;
 		h->place.ring_tries = 1;
-		if (!apart && walked > 0) {
+		if ((!apart && walked > 0) || h->place.force_retry) {  // (force_retry: option "ring_force_retry", tests)
 			// A search was made and every candidate within its bound shared the input's class (round 5 met boxes where one class
 			// runs on for more than 16 GB).  Here the handle owns the OTHER side as well: the ring's device inputs move - new ones
 			// are allocated while the old ones are still held, so that they come from somewhere else - and the search runs once

@@ -1581,6 +1581,37 @@ def test_placement_in_ten_fresh_processes():
     assert found >= 6, seen
 
 
+def test_ring_moves_its_inputs_when_a_search_finds_nothing(oracle_lib):
+    """Where a bounded placement search comes back empty-handed the ring - whose device inputs are the handle's own - moves
+    them once and searches again (round 5).  The first search is declared failed by option; the callback path must give the
+    oracle's samples through the moved buffers, over several runs."""
+    from rtlsdr_amd.demod import GpuDemod
+    L, nb, ns = 262144, 2, 512  # large enough for a search to be made at all
+    cfg = make_cfg(dict(downsample=16, downsample_passes=4, rate_out=150000), L, nb)
+    iq = synth.fm_iq_u8(4, L // 2 * nb * 2, seed=77, fs=2.4e6, dev_hz=75e3, amplitude=60.0)
+    cfg2 = RtlfmCfg.from_buffer_copy(bytes(cfg)); cfg2.max_blocks = 2 * nb
+    want, want_len, _ = oracle_lib.run_batch(cfg2, iq, nthreads=4)
+    with GpuDemod(cfg, ns, 0, options=dict(ring_force_retry=1)) as g:
+        got = [[] for _ in range(4)]
+        for run in range(2):
+            for s in range(ns):
+                for b in range(nb):
+                    k = run * nb + b
+                    g.rtlsdr_callback(iq[s % 4, k * L:(k + 1) * L], s)
+            if run == 0:
+                assert g.get_option("ring_tries") == 2 and g.get_option("ring_apart") in (0, 1)
+                assert g.get_option("placement_walked_mb") <= 16 * 1024
+            g.full_demod()
+            out, lens = g.fetch_all()
+            for s in range(ns):
+                if s < 4:
+                    got[s].append(out[s, :lens[s]].copy())
+                else:
+                    assert lens[s] == lens[s % 4] and np.array_equal(out[s, :lens[s]], out[s % 4, :lens[s]]), (run, s)
+        for s in range(4):
+            assert_parity(np.concatenate(got[s]), want[s, :want_len[s]], cfg, f"moved ring, stream {s}")
+
+
 def test_push_and_acquire_do_not_mix_on_one_stream():
     """One producer per stream: while a slot is out between rtlfm_gpu_acquire and _commit, rtlfm_gpu_push for that stream
     is refused (-EBUSY; it would land in that very slot), a second acquire too, and rtlfm_gpu_run says -EAGAIN."""
