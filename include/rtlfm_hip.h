@@ -307,7 +307,14 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        a four-instruction filter step for a == 2) instead of k_deemph_spec_arb: 18 % fewer instructions,
  *                        the same time - kept for A/B
  *   arb_chunk            samples per lane of k_deemph_arb_span: 32 (default) or 64, anything else -EINVAL
+ *   verify_twice         debugging: 1 = every rtlfm_gpu_run_device() executes its run TWICE from the same carried state - into
+ *                        shadow rows first, then into the caller's, the device idle in between - and compares rows, lengths and
+ *                        the state records on the device; a difference is reported on stderr and counted.  Separates a transient
+ *                        fault of the device code from a deterministic one (tests/test_soak_gpu.py).  Twice the time and a
+ *                        second set of output rows; ragged runs (short callback buffers) are not verified
  * Read-only (rtlfm_gpu_get_option):
+ *   verify_runs          runs executed under verify_twice so far, and
+ *   verify_mismatches    ... how many of them differed between their two executions
  *   ring_apart           1 / 0: the result buffers behind rtlfm_gpu_push() / _run() are / are not a quarter of the HBM
  *                        away from the ring's device input; -1 before the ring exists (it is built by the first push)
  *   ring_tries           searches the ring's placement took: 2 = the first found every candidate in the input's class and the

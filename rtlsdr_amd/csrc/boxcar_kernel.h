@@ -534,8 +534,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				}
 				const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);
 				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
-				const int cr = fused::dot2_first(z, b);
-				const int cj = fused::dot2_first(z, bx);
+				int cr, cj;
+				fused::dot2_pair(z, b, bx, cr, cj);
 				int v;
 				if (V == 0 && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
 				else if (V == 1) v = atan2_q14(cj, cr, nodes);
@@ -586,7 +586,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 						const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
 						const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
 						const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
-						const int v0 = atan2_q14(fused::dot2_first(z0, bx), fused::dot2_first(z0, b0), nodes);
+						int cr0, cj0;
+						fused::dot2_pair(z0, b0, bx, cr0, cj0);
+						const int v0 = atan2_q14(cj0, cr0, nodes);
 						pcm[pcm_idx(e)] = (uint16_t)(int16_t)v0;
 					}
 				}

@@ -222,16 +222,23 @@ __device__ __forceinline__ int dot4_first(uint32_t a, int32_t taps)
 	// wait state later it is wrong every time, three later it is right - tools/dot_hazard_probe.hip -, and the compiler only
 	// keeps that distance for dots it has emitted itself, not for a line of assembly.  Until now the consumers of this one
 	// were three or more slots away by the scheduler's grace.  The builtin instead (v_mov 0 + v_dot4c) moves the v_dot4
-	// engine's P = 1 kernels' tile loads: tools/check_prefetch.py.  v_dot2_i32_i16 has no such window: dot2_first stays.)
+	// engine's P = 1 kernels' tile loads: tools/check_prefetch.py.  v_dot2_i32_i16: see dot2_pair.)
 	int r;
 	asm("v_dot4_i32_i8 %0, %1, %2, 0\n\ts_nop 2" : "=v"(r) : "v"(a), "s"(taps));
 	return r;
 }
-__device__ __forceinline__ int dot2_first(uint32_t a, uint32_t b)
+// The conjugate product of a discriminator: r0 = dot2(a, b0), r1 = dot2(a, b1), zero accumulators, with their own wait states.
+// (Round 6.  LLVM's hazard recogniser keeps ANY VALU read of a dot result three wait states behind the dot and a write of
+// another opcode two - v_dot2 included - but only for dots it emitted itself.  tools/dot_hazard_probe.hip never caught
+// v_dot2_i32_i16 -> v_add_u32 wrong, so round 5 left the bare one-instruction wrapper in; tools/check_dot_hazard.py then
+// found its result read by v_cvt_f64_i32 one and two wait states later, and overwritten one later, in 37 shipped kernels:
+// every boxcar front end and the 1-, 2-, 5- and 6-pass fifth_order ones.  No test ever failed on it - and LAB.md I.17's one
+// unexplained wrong sample came out of one of those kernels.  Whatever the hardware does most of the time, the documented
+// distance is now kept: the second dot and s_nop 2 put four and three wait states behind the two results, and the lint
+// runs in the CPU suite, tests/test_isa_lint.py.)
+__device__ __forceinline__ void dot2_pair(uint32_t a, uint32_t b0, uint32_t b1, int &r0, int &r1)
 {
-	int r;
-	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
-	return r;
+	asm("v_dot2_i32_i16 %0, %2, %3, 0\n\tv_dot2_i32_i16 %1, %2, %4, 0\n\ts_nop 2" : "=&v"(r0), "=&v"(r1) : "v"(a), "v"(b0), "v"(b1));
 }
 
 struct Params {
@@ -1223,8 +1230,8 @@ __global__ void __launch_bounds__(64, (P == 1 ? 2 : P == 2 ? 3 : RTLFM_FUSED_WAV
 			// the int16 negation and the 32-bit dot products are exact
 			const uint32_t bsw = __builtin_amdgcn_alignbit(b, b, 16);                      // (bq, bi)
 			const uint32_t bx = as_u32(as_s2(bsw) * short2_t{(short)-1, (short)1});          // (-bq, bi)
-			const int cr = dot2_first(c, b);
-			const int cj = dot2_first(c, bx);
+			int cr, cj;
+			dot2_pair(c, b, bx, cr, cj);
 			int v;
 			if (STD) {
 				v = atan2_q14(cj, cr, nodes);

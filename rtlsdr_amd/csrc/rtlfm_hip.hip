@@ -118,7 +118,15 @@ struct rtlfm_gpu {
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
+		int verify_twice = 0;  // debug: every run_device runs twice - into a shadow output, then into the caller's - and the two are compared on the device
 	} opt;
+	// verify_twice (round 6): shadow rows / lengths / state, and what the comparisons found so far
+	int16_t *vt_out = nullptr;
+	size_t vt_out_cap = 0;        // int16 elements
+	int32_t *vt_len = nullptr, *vt_len2 = nullptr;
+	state_t *vt_state = nullptr;
+	unsigned long long *vt_cnt = nullptr;  // [4]: differing PCM dwords, differing lengths, differing state dwords, first differing (stream << 32 | index) + 1
+	long vt_mismatches = 0, vt_runs = 0;
 
 	// timing of the decimating front end
 	bool timing = false;
@@ -474,7 +482,8 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	for (auto &p : h->ev_free) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
 	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_arb_tab, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res_one_block ? nullptr : (void *)h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
-	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sq_sums, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg};
+	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sq_sums, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg,
+	                h->vt_out, h->vt_len, h->vt_len2, h->vt_state, h->vt_cnt};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	h->fws.release();
@@ -583,6 +592,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
 		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
+		{"verify_twice", &h->opt.verify_twice},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -645,6 +655,8 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 	if (!strcmp(name, "deep_apart")) { *value = h->place.deep_apart; return 0; }
 	if (!strcmp(name, "placement_ms")) { *value = (long)(h->place.search_ms + 0.5); return 0; }
 	if (!strcmp(name, "placement_walked_mb")) { *value = (long)(h->place.walked_peak >> 20); return 0; }
+	if (!strcmp(name, "verify_mismatches")) { *value = h->vt_mismatches; return 0; }  // verify_twice: runs whose two executions differed
+	if (!strcmp(name, "verify_runs")) { *value = h->vt_runs; return 0; }
 	int *slot = option_slot(h, name);
 	if (!slot) return -ENOENT;
 	*value = *slot;
@@ -1654,14 +1666,10 @@ static int run_boxfused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_st
 	return run_tail(h, tp, dd, dds, T, varcnt, nblocks, N0, D, d_out, out_stride, d_out_len);
 }
 
-extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
-                                    int16_t *d_out, size_t out_stride, int32_t *d_out_len)
+// one execution of a run: everything rtlfm_gpu_run_device does except moving on to the next state copy / step
+static int run_device_once(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
+                           int16_t *d_out, size_t out_stride, int32_t *d_out_len)
 {
-	if (!h || !d_iq || !d_out || nblocks < 1) return -EINVAL;
-	if (nblocks > h->cap_blocks) return -E2BIG;
-	if (((uintptr_t)d_iq & 15) || (stream_stride & 15) || ((uintptr_t)d_out & 3) || (out_stride & 1)) return -EINVAL;
-	if (stream_stride < (size_t)nblocks * h->cfg.block_len) return -EINVAL;
-	HIP_TRY(hipSetDevice(h->device));
 	rtl_debug::poison_lds(h->stream);  // RTLFM_POISON=1 only
 	const size_t S = (size_t)h->nstreams;
 	// the squelch / -L with rms()'s sums taken by the front end itself (round 5) comes before the emit mode
@@ -1709,6 +1717,91 @@ extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t st
 	}
 	if (r < 0) return r;
 	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// verify_twice: rows of two executions of one run, dword by dword up to each stream's length; lengths; state records
+__global__ void k_verify_rows(const int16_t *a, const int16_t *b, size_t stride, const int32_t *la, const int32_t *lb, int S,
+                              unsigned long long *cnt)
+{
+	const int s = blockIdx.x;
+	if (s >= S) return;
+	const int n = la[s];
+	if (threadIdx.x == 0 && n != lb[s]) atomicAdd(cnt + 1, 1ull);
+	const int16_t *ra = a + (size_t)s * stride, *rb = b + (size_t)s * stride;
+	unsigned long long bad = 0, first = 0;
+	for (int i = threadIdx.x; i < n; i += blockDim.x)
+		if (ra[i] != rb[i]) { bad++; if (!first) first = ((unsigned long long)s << 32 | (unsigned)i) + 1; }
+	if (bad) { atomicAdd(cnt, bad); atomicMin(cnt + 3, first); }
+}
+__global__ void k_verify_words(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *cnt)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && a[i] != b[i]) atomicAdd(cnt + 2, 1ull);
+}
+
+// The debug option verify_twice (round 6, VERDICT r5 task 1b): the run is executed twice from the same carried state -
+// first into shadow rows, then into the caller's - with the device idle in between, and rows, lengths and the state
+// records the two executions left are compared on the device.  A difference is a TRANSIENT fault of the device code
+// (the kernels are deterministic functions of their input: tools/determinism_stress.py); a result that differs from the
+// oracle while the two executions agree is a deterministic fault, or one outside the launch (the upload, the download).
+static int run_device_verified(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
+                               int16_t *d_out, size_t out_stride, int32_t *d_out_len)
+{
+	const size_t S = (size_t)h->nstreams;
+	const size_t need = S * out_stride;
+	if (h->vt_out_cap < need) {
+		if (h->vt_out) hipFree(h->vt_out);
+		h->vt_out = nullptr; h->vt_out_cap = 0;
+		HIP_TRY(hipMalloc(&h->vt_out, need * sizeof(int16_t)));
+		h->vt_out_cap = need;
+	}
+	if (!h->vt_len) {
+		HIP_TRY(hipMalloc(&h->vt_len, S * sizeof(int32_t)));
+		HIP_TRY(hipMalloc(&h->vt_len2, S * sizeof(int32_t)));
+		HIP_TRY(hipMalloc(&h->vt_state, S * sizeof(state_t)));
+		HIP_TRY(hipMalloc(&h->vt_cnt, 4 * sizeof(unsigned long long)));
+	}
+	state_t *sout = h->st[(h->st_cur + 1) % 3];
+	int r = run_device_once(h, d_iq, stream_stride, nblocks, h->vt_out, out_stride, h->vt_len);
+	if (r < 0) return r;
+	HIP_TRY(sync_all(h));
+	HIP_TRY(hipMemcpy(h->vt_state, sout, S * sizeof(state_t), hipMemcpyDeviceToDevice));
+	int32_t *len2 = d_out_len ? d_out_len : h->vt_len2;
+	r = run_device_once(h, d_iq, stream_stride, nblocks, d_out, out_stride, len2);
+	if (r < 0) return r;
+	HIP_TRY(sync_all(h));
+	const unsigned long long init[4] = {0, 0, 0, ~0ull};
+	HIP_TRY(hipMemcpy(h->vt_cnt, init, sizeof(init), hipMemcpyHostToDevice));
+	k_verify_rows<<<(unsigned)S, 256, 0, h->stream>>>(h->vt_out, d_out, out_stride, h->vt_len, len2, (int)S, h->vt_cnt);
+	const size_t nw = S * sizeof(state_t) / 4;
+	k_verify_words<<<(unsigned)((nw + 255) / 256), 256, 0, h->stream>>>(reinterpret_cast<const uint32_t *>(h->vt_state),
+	                                                                  reinterpret_cast<const uint32_t *>(sout), nw, h->vt_cnt);
+	unsigned long long got[4];
+	HIP_TRY(hipMemcpyAsync(got, h->vt_cnt, sizeof(got), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	h->vt_runs++;
+	if (got[0] || got[1] || got[2]) {
+		h->vt_mismatches++;
+		fprintf(stderr, "rtlfm_hip: verify_twice: two executions of one run differ: %llu PCM samples, %llu lengths, %llu state words; "
+		        "first at stream %llu sample %llu (run %ld of this handle, input %p, rows %p / shadow %p)\n",
+		        got[0], got[1], got[2], got[0] ? (got[3] - 1) >> 32 : 0ull, got[0] ? (got[3] - 1) & 0xffffffffull : 0ull,
+		        h->vt_runs, (const void *)d_iq, (void *)d_out, (void *)h->vt_out);
+	}
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_run_device(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, int nblocks,
+                                    int16_t *d_out, size_t out_stride, int32_t *d_out_len)
+{
+	if (!h || !d_iq || !d_out || nblocks < 1) return -EINVAL;
+	if (nblocks > h->cap_blocks) return -E2BIG;
+	if (((uintptr_t)d_iq & 15) || (stream_stride & 15) || ((uintptr_t)d_out & 3) || (out_stride & 1)) return -EINVAL;
+	if (stream_stride < (size_t)nblocks * h->cfg.block_len) return -EINVAL;
+	HIP_TRY(hipSetDevice(h->device));
+	const int r = h->opt.verify_twice ? run_device_verified(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len)
+	                                  : run_device_once(h, d_iq, stream_stride, nblocks, d_out, out_stride, d_out_len);
+	if (r < 0) return r;
 	h->st_cur = (h->st_cur + 1) % 3;
 	h->step++;
 	h->last_nblocks = nblocks;
@@ -2024,6 +2117,7 @@ static rtlfm_gpu make_view(rtlfm_gpu *h, int s0, int ns, uint32_t block_len)
 	v.tail_overlap = false;
 	v.timing = false;
 	v.no_deemph_scan = true;
+	v.opt.verify_twice = 0;  // views must not allocate (the shadow rows): ragged runs are not verified
 	v.ev_pending.clear(); v.ev_free.clear();
 	const size_t cb = (size_t)h->cap_blocks;
 	for (int k = 0; k < 3; k++) v.st[k] = h->st[k] + s0;

@@ -448,18 +448,13 @@ def test_buffers_of_any_512n_bytes(oracle_lib, front, L):
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (front, L, splits, opts, s_)
 
 
-@pytest.mark.parametrize("L", [12288, 20480, 512 * 23, 512 * 37, 32768, 1536])
-@pytest.mark.parametrize("front", ["p1rdc", "p3rdc", "p4rdc", "p4rdcfast", "p5firrdc", "p6firrdc", "p4rdcraw", "p4rdcsq", "p7firrdc",
-                                   "box10rdc", "box7fastrdc", "box42rdc", "box10rdcraw", "box10rdcsq",
-                                   "box1", "box1fast", "box1lut", "box1raw", "box1sq", "box1am", "box1rdc"])
-def test_what_round_four_left_on_the_staged_kernels(oracle_lib, front, L):
-    """tools/path_census.py of round 4: 57 of 561 accepted random configurations still took the staged front end - -E rdc
-    together with buffers that are not whole tiles (src/rtl_fm.c:1043-1065, :1869-1873), -E rdc in front of -M raw / the
-    squelch / 7 and more passes (the fifth_order front end's emit mode had no raw DC block), and low_pass with
-    downsample == 1 (rtl_fm -s 1.2M: optimal_settings gives 1, :1415).  All of them on the one-launch front ends now
-    (`last_path == 2`): the partial-tile kernels with the averages on pass 0's accumulators, a tile of the boxcar kernel
-    with two buffers' averages, 4096 outputs per tile at /1.  Drifting DC offsets, full-scale bytes, split launches,
-    segments that start anywhere."""
+ROUND_FOUR_SHAPES = ((None, None), ([(0, 1), (1, 3), (3, 5)], dict(fused_tiles_per_seg=3)), (None, dict(fused_waves=1)),
+                     (None, dict(fused_tiles_per_seg=1)))
+
+
+def round_four_case(front, L):
+    """Configuration and input of test_what_round_four_left_on_the_staged_kernels (tests/test_soak_gpu.py repeats its
+    launches): (cfg, iq [ns, nb * L], nb, ns); skips what the chain cannot take."""
     ov = {}
     rdc = "rdc" in front
     if front.startswith("box"):
@@ -494,9 +489,24 @@ def test_what_round_four_left_on_the_staged_kernels(oracle_lib, front, L):
                 iq[s_, b * L:(b + 1) * L] = np.clip(blk, 0, 255).astype(np.uint8)
     if ov.get("custom_atan") != 1:
         iq[ns - 1] = synth.random_u8(1, L * nb, seed=L)[0]
+    return cfg, iq, nb, ns
+
+
+@pytest.mark.parametrize("L", [12288, 20480, 512 * 23, 512 * 37, 32768, 1536])
+@pytest.mark.parametrize("front", ["p1rdc", "p3rdc", "p4rdc", "p4rdcfast", "p5firrdc", "p6firrdc", "p4rdcraw", "p4rdcsq", "p7firrdc",
+                                   "box10rdc", "box7fastrdc", "box42rdc", "box10rdcraw", "box10rdcsq",
+                                   "box1", "box1fast", "box1lut", "box1raw", "box1sq", "box1am", "box1rdc"])
+def test_what_round_four_left_on_the_staged_kernels(oracle_lib, front, L):
+    """tools/path_census.py of round 4: 57 of 561 accepted random configurations still took the staged front end - -E rdc
+    together with buffers that are not whole tiles (src/rtl_fm.c:1043-1065, :1869-1873), -E rdc in front of -M raw / the
+    squelch / 7 and more passes (the fifth_order front end's emit mode had no raw DC block), and low_pass with
+    downsample == 1 (rtl_fm -s 1.2M: optimal_settings gives 1, :1415).  All of them on the one-launch front ends now
+    (`last_path == 2`): the partial-tile kernels with the averages on pass 0's accumulators, a tile of the boxcar kernel
+    with two buffers' averages, 4096 outputs per tile at /1.  Drifting DC offsets, full-scale bytes, split launches,
+    segments that start anywhere."""
+    cfg, iq, nb, ns = round_four_case(front, L)
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
-    for splits, opts in ((None, None), ([(0, 1), (1, 3), (3, nb)], dict(fused_tiles_per_seg=3)), (None, dict(fused_waves=1)),
-                         (None, dict(fused_tiles_per_seg=1))):
+    for splits, opts in ROUND_FOUR_SHAPES:
         outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
         assert used == 2, (front, L)
         for s_ in range(ns):
