@@ -509,6 +509,42 @@ class ApartRows:
             self.ptr = None
 
 
+class _DevMem:
+    """A raw device pointer dressed for torch.as_tensor (__cuda_array_interface__, which the ROCm build reads too)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PlacedPair(ApartRows):
+    """Input AND output of a launch placed together (rtlfm_gpu_place_pair): `gen` (a torch uint8 [S, n] tensor) is copied into
+    the placed input, which is what `.iq` then is - a torch view of library-owned memory; the rows quack like ApartRows."""
+
+    def __init__(self, rows, cols, gen, device, budget_gb=64, max_tries=3):
+        import ctypes as C
+
+        import torch
+        from rtlsdr_amd.capi import check, load
+        self.lib = load()
+        self.rows, self.cols = rows, cols
+        pin, pout, apart, tries, ms, walked = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int(), C.c_double(), C.c_size_t()
+        check(self.lib.rtlfm_gpu_place_pair(device, gen.numel(), rows * cols * 2, budget_gb << 30, max_tries, C.byref(pin), C.byref(pout),
+                                            C.byref(apart), C.byref(tries), C.byref(ms), C.byref(walked)), "rtlfm_gpu_place_pair")
+        self.ptr, self.in_ptr, self.apart = pout.value, pin.value, bool(apart.value)
+        self.search_ms, self.walked_mb, self.tries = round(ms.value, 1), walked.value >> 20, tries.value
+        self.iq = torch.as_tensor(_DevMem(self.in_ptr, gen.shape, "|u1"), device=gen.device)
+        assert self.iq.data_ptr() == self.in_ptr
+        self.iq.copy_(gen)
+        torch.cuda.synchronize()
+
+    def free(self):
+        super().free()
+        self.iq = None
+        if self.in_ptr:
+            self.lib.rtlfm_gpu_free(self.in_ptr)
+            self.in_ptr = None
+
+
 def ceiling_leg(job, local_rank):
     """This box's own HBM ceilings (nominal 8 TB/s AND a measured ceiling), same invocation:
     the front end's access pattern without its arithmetic (rtlfm_gpu_bw_probe, bw_probe_kernel.h) over
@@ -813,24 +849,17 @@ class FmJob:
             # the allocator cannot hand the same place out again) and the search runs once more - three tries in all
             # (r04: a first search walked 152 GB in 4.7 s and found nothing; with the input moved the first candidate was apart.
             # Round 5: the search itself is bounded - eight candidates of different sizes, 16 GiB held at most)
-            tries = []
-            # (round 5's last sessions met a box where 15.6 GB of candidates all shared the input's class, twice in a row: the
-            # harness, which has the GPU to itself, lets the first search walk up to 64 GiB - `walked_mb` says what it took -
-            # before it moves anything; the library's own default for a handle's buffers stays 16 GiB)
-            for attempt, budget_gb in enumerate((64, 64, 150)):
-                self.out = ApartRows(S, cap, self.iq.data_ptr(), self.iq.numel(), local_rank, budget_gb)
-                tries.append({"apart": self.out.apart, "search_ms": self.out.search_ms, "walked_mb": self.out.walked_mb, "budget_gb": budget_gb})
-                if self.out.apart or attempt == 2 or a.pmc_child:
-                    break
-                self.out.free()
-                moved = torch.empty_like(self.iq)
-                moved.copy_(self.iq)
-                self._parked.append(self.iq)
-                self.iq = moved
+            # Round 6: the harness owns BOTH sides, so it asks for the pair in one call (rtlfm_gpu_place_pair: the library's own
+            # retry - park the input, take another, search again - in exported form; up to three searches, 64 GiB each here,
+            # where the library's default for a handle's own buffers stays 16 GiB).  The generated input moves into the placed
+            # memory once; run_device only ever sees pointers.
+            self.out = PlacedPair(S, cap, self.iq, local_rank, budget_gb=64, max_tries=1 if a.pmc_child else 3)
+            self.iq = self.out.iq
+            tries = self.out.tries
         self.output_apart = bool(getattr(self.out, "apart", False))
         self.placement = {"search_ms": getattr(self.out, "search_ms", None), "walked_mb": getattr(self.out, "walked_mb", None)}
         if not a.colocate:
-            self.placement["tries"] = tries
+            self.placement.update(searches=tries, budget_gb=64, how="rtlfm_gpu_place_pair: input and output chosen together")
         self.out_len = torch.zeros(S, dtype=torch.int32, device=dev)
         self.local_rank = local_rank
         # u8 I + u8 Q in, int16 PCM out at 1/D (x the resampling ratio)
@@ -877,6 +906,8 @@ class FmJob:
     def close(self):
         self.g.close()
         if hasattr(self.out, "free"):
+            if isinstance(self.out, PlacedPair):
+                self.iq = None  # a view of memory the pair owns
             self.out.free()
         self._parked = []
 
@@ -946,6 +977,22 @@ class PowerJob:
                 floor_ms = valu_insts * 4.0 / (1024 * clk[0] * 1e6) * 1e3
                 out["floor_ms"] = round(floor_ms, 3)
                 out["frac"] = round(floor_ms / launch_ms, 3)
+        # ... and against a count made by hand of what a bit-exact radix-2 fix_fft NEEDS per complex sample (the
+        # figure above is the kernel's own instruction count and says how busy the VALU is, not how few instructions would do).
+        # A butterfly is 4 FIX_MPY - each rounds by itself, so four 16 x 16 multiply-adds whose high halves are the results
+        # (v_mad_i32_i16) - 2 v_perm to gather the four high halves into two packed pairs, one packed multiply-add for
+        # (m1 - m2, m3 + m4), a >> 1 and the packed sum and difference: 10, two points each; the first two stages' twiddles
+        # are real or imaginary (two products less: 7.5 on average); src/rtl_power.c:271-327.  In front: unpack, - 127 - DC,
+        # window (int16 wrap), bit-reversed address: 6 per point (:666-668, 581-596, 697-706); behind: re^2 + im^2 and a
+        # 64-bit add: 3 (:708-716).  LDS reads and writes, waits and scalar work are not VALU instructions.
+        e = self.bin_e
+        hand = 6.0 + (10.0 * (e - 2) + 7.5 * 2) / 2.0 + 3.0
+        out["lane_ops_hand_count"] = round(hand, 1)
+        out["hand_count_what"] = "6 (convert, DC, window, bit-reversed address) + 5 per radix-2 stage (3.75 for the first two) + 3 (|X|^2, int64 add)"
+        if clk:
+            hand_ms = hand * self.samples / 64.0 * 4.0 / (1024 * clk[0] * 1e6) * 1e3
+            out["hand_count_floor_ms"] = round(hand_ms, 3)
+            out["frac_of_hand_count"] = round(hand_ms / launch_ms, 3)
         return out
 
     def describe(self):
@@ -1035,6 +1082,23 @@ def main():
     # figure of the same invocation (0.7225 against 0.7405).  If the caller asks for fewer warm-up steps than 400 (0.3 s), the
     # difference is run first and reported as config.prewarm_steps, so that the K timed steps measure the steady state.
     prewarm = 0 if a.pmc_child else max(0, 400 - a.warmup)
+    # ... and what the K steps measure behind EXACTLY --warmup untimed ones (`cold`), first: the figure a caller who warms up
+    # as the command line says would see; the steady-state figure below stays `value` (say both)
+    cold = None
+    if prewarm and not a.pmc_child:
+        for _ in range(a.warmup):
+            step()
+        fence()
+        job.g.timing_enable(True)
+        job.g.timing_read()
+        tc = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        cold_elapsed = time.perf_counter() - tc
+        c_ms, c_n = job.g.timing_read()
+        job.g.timing_enable(False)
+        cold = (cold_elapsed, c_ms / max(c_n, 1))
     for _ in range(prewarm + a.warmup):
         step()
     fence()
@@ -1170,6 +1234,12 @@ def main():
                 "frac": round(alg_bytes / (s_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "value": round(world * job.samples * n_s / dt / 1e6, 1),
             }
+        if cold:
+            roof["cold"] = {"what": f"the {a.steps} steps timed right behind exactly --warmup = {a.warmup} untimed ones, before the pre-warm "
+                                    f"(the GPU's clock is still ramping: ~50 launches from idle)",
+                            "ms_per_step": round(cold[0] / a.steps * 1e3, 4), "launch_ms": round(cold[1], 4),
+                            "frac": round(alg_bytes / (cold[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "value": round(world * job.samples * a.steps / cold[0] / 1e6, 1)}
         if clock:
             roof["shader_mhz"] = round(clock[0], 0)
             roof["kernel_span_ms"] = round(clock[1], 4)
@@ -1207,6 +1277,13 @@ def main():
             },
             "roofline": roof,
         }
+        # which placement produced the headline, in the open: the searches it took and their budget; the same launch
+        # with its output wherever the allocator puts it is also.ns4096_colocated
+        pl = getattr(job, "placement", None)
+        if pl:
+            res["placement"] = {"output_apart": getattr(job, "output_apart", None), "searches": pl.get("searches"), "budget_gb": pl.get("budget_gb"),
+                                "search_ms": pl.get("search_ms"), "walked_mb": pl.get("walked_mb"), "library_default_budget_gb": 16,
+                                "colocated_frac": (also or {}).get("ns4096_colocated", {}).get("frac") if isinstance(also, dict) else None}
         if also:
             res["also"] = also
         if e2e:

@@ -198,6 +198,10 @@ int rtlfm_gpu_run(rtlfm_gpu *h);
  * is pending).  A caller that gates its producers itself (one that counts queued buffers: host/rtl_fm_hip.cpp) holds
  * its gate around _begin only, so that a callback waits for a flip, never for a transfer, a first run's allocations or
  * a kernel launch.  rtlfm_gpu_run() is _begin followed by _end.
+ * A FAILED _end (a HIP error, -ENOTSUP) loses the buffers _begin took: the producers have been released, the carried state
+ * has not moved on, so the stream now has a gap - what the filters carry no longer matches the input position.  The
+ * handle stays usable, but the caller must start the streams afresh (rtlfm_gpu_reset, or rtlfm_gpu_state_set per stream)
+ * before the next run if continuity matters; results of earlier runs stay fetchable.
  */
 int rtlfm_gpu_run_begin(rtlfm_gpu *h, int *taken);
 int rtlfm_gpu_run_end(rtlfm_gpu *h);
@@ -289,6 +293,11 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   lpr_scalar_stores    1: the resampler's outputs one by one
  *   lpr_chunk            most samples per lane of the one-pass deemph + low_pass_real kernel (default 5440; 256 ... 2^20,
  *                        anything else -EINVAL); shorter runs get shorter chunks so that about 64 K lanes work
+ *   lpr_slim             1 (default): deemph_filter + low_pass_real behind a front end (-M wbfm) as k_lpr_slim_plan + k_deemph_lpr_slim:
+ *                        one-wave workgroups of 32 registers and no LDS, which run as a FIFTH wave per SIMD beside the next
+ *                        step's four front-end waves instead of in the place of one; 0: k_deemph_spec_lpr (round 5)
+ *   lpr_slim_chunk       samples per lane of that kernel (default 6120: 16 chunks per stream and one wave per SIMD at the
+ *                        wbfm shape; 256 ... 2^20)
  *   lpr_ring             1 (default): that kernel's outputs leave through LDS in aligned 64-byte pieces; 0: 16 bytes per lane
  *   squelch_fused        1 (default): rms()'s sums per buffer inside the front end + k_squelch_apply; 0: emit mode + k_squelch_*
  *   adc_separate         1: dc_block_audio as sums / smooth / apply kernels (round 4) instead of sums + k_adc_smooth_apply
@@ -327,6 +336,9 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        -1: this configuration has none / not allocated yet
  *   placement_ms         wall time the placement searches of this handle took, in all
  *   placement_walked_mb  most a search held in temporary allocations (MiB)
+ *   placement_held_mb    what the handle's placed blocks hold NOW (MiB): a search that finds a place returns the candidate
+ *                        itself, which may be a 1, 2 or 4 GiB block for a smaller request (the buffers that belong together
+ *                        share one); a search that finds nothing keeps nothing and the block is exactly the request
  *   poison               1 when RTLFM_POISON=1 was in the environment at the library's first allocation: every device
  *                        allocation of both libraries is filled with 0xA5 and every run / scan first leaves 0xA5 in all of
  *                        every CU's LDS, so that nothing read before it is written goes unnoticed (debug_poison.h;
@@ -422,9 +434,11 @@ int rtlfm_gpu_rotate_90_u8(int device, void *d_buf, size_t len, void *hip_stream
  * `other` with one short bandwidth probe, never more than 16 GiB (rtlfm_gpu_malloc_apart_ex: budget_bytes) or half of
  * the free device memory held at once, typically 5-30 ms; the step that succeeded on a device is tried first the next
  * time in this process.  A winning candidate larger than the request is kept whole (the library asks for the buffers of
- * one handle that belong together as ONE block).  *apart (may be NULL) = 1 when found; otherwise - buffers too small to
- * matter (< 256 MiB streamed), no budget, every candidate in `other`'s class, probe failure - ordinary memory is
- * returned with *apart = 0: the result is always usable, and the caller can see which it got.
+ * one handle that belong together as ONE block; "placement_held_mb" says what a handle's placed blocks hold).  *apart (may
+ * be NULL) = 1 when found; otherwise - buffers too small to matter (< 256 MiB streamed), no budget, every candidate in
+ * `other`'s class, probe failure - every candidate is freed and a plain allocation of exactly `bytes` is returned with
+ * *apart = 0: the result is always usable, nothing of a failed search is kept, and the caller can see which it got.
+ * A decision rests on the MEDIAN of three separately timed probe launches per candidate.
  * The library's own result buffers behind rtlfm_gpu_push() / _run() are placed this way.
  * rtlfm_gpu_placement_probe: 1 if existing buffers `in` / `out` are in different classes, 0 if not (or too
  * small to tell); OVERWRITES the first in_bytes / 16 bytes of `out`.
@@ -439,6 +453,22 @@ int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_
                               void **out, int *apart, double *search_ms, size_t *walked_bytes);
 int rtlfm_gpu_placement_probe(int device, const void *in, size_t in_bytes, void *out, size_t out_bytes,
                               double *read_ms, double *rw_ms);
+/*
+ * The caller owns BOTH sides (a service that allocates its own device input and output for rtlfm_gpu_run_device, on its
+ * own stream or not): one call that chooses the PAIR.  in_bytes of input memory and out_bytes of output memory in
+ * different classes of the HBM: an input is allocated, a bounded search (as rtlfm_gpu_malloc_apart_ex, budget_bytes)
+ * looks for its partner; if every candidate shares the input's class the input itself MOVES - a new one is allocated
+ * while the old one is still held, so that it comes from somewhere else - and the search runs again, up to max_tries
+ * searches (1 ... 8; the library's ring does the same with its own device inputs).  Whatever was only held to push the
+ * allocator on is freed before the call returns.  *in is uninitialised device memory for the caller to fill; both
+ * pointers are released with rtlfm_gpu_free.  *apart = 1 when a pair was found (0: plain allocations, usable all the
+ * same), *tries = searches made, *search_ms / *walked_bytes = wall time and most memory held at once (any may be NULL).
+ * Runs probe launches on the null stream and synchronises the device: call it at set-up, not while samples flow.
+ */
+int rtlfm_gpu_place_pair(int device, size_t in_bytes, size_t out_bytes, size_t budget_bytes, int max_tries,
+                         void **in, void **out, int *apart, int *tries, double *search_ms, size_t *walked_bytes);
+/* bytes from one device buffer to another on `device` (synchronous), for callers without a HIP runtime at hand. */
+int rtlfm_gpu_copy(int device, void *dst, const void *src, size_t bytes);
 int rtlfm_gpu_free(void *p);
 /* NUMA node of the host the device hangs on (sysfs), or -1 if unknown: where the threads that fill the
  * device's staging ring should run. */

@@ -31,8 +31,13 @@ UNIT_HEADERS = {
     "rtlpower_hip.hip": ["debug_poison.h", "dsp_device.h", "power_kernels.h", os.path.join("..", "..", "include", "rtlpower_hip.h"),
                          os.path.join("..", "..", "include", "rtlfm_hip.h")],
 }
+# -ffile-prefix-map: __FILE__ (HIP_TRY's messages) and every other path the compiler embeds are written relative to the
+# repository, so that two checkouts in different directories build the same bytes (a rebuild under /tmp
+# differed from the shipped library in its path strings)
+ROOT = os.path.dirname(HERE)
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
+         f"-ffile-prefix-map={ROOT}=."]
 
 
 def _obj(src: str) -> str:

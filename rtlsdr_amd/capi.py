@@ -209,6 +209,9 @@ _SIGNATURES = [
     ("rtlfm_gpu_malloc_apart_ex", C.c_int, [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, _P(C.c_void_p), _P(C.c_int),
                                             _P(C.c_double), _P(C.c_size_t)]),
     ("rtlfm_gpu_placement_probe", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_double), _P(C.c_double)]),
+    ("rtlfm_gpu_place_pair", C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P(C.c_void_p), _P(C.c_void_p), _P(C.c_int), _P(C.c_int),
+                                       _P(C.c_double), _P(C.c_size_t)]),
+    ("rtlfm_gpu_copy", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("rtlfm_gpu_free", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_device_numa_node", C.c_int, [C.c_int]),
     ("rtlfm_gpu_strerror", C.c_char_p, [C.c_int]),

@@ -65,6 +65,9 @@ struct rtlfm_gpu {
 	DeemphChunk *d_deemph_tab = nullptr;  // time-parallel deemph (k_deemph_scan_*): [nstreams][deemph_chunks]
 	uint32_t *d_deemph_inc = nullptr;
 	LprChunk *d_lpr_chunks = nullptr;     // low_pass_real folded into the replay pass: [nstreams][deemph_chunks]
+	SlimPlan *d_slim_plan = nullptr;      // k_lpr_slim_plan -> k_deemph_lpr_slim: [nstreams * chunks + 64]
+	size_t slim_plan_cap = 0;             // entries
+	int slim_magic_for = 0; uint32_t slim_magic = 0; size_t slim_magic_upto = 0;  // g / chunks as one multiply-high, checked up to slim_magic_upto
 	int32_t *d_arb_i = nullptr;           // k_deemph_spec_arb: (i, frac) of every output of a buffer, [arb_len2]
 	double *d_arb_frac = nullptr;
 	ArbTab *d_arb_tab = nullptr;          // k_deemph_arb_span: the same as one 16-byte entry per output
@@ -118,6 +121,9 @@ struct rtlfm_gpu {
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
+		int lpr_slim = 1;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6); 0: k_deemph_spec_lpr
+		int lpr_slim_prio = 3;      // s_setprio of that kernel's waves (0 .. 3)
+		int lpr_slim_chunk = 6120;  // samples per lane of that kernel: 16 chunks per stream at the wbfm shape = 1024 waves, one per SIMD
 		int verify_twice = 0;  // debug: every run_device runs twice - into a shadow output, then into the caller's - and the two are compared on the device
 	} opt;
 	// verify_twice (round 6): shadow rows / lengths / state, and what the comparisons found so far
@@ -285,6 +291,7 @@ static void init_states_host(std::vector<state_t> &v)
 
 static int create_body(rtlfm_gpu *h);
 static int options_from_env(rtlfm_gpu *h);
+static long placement_held_mb(rtlfm_gpu *h);
 static void ingest_destroy(rtlfm_gpu *h);
 static void ingest_reset(rtlfm_gpu *h);
 
@@ -483,13 +490,17 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 	void *ptrs[] = {h->d_arb_i, h->d_arb_frac, h->d_arb_tab, h->d_deemph_tab, h->d_deemph_inc, h->d_lpr_chunks, h->deepA, h->deepB, h->bufA, h->bufB, h->res[0][0], h->res[0][1], h->res_one_block ? nullptr : (void *)h->res[1][0], h->res[1][1],
 	                h->d_cnt[0], h->d_cnt[1], h->d_cnt2,
 	                h->st[0], h->st[1], h->st[2], h->d_lut, h->d_mute, h->d_levels, h->d_sq_sums, h->d_sums, h->d_adc_sums, h->d_rdc_avg, h->d_adc_avg,
-	                h->vt_out, h->vt_len, h->vt_len2, h->vt_state, h->vt_cnt};
+	                h->vt_out, h->vt_len, h->vt_len2, h->vt_state, h->vt_cnt, h->d_slim_plan};
 	for (void *p : ptrs)
 		if (p) hipFree(p);
 	h->fws.release();
 	ingest_destroy(h);
-	if (h->own_stream) hipStreamDestroy(h->own_stream);
-	if (h->tail_stream) hipStreamDestroy(h->tail_stream);
+	// (RTLFM_KEEP_STREAMS=1, an experiment switch of the soak test: the handle's two streams are leaked instead of destroyed)
+	static const bool keep_streams = [] { const char *e = getenv("RTLFM_KEEP_STREAMS"); return e && *e == '1'; }();
+	if (!keep_streams) {
+		if (h->own_stream) hipStreamDestroy(h->own_stream);
+		if (h->tail_stream) hipStreamDestroy(h->tail_stream);
+	}
 	delete h;
 	return 0;
 }
@@ -592,7 +603,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
 		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
-		{"verify_twice", &h->opt.verify_twice},
+		{"verify_twice", &h->opt.verify_twice}, {"lpr_slim", &h->opt.lpr_slim}, {"lpr_slim_chunk", &h->opt.lpr_slim_chunk}, {"lpr_slim_prio", &h->opt.lpr_slim_prio},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -632,7 +643,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if (!strcmp(name, "apart_budget_gb") && (value < 0 || value > 256)) return -EINVAL;
 	if ((!strcmp(name, "box_store") || !strcmp(name, "fused_store")) && (value < -1 || value > 1)) return -EINVAL;
 	// the chunk tables of the one-pass deemph + low_pass_real kernel are sized from it: keep it in a sane range
-	if (!strcmp(name, "lpr_chunk") && (value < 256 || value > (1 << 20))) return -EINVAL;
+	if ((!strcmp(name, "lpr_chunk") || !strcmp(name, "lpr_slim_chunk")) && (value < 256 || value > (1 << 20))) return -EINVAL;
 	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;
 	// ... then what an accepted value implies
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
@@ -655,8 +666,20 @@ extern "C" int rtlfm_gpu_get_option(rtlfm_gpu *h, const char *name, long *value)
 	if (!strcmp(name, "deep_apart")) { *value = h->place.deep_apart; return 0; }
 	if (!strcmp(name, "placement_ms")) { *value = (long)(h->place.search_ms + 0.5); return 0; }
 	if (!strcmp(name, "placement_walked_mb")) { *value = (long)(h->place.walked_peak >> 20); return 0; }
+	if (!strcmp(name, "placement_held_mb")) { *value = placement_held_mb(h); return 0; }
 	if (!strcmp(name, "verify_mismatches")) { *value = h->vt_mismatches; return 0; }  // verify_twice: runs whose two executions differed
 	if (!strcmp(name, "verify_runs")) { *value = h->vt_runs; return 0; }
+	// debugging (tests/test_soak_gpu.py): the host addresses of the runtime objects the handle owns - a hipStream_t / hipEvent_t
+	// IS the address of the runtime's object, which the runtime frees when the handle is destroyed
+	if (!strcmp(name, "dbg_own_stream")) { *value = (long)(uintptr_t)h->own_stream; return 0; }
+	if (!strcmp(name, "dbg_tail_stream")) { *value = (long)(uintptr_t)h->tail_stream; return 0; }
+	if (!strncmp(name, "dbg_event", 9) && name[9] >= '0' && name[9] <= '5' && !name[10]) {
+		const hipEvent_t ev[6] = {h->ev_wait, h->ev_release, h->ev_front[0], h->ev_front[1], h->ev_tail[0], h->ev_tail[1]};
+		*value = (long)(uintptr_t)ev[name[9] - '0'];
+		return 0;
+	}
+	if (!strcmp(name, "dbg_handle")) { *value = (long)(uintptr_t)h; return 0; }
+	if (!strcmp(name, "dbg_handle_bytes")) { *value = (long)sizeof(*h); return 0; }
 	int *slot = option_slot(h, name);
 	if (!slot) return -ENOENT;
 	*value = *slot;
@@ -1009,7 +1032,8 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				// fewer samples in all, shorter chunks - about 64 K lanes again, never so short that the settling (W samples
 				// walked twice per chunk) outweighs the chunk (256 streams of rtl_fm -s 48k -r 24k -E deemp: 294 waves on 1024
 				// SIMDs took 1.45 ms for 102 M samples)
-				int Lwant = h->opt.lpr_chunk;  // 256 .. 2^20 (rtlfm_gpu_set_option)
+				const bool slim = h->opt.lpr_slim != 0;
+				int Lwant = slim ? h->opt.lpr_slim_chunk : h->opt.lpr_chunk;  // 256 .. 2^20 (rtlfm_gpu_set_option)
 				{
 					long long fit = (long long)S * T / 65536;
 					const long long lo = 6ll * Ws > 512 ? 6ll * Ws : 512;
@@ -1036,6 +1060,40 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 					} else {
 						if (per <= Lwant) Ls = (int)(per * ((Lwant + per / 2) / per));
 						mcsp = T / Ls + 2;
+					}
+				}
+				if (slim) {
+					// Round 6: the tail as a FIFTH wave per SIMD beside the next step's front end (staged_kernels.h, k_deemph_lpr_slim):
+					// the plan - every lane's stretch, the run's totals - by a small kernel in front, then one-wave workgroups of
+					// 32 registers and no LDS.  g / chunks is a multiply-high whose magic number is checked over the whole grid once.
+					const size_t lanes_all = (size_t)S * mcsp;
+					if (lanes_all + 64 < (1ull << 31)) {
+						if (h->slim_magic_for != mcsp || h->slim_magic_upto < lanes_all + 64) {
+							const uint32_t M = (uint32_t)(0x100000000ull / (uint32_t)mcsp) + 1u;
+							bool ok = true;
+							for (uint64_t g = 0; g < lanes_all + 64 && ok; g++) ok = (uint32_t)((g * M) >> 32) == (uint32_t)(g / (uint32_t)mcsp);
+							h->slim_magic_for = ok ? mcsp : -1; h->slim_magic = M; h->slim_magic_upto = lanes_all + 64;
+						}
+						if (h->slim_magic_for == mcsp) {
+							if (lanes_all + 64 > h->slim_plan_cap) {
+								if (h->d_slim_plan) { HIP_TRY(hipStreamSynchronize(q)); HIP_TRY(hipFree(h->d_slim_plan)); }
+								h->d_slim_plan = nullptr; h->slim_plan_cap = 0;
+								HIP_TRY(hipMalloc(&h->d_slim_plan, (lanes_all + 64) * sizeof(SlimPlan)));
+								h->slim_plan_cap = lanes_all + 64;
+							}
+							next_dst(&lpr_dst, &lpr_ds);
+							if (lpr_dst != final_dst) return -EFAULT;  // routing bug
+							const int vec16 = (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
+							const unsigned gw = (unsigned)((lanes_all + 63) / 64);
+							k_lpr_slim_plan<<<gw, 64, 0, q>>>(cur, cur_stride, T, cnt, S, c.deemph_a, mcsp, Ls, lpr_dst, lpr_ds, c.rate_out, c.rate_out2,
+							                                 sin, sout, cnt_dst, h->d_slim_plan);
+#define RTLFM_LPR_SLIM(MM) k_deemph_lpr_slim<MM><<<gw, 64, 0, q>>>(cur, cur_stride, S, st, mcsp, h->slim_magic, Ws, lpr_dst, lpr_ds, c.rate_out, c.rate_out2, \
+							sin, sout, vec16, h->d_slim_plan, h->opt.lpr_slim_prio)
+							if (M == 2) RTLFM_LPR_SLIM(2); else if (M == 1) RTLFM_LPR_SLIM(1); else RTLFM_LPR_SLIM(0);
+#undef RTLFM_LPR_SLIM
+							RTLFM_DBG_SYNC("one pass (lpr, slim)");
+							return 0;
+						}
 					}
 				}
 				if ((size_t)mcsp > (size_t)h->lpr_chunks_cap) {
@@ -1202,7 +1260,7 @@ static int run_irregular_rest(rtlfm_gpu *h, const uint32_t *cur, size_t xstride,
 	ip.levels = (c.squelch_level || c.report_levels) ? h->d_levels : nullptr;
 	ip.sin = h->st[h->st_cur]; ip.sout = h->st[(h->st_cur + 1) % 3];
 	if (2 * ip.n_in + 8 > kIrregularMaxElems) return -ENOTSUP;
-	k_fifth_irregular<<<(unsigned)((S + 63) / 64), 64, 0, q>>>(ip);
+	k_fifth_irregular<<<(unsigned)S, 64, 0, q>>>(ip);  // one wave per stream
 	if (c.mode == RTLFM_MODE_RAW) {
 		if (d_out_len) k_fill_cnt<<<grid_for(S, 64), 64, 0, q>>>(d_out_len, S, nblocks * ip.lp_len);
 		return 0;
@@ -1447,13 +1505,14 @@ static int run_fused_emit(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_strid
 		if (r0 < 0) return r0;
 	}
 	TailPlan tp = plan_tail(h, nblocks);
-	if (tp.any()) {
+	if (tp.any() && !raw_direct) {  // (-M raw has no audio tail: full_demod returns behind raw_demod, src/rtl_fm.c:1257-1259)
 		int r = ensure_res_buffers(h, d_iq, iq_extent(h, stream_stride, nblocks));
 		if (r < 0) return r;
 	}
 	std::pair<hipEvent_t, hipEvent_t> ev;
 	int r = timing_begin(h, ev);
 	if (r < 0) return r;
+	h->fws.tail_follows = !raw_direct;  // kernels follow on this stream and, with a tail, on the tail's (as run_boxfused_emit)
 	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);  // -E rdc in front of -M raw, the squelch, 7-10 passes
 	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, nullptr, 0, sin, sout, h->d_lut, q,
 	                  raw_direct ? reinterpret_cast<uint32_t *>(d_out) : h->deepA, raw_direct ? out_stride / 2 : h->deep_stride, rdc);
@@ -1873,6 +1932,23 @@ struct Ingest {
 };
 
 static std::mutex g_ingest_alloc_mu;
+
+// what the handle's placed blocks really hold (a winning candidate of a placement search may be larger than the request:
+// rtlfm_gpu_malloc_apart_ex): the ring's result block(s), the audio tail's work buffers, the emit mode's buffer
+static size_t alloc_size(const void *p)
+{
+	hipDeviceptr_t base = nullptr;
+	size_t size = 0;
+	if (!p || hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return size;
+}
+static long placement_held_mb(rtlfm_gpu *h)
+{
+	size_t b = alloc_size(h->res[0][0]) + (h->res_one_block ? 0 : alloc_size(h->res[1][0])) + alloc_size(h->deepA);
+	if (Ingest *in = __atomic_load_n(&h->ing, __ATOMIC_ACQUIRE))
+		b += alloc_size(in->d_result[0]) + (in->result_one_block ? 0 : alloc_size(in->d_result[1]));
+	return (long)(b >> 20);
+}
 
 static void ingest_free(Ingest *in)
 {
@@ -2490,7 +2566,7 @@ struct ProbeRig {
 	}
 	// ms per launch: `region` bytes of `in` streamed by 8192 waves, W bytes stored per lane and tile into `out`
 	// (region / 8192 * 64 * W / 8192 ... = region * W / 128 bytes in all)
-	int run(const uint8_t *in, size_t region, uint8_t *out, int W, int reps, float *ms, int warm = 3)
+	int run(const uint8_t *in, size_t region, uint8_t *out, int W, int reps, float *ms, int warm = 3, bool median = false)
 	{
 		const int waves = 8192;
 		const size_t seg = (region / waves) & ~(size_t)8191;
@@ -2505,6 +2581,21 @@ struct ProbeRig {
 			}
 		};
 		for (int i = 0; i < warm; i++) go();  // clocks, TLBs
+		if (median) {
+			// a decision rests on this number (rtlfm_gpu_malloc_apart_ex): every launch timed by itself, the median taken -
+			// one launch that met another tenant's burst or a clock step does not decide
+			float t[9];
+			if (reps > 9) reps = 9;
+			for (int i = 0; i < reps; i++) {
+				if (hipEventRecord(a, 0) != hipSuccess) return -EIO;
+				go();
+				if (hipEventRecord(b, 0) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return -EIO;
+				if (hipEventElapsedTime(&t[i], a, b) != hipSuccess) return -EIO;
+			}
+			std::sort(t, t + reps);
+			*ms = t[reps / 2];
+			return hipGetLastError() == hipSuccess ? 0 : -EIO;
+		}
 		if (hipEventRecord(a, 0) != hipSuccess) return -EIO;
 		for (int i = 0; i < reps; i++) go();
 		if (hipEventRecord(b, 0) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return -EIO;
@@ -2542,10 +2633,12 @@ std::atomic<int> g_recipe[64];  // per device: 1 + the step that won last, 0 = n
 // Device memory for a WRITE stream that is to run next to the read stream of `other` (the output of
 // rtlfm_gpu_run_device next to its input): `bytes` in another class of the HBM than `other` (see above).
 // Candidates are allocated and timed against `other` with the bandwidth probe (read only once, then read + write per
-// candidate: one warm-up launch and two timed ones); those that share its class are kept until the search ends, so
-// that the allocator moves on, and everything but the winner is freed.  *apart = 1 when a place away from `other` was
-// found, 0 when the buffers are too small for it to matter (< 256 MiB streamed), the search ran out of its budget, or
-// the probe failed - the memory returned is good device memory in every case.  `other` is only read.
+// candidate: one warm-up launch and the MEDIAN of three timed ones); those that share its class are kept until the search
+// ends, so that the allocator moves on, and everything but the winner is freed.  *apart = 1 when a place away from
+// `other` was found - the block returned may then be LARGER than `bytes` (the candidate itself: 1, 2 or 4 GiB; the
+// handle's "placement_held_mb" says what its placed blocks really hold) -, 0 when the buffers are too small for it to
+// matter (< 256 MiB streamed), the search ran out of its budget, or the probe failed: then the memory returned is a plain
+// allocation of exactly `bytes` and nothing of the search is kept.  `other` is only read.
 // budget_bytes: the most the search may hold at any time, winner included (0 = no search at all).
 extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *other, size_t other_bytes, size_t budget_bytes,
                                          void **out, int *apart, double *search_ms, size_t *walked_bytes)
@@ -2577,7 +2670,7 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 	if (r < 0) return r;
 	HIP_TRY(hipDeviceSynchronize());
 	float rd = 0;
-	if ((r = rig.run((const uint8_t *)other, region, nullptr, 0, 3, &rd, 2)) < 0) return r;
+	if ((r = rig.run((const uint8_t *)other, region, nullptr, 0, 3, &rd, 2, true)) < 0) return r;
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	// never more than half of what is free: the device may have other tenants, whose next allocation must not fail
@@ -2612,7 +2705,7 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 		held += cb;
 		if (held > clk.peak) clk.peak = held;
 		float rw = 0;
-		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 2, &rw, 1) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
+		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 3, &rw, 1, true) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
 		if (rw < kApartRatio * rd) { win = p; won_step = step; break; }
 		cand.push_back(p); cand_rw.push_back(rw);
 	}
@@ -2627,26 +2720,21 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 		held += cb;
 		if (held > clk.peak) clk.peak = held;
 		float rw = 0;
-		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 2, &rw, 1) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
+		if (rig.run((const uint8_t *)other, region, (uint8_t *)p, 8, 3, &rw, 1, true) < 0) { cand.push_back(p); cand_rw.push_back(1e30f); break; }
 		if (rw < kApartRatio * rd) { win = p; break; }
 		cand.push_back(p); cand_rw.push_back(rw);
 	}
-	// no candidate under the threshold (a noisy box, or every candidate the budget allowed shares the input's class): the
-	// one that measured fastest is still the best place there is
-	if (!win && !cand.empty()) {
-		size_t best = 0;
-		for (size_t i = 1; i < cand.size(); i++)
-			if (cand_rw[i] < cand_rw[best]) best = i;
-		win = cand[best];
-		cand[best] = nullptr;
-		if (apart) *apart = 0;
-	} else if (win) {
+	// No candidate under the threshold (every candidate the budget allowed shares the input's class): nothing was found, so
+	// nothing of the search is kept - until round 5 the fastest candidate was returned, possibly a 4 GiB block for a request
+	// of a few hundred MiB, pinned for the handle's life and buying nothing.  Every candidate is freed and the
+	// caller gets a plain allocation of exactly `bytes`, *apart = 0.
+	if (win) {
 		if (apart) *apart = 1;
 		if (device < 64) g_recipe[device].store(won_step + 1, std::memory_order_relaxed);
 	}
 	for (void *c : cand)
 		if (c) hipFree(c);
-	if (!win) HIP_TRY(hipMalloc(&win, bytes));  // (nothing could be allocated at any candidate size)
+	if (!win) HIP_TRY(hipMalloc(&win, bytes));
 	*out = win;
 	return 0;
 }
@@ -2654,6 +2742,66 @@ extern "C" int rtlfm_gpu_malloc_apart_ex(int device, size_t bytes, const void *o
 extern "C" int rtlfm_gpu_malloc_apart(int device, size_t bytes, const void *other, size_t other_bytes, void **out, int *apart)
 {
 	return rtlfm_gpu_malloc_apart_ex(device, bytes, other, other_bytes, kApartBudgetDefault, out, apart, nullptr, nullptr);
+}
+
+// The caller owns both sides: choose the pair (include/rtlfm_hip.h).  The ring's own retry (ingest_build) in exported form.
+extern "C" int rtlfm_gpu_place_pair(int device, size_t in_bytes, size_t out_bytes, size_t budget_bytes, int max_tries,
+                                    void **in, void **out, int *apart, int *tries, double *search_ms, size_t *walked_bytes)
+{
+	if (!in || !out || !in_bytes || !out_bytes || max_tries < 1 || max_tries > 8) return -EINVAL;
+	if (apart) *apart = 0;
+	if (tries) *tries = 0;
+	if (search_ms) *search_ms = 0;
+	if (walked_bytes) *walked_bytes = 0;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	std::vector<void *> parked;  // inputs that found no partner: held until the end, so that the next one lies elsewhere
+	size_t parked_bytes = 0;
+	void *cur_in = nullptr, *cur_out = nullptr;
+	int rc = 0, found = 0, n = 0;
+	double ms_all = 0;
+	size_t peak = 0;
+	for (; n < max_tries; ) {
+		if (hipMalloc(&cur_in, in_bytes) != hipSuccess) { (void)hipGetLastError(); cur_in = nullptr; rc = parked.empty() ? -ENOMEM : 0; break; }
+		double ms = 0; size_t walked = 0; int ap = 0;
+		rc = rtlfm_gpu_malloc_apart_ex(device, out_bytes, cur_in, in_bytes, budget_bytes, &cur_out, &ap, &ms, &walked);
+		n++;
+		ms_all += ms;
+		if (walked + parked_bytes + in_bytes > peak) peak = walked + parked_bytes + in_bytes;
+		if (rc < 0) break;
+		if (ap || walked == 0 || n == max_tries) { found = ap; break; }  // walked == 0: no search was made (too small, no budget)
+		(void)hipFree(cur_out); cur_out = nullptr;
+		parked.push_back(cur_in); parked_bytes += in_bytes;
+		cur_in = nullptr;
+	}
+	if (rc == 0 && !cur_in && !parked.empty()) {
+		// no memory left for another input: the last parked one is as good as any
+		cur_in = parked.back(); parked.pop_back();
+		if (hipMalloc(&cur_out, out_bytes) != hipSuccess) { (void)hipGetLastError(); rc = -ENOMEM; }
+	}
+	for (void *q : parked) (void)hipFree(q);
+	if (rc < 0) {
+		if (cur_in) (void)hipFree(cur_in);
+		if (cur_out) (void)hipFree(cur_out);
+		return rc;
+	}
+	*in = cur_in; *out = cur_out;
+	if (apart) *apart = found;
+	if (tries) *tries = n;
+	if (search_ms) *search_ms = ms_all;
+	if (walked_bytes) *walked_bytes = peak;
+	return 0;
+}
+
+extern "C" int rtlfm_gpu_copy(int device, void *dst, const void *src, size_t bytes)
+{
+	if (!dst || !src) return -EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+	return 0;
 }
 
 // Are two existing buffers a quarter apart?  1 = yes, 0 = no / too small to tell; `in` is read,

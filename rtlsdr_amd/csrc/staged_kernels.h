@@ -690,17 +690,27 @@ __global__ void __launch_bounds__(256) k_deep_rest(const DeepRestParams p)
 	}
 }
 
-// ---- fifth_order on lengths its passes do not divide (round 5) -------------------------------------------------
+// ---- fifth_order on lengths its passes do not divide (round 5; lane-parallel since round 6) --------------------
 // `rtl_fm -W n -F 9` with nine or ten passes and n odd (n % 4 != 0 for ten) is something the reference runs
-// (src/rtl_fm.c:1188-1191): pass 8 (or 9) is then called with a length that is not a multiple of four elements - it
-// produces ceil(length / 4) outputs per component from whatever the array holds, the Q call (`lowpassed + 1,
-// length - 1`) sees another count than the I call, the last passes stop decimating, and everything behind them
-// (generic_fir, rms, the demodulators, fm_demod's pre_r / pre_j) works on an ODD number of elements and pairs I with Q
-// of different samples.  None of that is arithmetic worth parallelising - a buffer is down to at most 512 samples
-// there - and all of it is defined by the reference's loops over its `lowpassed` array, so those loops are what runs
-// here: one lane per stream walks its buffers in order with the array in private memory, from the first pass whose
-// length is not a multiple of four to mode_demod().  The regular passes in front (k_fused emit / k_fifth) and the
-// audio tail behind (run_tail, result_len = lp_len / 2 per buffer) are the ordinary kernels.
+// (src/rtl_fm.c:1188-1191): pass 8 (or 9) is then called with a length that is not a multiple of four elements.  What
+// the reference's loops then DO, as functions of the `lowpassed` array they are handed (derived from :777-831, not
+// copied from them):
+//   * one fifth_order call on (data, length, hist) works on the component x[k] = data[2k] and produces
+//     count = max(1, ceil(length / 4)) outputs y[m] = (x[2m-5] + 5 x[2m-4] + 10 x[2m-3] + 10 x[2m-2] + 5 x[2m-1] + x[2m]) >> 4
+//     into data[2m], x[-5..-1] = hist[1..5]; it reads every input before the position is overwritten (it writes data[2m]
+//     and has then read up to data[4m]), so "all lanes read, then all lanes write" on the one array IS the loop; the archive
+//     it leaves is x[2M-5 .. 2M] of its last output M.  The first output is unconditional - a call with length <= 0 (the Q
+//     call of a one-element buffer) still reads data[0], writes it and moves the history on;
+//   * the Q call (`lowpassed + 1, length - 1`) sees another count than the I call, the last passes stop decimating, and
+//     everything behind them works on an ODD number of elements: generic_fir yields ceil(len / 2) outputs per call, each
+//     the tap sum over the nine inputs BEFORE it (original values: the history holds them), rms() sums lp_len elements,
+//     the demodulators pair lowpassed[i] with lowpassed[i + 1] - I with the Q of another sample, or with whatever the array
+//     holds behind lp_len -, fm_demod's pre_r / pre_j are the array's last two elements.
+// So the array itself, with what earlier passes and buffers left in it, is part of the semantics: it lives in LDS, one
+// WAVE per stream walks the stream's buffers in order (the history chains them), and every stage is a lane-parallel
+// pass over it - a lane per output, the repo's own window forms (fifth_tap, fir9_tap, discriminate) - with a barrier
+// between its reads and its writes.  A buffer is down to at most 512 samples here.  The regular passes in front
+// (k_fused emit / k_fifth) and the audio tail behind (run_tail, result_len = lp_len / 2 per buffer) are the ordinary kernels.
 constexpr int kIrregularMaxElems = 1024 + 16;  // block_len >> 8 elements at most (RTLFM_MAX_BLOCK_LEN = 262144)
 struct IrregularParams {
 	const uint32_t *X; size_t xstride;  // packed (I, Q) of the level in front of pass `first`: n_in samples per buffer
@@ -714,100 +724,147 @@ struct IrregularParams {
 	const state_t *sin; state_t *sout;
 };
 
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v = (int)((uint32_t)v + (uint32_t)__shfl_xor(v, off));
+	return v;
+}
+
 __global__ void __launch_bounds__(64) k_fifth_irregular(const IrregularParams p)
 {
-	const int s = (int)(blockIdx.x * 64 + threadIdx.x);
+	const int s = (int)blockIdx.x, lane = (int)threadIdx.x;  // one wave per stream
 	if (s >= p.nstreams) return;
-	int16_t lp[kIrregularMaxElems];
+	__shared__ int16_t lp[kIrregularMaxElems + 8];
+	__shared__ int16_t hist[2][RTLFM_MAX_PASSES][6];  // [I / Q][pass]: lp_i_hist / lp_q_hist
+	__shared__ int16_t droop[2][9];
+	__shared__ int carry[3];                           // pre_r, pre_j, squelch_hits
 	const state_t &in = p.sin[s];
 	state_t &out = p.sout[s];
-	int16_t hi[RTLFM_MAX_PASSES][6], hq[RTLFM_MAX_PASSES][6], di[9], dq[9];
-	for (int q = p.first; q < p.passes; q++)
-		for (int j = 0; j < 6; j++) { hi[q][j] = in.lp_i_hist[q][j]; hq[q][j] = in.lp_q_hist[q][j]; }
-	for (int j = 0; j < 9; j++) { di[j] = in.droop_i_hist[j]; dq[j] = in.droop_q_hist[j]; }
-	int pre_r = in.pre_r, pre_j = in.pre_j, hits = in.squelch_hits;
-	// fifth_order(), src/rtl_fm.c:777-806, as it is
-	auto fifth = [&](int16_t *data, int length, int16_t *hist) {
-		int a = hist[1], b = hist[2], c = hist[3], d = hist[4], e = hist[5], f = data[0];
-		data[0] = (int16_t)((a + (b + e) * 5 + (c + d) * 10 + f) >> 4);
-		for (int i = 4; i < length; i += 4) {
-			a = c; b = d; c = e; d = f;
-			e = data[i - 2];
-			f = data[i];
-			data[i / 2] = (int16_t)((a + (b + e) * 5 + (c + d) * 10 + f) >> 4);
+	for (int k = lane; k < 6 * (p.passes - p.first); k += 64) {
+		const int q = p.first + k / 6, j = k % 6;
+		hist[0][q][j] = in.lp_i_hist[q][j]; hist[1][q][j] = in.lp_q_hist[q][j];
+	}
+	if (lane < 9) { droop[0][lane] = in.droop_i_hist[lane]; droop[1][lane] = in.droop_q_hist[lane]; }
+	if (lane == 0) { carry[0] = in.pre_r; carry[1] = in.pre_j; carry[2] = in.squelch_hits; }
+	for (int k = lane; k < kIrregularMaxElems + 8; k += 64) lp[k] = 0;
+	__syncthreads();
+	constexpr int kPer5 = (kIrregularMaxElems / 4 + 63) / 64 + 1;  // outputs of one fifth_order call per lane
+	constexpr int kPer9 = (kIrregularMaxElems / 2 + 63) / 64 + 1;  // ... of one generic_fir call
+	// one fifth_order call: component x[k] = data[2k], x[-5..-1] = h[1..5]
+	auto fifth = [&](int16_t *data, int length, int16_t *h) {
+		const int count = length > 0 ? (length + 3) / 4 : 1;
+		auto X = [&](int k) -> int { return k < 0 ? (int)h[6 + k] : (int)data[2 * k]; };
+		int y[kPer5];
+#pragma unroll
+		for (int r = 0; r < kPer5; r++) {
+			const int m = lane + 64 * r;
+			y[r] = m < count ? fifth_tap(X(2 * m - 5), X(2 * m - 4), X(2 * m - 3), X(2 * m - 2), X(2 * m - 1), X(2 * m)) : 0;
 		}
-		hist[0] = (int16_t)a; hist[1] = (int16_t)b; hist[2] = (int16_t)c; hist[3] = (int16_t)d; hist[4] = (int16_t)e; hist[5] = (int16_t)f;
+		int16_t keep = 0;  // the archive: x[2M - 5 + lane] of the call's last output M, lanes 0..5
+		if (lane < 6) keep = (int16_t)X(2 * (count - 1) - 5 + lane);
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < kPer5; r++) {
+			const int m = lane + 64 * r;
+			if (m < count) data[2 * m] = (int16_t)y[r];
+		}
+		if (lane < 6) h[lane] = keep;
+		__syncthreads();
 	};
-	// generic_fir(), :808-831
-	auto fir9 = [&](int16_t *data, int length, int16_t *hist) {
+	// one generic_fir call: output k (of ceil(length / 2)) = taps over x[k-9 .. k-1], x[-9..-1] = h[0..8]
+	auto fir9 = [&](int16_t *data, int length, int16_t *h) {
+		const int count = length > 0 ? (length + 1) / 2 : 0;
+		auto X = [&](int k) -> int { return k < 0 ? (int)h[9 + k] : (int)data[2 * k]; };
 		const int32_t *t = k_cic9[p.passes];
-		for (int d = 0; d < length; d += 2) {
-			const int16_t temp = data[d];
-			int h[9];
-			for (int j = 0; j < 9; j++) h[j] = hist[j];
-			data[d] = (int16_t)fir9_tap(h, t);
-			for (int j = 0; j < 8; j++) hist[j] = hist[j + 1];
-			hist[8] = temp;
+		int y[kPer9];
+#pragma unroll
+		for (int r = 0; r < kPer9; r++) {
+			const int k = lane + 64 * r;
+			int w[9];
+#pragma unroll
+			for (int j = 0; j < 9; j++) w[j] = k < count ? X(k - 9 + j) : 0;
+			y[r] = fir9_tap(w, t);
 		}
+		int16_t keep = 0;  // the last nine of (history, x[0 .. count - 1])
+		if (lane < 9) keep = (int16_t)X(count - 9 + lane);
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < kPer9; r++) {
+			const int k = lane + 64 * r;
+			if (k < count) data[2 * k] = (int16_t)y[r];
+		}
+		if (lane < 9) h[lane] = keep;
+		__syncthreads();
 	};
 	const int len0 = 2 * p.n_in;  // elements pass `first` is given
-	const int n_res = p.mode == RTLFM_MODE_RAW ? p.lp_len : p.lp_len / 2;
+	const int lp_len = p.lp_len;
+	const int n_res = p.mode == RTLFM_MODE_RAW ? lp_len : lp_len / 2;
 	for (int b = 0; b < p.nblocks; b++) {
 		const uint32_t *x = p.X + (size_t)s * p.xstride + (size_t)b * p.n_in;
-		for (int k = 0; k < p.n_in; k++) { const iq16 w = unpack_iq(x[k]); lp[2 * k] = w.i; lp[2 * k + 1] = w.q; }
-		for (int k = len0; k < len0 + 8; k++) lp[k] = 0;
-		for (int q = p.first; q < p.passes; q++) {
+		for (int k = lane; k < p.n_in; k += 64) { const iq16 w = unpack_iq(x[k]); lp[2 * k] = w.i; lp[2 * k + 1] = w.q; }
+		if (lane < 8) lp[len0 + lane] = 0;  // what the oracle's array holds behind a buffer's elements
+		__syncthreads();
+		for (int q = p.first; q < p.passes; q++) {  // :1188-1191
 			const int length = len0 >> (q - p.first);
-			fifth(lp, length, hi[q]);
-			fifth(lp + 1, length - 1, hq[q]);
+			fifth(lp, length, hist[0][q]);
+			fifth(lp + 1, length - 1, hist[1][q]);
 		}
-		const int lp_len = p.lp_len;
 		if (p.fir) {  // :1193-1199
-			fir9(lp, lp_len, di);
-			fir9(lp + 1, lp_len - 1, dq);
+			fir9(lp, lp_len, droop[0]);
+			fir9(lp + 1, lp_len - 1, droop[1]);
 		}
 		if ((p.squelch_level || p.report_levels) && lp_len > 0) {
-			// rms(), :1083-1112, and the squelch, :1204-1215
-			uint32_t pw = 0; int32_t t = 0;
-			int step = 1;
-			while (lp_len > step * 32768) ++step;
-			for (int i = 0; i < lp_len; i += step) { const int v = lp[i]; t = (int32_t)((uint32_t)t + (uint32_t)v); pw += (uint32_t)(v * v); }
+			// rms() over the buffer's lp_len elements (:1083-1112; at most 1024 here, so its step is 1) and the squelch, :1204-1215
+			int t = 0, pw = 0;
+			for (int i = lane; i < lp_len; i += 64) { const int v = lp[i]; t = (int)((uint32_t)t + (uint32_t)v); pw = (int)((uint32_t)pw + (uint32_t)(v * v)); }
+			t = wave_sum_i32(t);
+			const uint32_t pwu = (uint32_t)wave_sum_i32(pw);
 			double r;
-			if (p.omit_dc_fix) r = sqrt((double)pw / (lp_len / step));
+			if (p.omit_dc_fix) r = sqrt((double)pwu / lp_len);
 			else {
-				const double dc = (double)(int32_t)((uint32_t)t * (uint32_t)step) / (double)lp_len;
+				const double dc = (double)t / (double)lp_len;
 				const double err = t * 2 * dc - dc * dc * lp_len;
-				r = sqrt((pw - err) / lp_len);
+				r = sqrt((pwu - err) / lp_len);
 			}
 			const int sr = r == r ? (int)r : INT32_MIN;  // (int)NaN is INT_MIN on the reference's machine: the squelch skips it
-			if (p.levels) p.levels[(size_t)s * p.nblocks + b] = sr;
-			if (p.squelch_level && sr >= 0) {
-				if (sr < p.squelch_level) { hits++; for (int i = 0; i < lp_len; i++) lp[i] = 0; }
-				else hits = 0;
+			if (lane == 0 && p.levels) p.levels[(size_t)s * p.nblocks + b] = sr;
+			if (p.squelch_level && sr >= 0) {  // wave-uniform
+				const bool mute = sr < p.squelch_level;
+				if (mute) for (int i = lane; i < lp_len; i += 64) lp[i] = 0;
+				if (lane == 0) carry[2] = mute ? carry[2] + 1 : 0;
 			}
+			__syncthreads();
 		}
 		int16_t *res = p.R + (size_t)s * p.rstride + (size_t)b * n_res;
 		if (p.mode == RTLFM_MODE_FM) {
-			// fm_demod(), :932-959; with fewer than two elements the reference reads lowpassed[-1]: nothing is produced
+			// fm_demod(), :932-959: output k pairs elements (2k, 2k + 1) with (2k - 2, 2k - 1); the first one with the carried
+			// pair and always polar_discriminant.  With fewer than two elements the reference reads lowpassed[-1]: nothing is produced
 			if (lp_len >= 2) {
-				res[0] = (int16_t)disc_std(lp[0], lp[1], pre_r, pre_j);
-				for (int i = 2; i < lp_len - 1; i += 2)
-					res[i / 2] = (int16_t)discriminate(p.variant, lp[i], lp[i + 1], lp[i - 2], lp[i - 1], p.lut);
-				pre_r = lp[lp_len - 2]; pre_j = lp[lp_len - 1];
+				if (lane == 0) res[0] = (int16_t)disc_std(lp[0], lp[1], carry[0], carry[1]);
+				for (int k = 1 + lane; 2 * k < lp_len - 1; k += 64)
+					res[k] = (int16_t)discriminate(p.variant, lp[2 * k], lp[2 * k + 1], lp[2 * k - 2], lp[2 * k - 1], p.lut);
+				__syncthreads();
+				if (lane == 0) { carry[0] = lp[lp_len - 2]; carry[1] = lp[lp_len - 1]; }
 			}
 		} else if (p.mode == RTLFM_MODE_RAW) {
-			for (int i = 0; i < lp_len; i++) res[i] = lp[i];
+			for (int i = lane; i < lp_len; i += 64) res[i] = lp[i];
 		} else {
-			// am_demod / usb_demod / lsb_demod, :961-1000: pairs (lp[i], lp[i + 1]) for i = 0, 2, ... < lp_len
-			for (int i = 0; i < lp_len; i += 2)
-				if (i / 2 < n_res) res[i / 2] = simple_demod(p.mode, pack_iq(lp[i], lp[i + 1]), p.output_scale);
+			// am_demod / usb_demod / lsb_demod, :961-1000: pairs (i, i + 1) for i = 0, 2, ... < lp_len
+			for (int k = lane; 2 * k < lp_len; k += 64)
+				if (k < n_res) res[k] = simple_demod(p.mode, pack_iq(lp[2 * k], lp[2 * k + 1]), p.output_scale);
 		}
+		__syncthreads();
 	}
-	for (int q = p.first; q < p.passes; q++)
-		for (int j = 0; j < 6; j++) { out.lp_i_hist[q][j] = hi[q][j]; out.lp_q_hist[q][j] = hq[q][j]; }
-	for (int j = 0; j < 9; j++) { out.droop_i_hist[j] = di[j]; out.droop_q_hist[j] = dq[j]; }
-	if (p.mode == RTLFM_MODE_FM) { out.pre_r = pre_r; out.pre_j = pre_j; }
-	if (p.squelch_level) out.squelch_hits = hits;
+	for (int k = lane; k < 6 * (p.passes - p.first); k += 64) {
+		const int q = p.first + k / 6, j = k % 6;
+		out.lp_i_hist[q][j] = hist[0][q][j]; out.lp_q_hist[q][j] = hist[1][q][j];
+	}
+	if (lane < 9) { out.droop_i_hist[lane] = droop[0][lane]; out.droop_q_hist[lane] = droop[1][lane]; }
+	if (lane == 0) {
+		if (p.mode == RTLFM_MODE_FM) { out.pre_r = carry[0]; out.pre_j = carry[1]; }
+		if (p.squelch_level) out.squelch_hits = carry[2];
+	}
 }
 
 // ------------------------------------------------------------- audio tail ----
@@ -1552,6 +1609,215 @@ k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__
 			sout[s].prev_lpr_index = phase;
 			if (cnt_out) cnt_out[s] = E;
 		}
+	}
+}
+
+// ---- -M wbfm's tail where it takes no wave slot from the front end (round 6) -----------------------------------
+// k_deemph_spec_lpr above is 146 registers per lane in 256-thread workgroups.  Beside the NEXT step's front end - four
+// waves of k_boxcar_scan per SIMD, 120 registers each - one of its waves only fits where a front-end wave has left, a
+// workgroup only where four have left at once, and every wave of the tail that runs displaces a whole wave of a front end
+// whose speed is the number of tiles it has in flight: a step cost front end + 0.27 ms (LAB.md I.1, I.19; round 6: I.21).
+// But 4 x 120 registers leave 32 of a SIMD's 512, a wave slot (eight per SIMD) and 13 KB of the CU's LDS unused.  This
+// kernel is the same arithmetic made to fit THERE: at most 32 registers, no LDS, one-wave workgroups, no barrier - a fifth
+// wave beside four front-end waves that costs them issue cycles and memory bandwidth, not a slot.
+// What had to go for that:
+//   * the chunk records and the finishing pass behind a workgroup barrier.  low_pass_real's accumulator is empty right
+//     behind every emission (src/rtl_fm.c:755-775), and where the emissions fall is a closed form of the carried phase: a
+//     lane's stretch runs from the last emission at or before its chunk's first sample to the last one at or before the
+//     chunk's end, so every output belongs to exactly one lane and nothing is put together afterwards.  The few samples in
+//     front of the chunk (fewer than fast / slow + 1) come out of the settle walk, which has to have met by then;
+//   * the walk's sixteen 16-byte groups in flight: one group is walked while the next is loaded;
+//   * the 64-byte output pieces through LDS: outputs leave in 16-byte groups from four registers (rows 16-byte aligned),
+//     the odd ones at a stretch's ends one by one;
+//   * the redo of a stream that cannot settle (silence: the two extreme walks stop a / 2 either side of the input) by its
+//     workgroup: the lane walks from the stream's carried state to its own stretch instead - every lane of such a stream
+//     does, so a silent stream costs up to chunks / 2 times the walk, and is as slow as its last lane (as before);
+//   * a carried state outside its range (filter state beyond int16, resampler phase outside [0, fast): only
+//     rtlfm_gpu_state_set can do that): the stream's first lane runs the reference's two loops over the whole run.
+struct SlimSink {
+	int16_t *bof;  // the output row advanced to the stretch's first 16-byte group boundary: output m lives at bof[m - first_full]
+	int mrel;      // m - first_full (negative in front of the boundary: those outputs leave one by one)
+	int phi;
+	uint32_t acc, p0, p1, p2, p3;  // the accumulator; the last eight outputs, oldest in the low half of p0
+	__device__ __forceinline__ void init(int16_t *bo, int m, int phi_, uint32_t acc_, bool vec)
+	{
+		const int first_full = vec ? ((m + 7) & ~7) : (1 << 30);
+		bof = bo + first_full; mrel = m - first_full; phi = phi_; acc = acc_; p0 = p1 = p2 = p3 = 0;
+	}
+	__device__ __forceinline__ void put(int y, int sl, int fa, const ConstDiv &cdiv)
+	{
+		acc += (uint32_t)y;
+		phi += sl;
+		if (phi >= fa) {
+			const uint32_t q = (uint32_t)cdiv((int)acc);
+			p0 = __builtin_amdgcn_alignbit(p1, p0, 16);
+			p1 = __builtin_amdgcn_alignbit(p2, p1, 16);
+			p2 = __builtin_amdgcn_alignbit(p3, p2, 16);
+			p3 = (p3 >> 16) | (q << 16);
+			if (mrel < 0) bof[mrel] = (int16_t)q;
+			mrel++;
+			if ((mrel & 7) == 0 && mrel > 0) *reinterpret_cast<uint4 *>(bof + mrel - 8) = make_uint4(p0, p1, p2, p3);
+			phi -= fa;
+			acc = 0;
+		}
+	}
+	__device__ __forceinline__ void finish()
+	{
+		const int nrem = mrel & 7;
+		if (mrel - nrem < 0) return;  // written one by one already
+		const uint32_t p[4] = {p0, p1, p2, p3};
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if (j >= 8 - nrem) bof[mrel - 8 + j] = (int16_t)(p[j >> 1] >> (16 * (j & 1)));
+	}
+};
+
+// `count` samples at p through the filter from the biased state v: one 16-byte group walked while the next is loaded.
+// PAIR: two states (the settle walk's extremes), nothing emitted; else the filtered samples go into the sink.
+template <int MAGIC, bool PAIR>
+__device__ __forceinline__ void slim_walk(const int16_t *p, int count, uint32_t &v, uint32_t &v2, const DeemphStep &ds,
+                                          SlimSink &sink, int sl, int fa, const ConstDiv &cdiv)
+{
+	auto one = [&](uint32_t xb) {
+		v = ds.step<MAGIC>(xb, v);
+		if (PAIR) v2 = ds.step<MAGIC>(xb, v2);
+		else sink.put((int)(int16_t)(uint16_t)(v ^ 0x8000u), sl, fa, cdiv);
+	};
+	for (; count > 0 && (((uintptr_t)p) & 15); count--, p++) one((uint32_t)(uint16_t)*p ^ 0x8000u);
+	if (count >= 8) {
+		uint4 cur = *reinterpret_cast<const uint4 *>(p);
+		for (; count >= 8; count -= 8) {
+			p += 8;
+			const uint4 nxt = *reinterpret_cast<const uint4 *>(count >= 16 ? p : p - 8);
+			one((cur.x ^ 0x80008000u) & 0xffffu); one((cur.x ^ 0x80008000u) >> 16);
+			one((cur.y ^ 0x80008000u) & 0xffffu); one((cur.y ^ 0x80008000u) >> 16);
+			one((cur.z ^ 0x80008000u) & 0xffffu); one((cur.z ^ 0x80008000u) >> 16);
+			one((cur.w ^ 0x80008000u) & 0xffffu); one((cur.w ^ 0x80008000u) >> 16);
+			cur = nxt;
+		}
+	}
+	for (; count > 0; count--, p++) one((uint32_t)(uint16_t)*p ^ 0x8000u);
+}
+
+// What a lane of k_deemph_lpr_slim is to do, worked out by k_lpr_slim_plan in front of it (the 64-bit divisions of the
+// closed forms cost forty registers; the walk itself must fit 32): samples [j0, j0 + count) of its stream into the
+// resampler, the first output being m0 at phase phi0.  count bit 30: the stream's last chunk (it leaves the carried
+// state); count < 0: nothing to do (no such chunk, or a stream the plan kernel has done itself).
+struct SlimPlan { int32_t j0, count, m0, phi0; };
+constexpr int kSlimLast = 1 << 30;
+
+// One lane per (stream, chunk).  Outputs emitted before sample i: m(i) = floor((p0 + i slow) / fast); the accumulator is
+// empty at the first sample j with m(j) == m(i): j = ceil((m(i) fast - p0) / slow) - that is where a lane's stretch begins
+// and where its predecessor's ends.  The run's totals (count of outputs, phase left) are closed forms too and are written
+// here.  A stream whose carried state no run of the chain produces (filter state beyond int16, resampler phase outside
+// [0, fast): only rtlfm_gpu_state_set can do that) is done here, by its first lane, with the reference's two loops
+// (src/rtl_fm.c:1011-1026, 755-775).
+__global__ void __launch_bounds__(64)
+k_lpr_slim_plan(const int16_t *__restrict__ R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams, int a,
+                int max_chunks, int L, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
+                const state_t *__restrict__ sin, state_t *__restrict__ sout, int32_t *__restrict__ cnt_out, SlimPlan *__restrict__ plan)
+{
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	const int s = (int)(g / (uint32_t)max_chunks);
+	const int c = (int)(g - (uint32_t)s * (uint32_t)max_chunks);
+	if (s >= nstreams) return;
+	SlimPlan out{0, -1, 0, 0};
+	const int n = cnt ? cnt[s] : T;
+	const int16_t *r = R + (size_t)s * rstride;
+	const int head = (int)(((16 - ((uintptr_t)r & 15)) & 15) >> 1);
+	const int nc = deemph_chunks(n, head, L);
+	const int carried = sin[s].deemph_avg;
+	const long long p0 = sin[s].prev_lpr_index;
+	if ((uint32_t)(carried + 32768) > 65535u || p0 < 0 || p0 >= fast) {
+		plan[g] = out;
+		if (c != 0) return;
+		int16_t *bo = B + (size_t)s * bstride;
+		int avg = carried, now = sin[s].now_lpr, i2 = 0;
+		long long idx = p0;
+		const int half = a / 2, div = fast / slow;
+		for (int i = 0; i < n; i++) {
+			const int d = r[i] - avg;
+			avg += d > 0 ? (d + half) / a : (d - half) / a;
+			now = (int)((uint32_t)now + (uint32_t)(int)(int16_t)avg);
+			idx += slow;
+			if (idx < fast) continue;
+			bo[i2++] = (int16_t)(now / div);
+			idx -= fast;
+			now = 0;
+		}
+		sout[s].deemph_avg = avg; sout[s].now_lpr = now; sout[s].prev_lpr_index = (int)idx;
+		if (cnt_out) cnt_out[s] = i2;
+		return;
+	}
+	if (c < nc) {
+		int begin, end;
+		deemph_chunk_range(c, n, head, L, begin, end);
+		auto stretch_start = [&](int i, int &mi) -> int {
+			const long long idx = p0 + (long long)i * slow;
+			mi = (int)floor_div_pos(idx, fast);
+			if (mi == 0) return 0;
+			const long long need = (long long)mi * fast - p0;  // > 0
+			return (int)floor_div_pos(need + slow - 1, slow);
+		};
+		int m0 = 0, m1 = 0;
+		const int j0 = c == 0 ? 0 : stretch_start(begin, m0);
+		const int j1 = c == nc - 1 ? n : stretch_start(end, m1);
+		if (c == 0) m0 = 0;
+		out.j0 = j0; out.count = (j1 - j0) | (c == nc - 1 ? kSlimLast : 0);
+		out.m0 = m0; out.phi0 = (int)(p0 + (long long)j0 * slow - (long long)m0 * fast);
+		if (c == nc - 1) {
+			int E, phase;
+			lpr_totals(p0, n, slow, fast, E, phase);
+			sout[s].prev_lpr_index = phase;
+			if (cnt_out) cnt_out[s] = E;
+		}
+	}
+	plan[g] = out;
+}
+
+template <int MAGIC>
+__global__ void __launch_bounds__(64)
+k_deemph_lpr_slim(const int16_t *__restrict__ R, size_t rstride, int nstreams, DeemphStep ds, int max_chunks, uint32_t chunks_magic,
+                  int W, int16_t *__restrict__ B, size_t bstride, int fast, int slow, const state_t *__restrict__ sin,
+                  state_t *__restrict__ sout, int vec, const SlimPlan *__restrict__ plan, int prio)
+{
+	// the front end's waves run at priorities 2 / 1 / 0 by their progress when a tail follows and leave 3 to the tail
+	// (fused_kernel.h, ProgressPrio): a lane's walk is one dependent chain, and at the lowest priority it got an issue slot
+	// in five - the tail then outlasted the front end it ran beside (LAB.md I.22)
+	if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+	else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+	else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+	else __builtin_amdgcn_s_setprio(0);
+	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+	const int s = (int)__umulhi(g, chunks_magic);  // g / max_chunks (the host checked the magic number over the grid)
+	if (s >= nstreams) return;
+	const SlimPlan pl = plan[g];
+	if (pl.count < 0) return;
+	const int16_t *r = R + (size_t)s * rstride;
+	const ConstDiv cdiv(fast / slow);
+	SlimSink sink;
+	const int carried = sin[s].deemph_avg;
+	// the filter's state at j0
+	uint32_t v = (uint32_t)(carried + 32768), v2 = v;
+	if (pl.j0 > 0) {
+		bool settled = false;
+		if (pl.j0 > W) {
+			v = 0; v2 = 65535;
+			slim_walk<MAGIC, true>(r + pl.j0 - W, W, v, v2, ds, sink, slow, fast, cdiv);
+			settled = v == v2;
+		}
+		if (!settled) {
+			// close to the run's start, or a stretch of the stream the filter does not forget over: from the carried state
+			v = (uint32_t)(carried + 32768); v2 = v;
+			slim_walk<MAGIC, true>(r, pl.j0, v, v2, ds, sink, slow, fast, cdiv);
+		}
+	}
+	sink.init(B + (size_t)s * bstride, pl.m0, pl.phi0, pl.m0 == 0 && pl.j0 == 0 ? (uint32_t)sin[s].now_lpr : 0u, vec != 0);
+	slim_walk<MAGIC, false>(r + pl.j0, pl.count & (kSlimLast - 1), v, v2, ds, sink, slow, fast, cdiv);
+	sink.finish();
+	if (pl.count & kSlimLast) {
+		sout[s].deemph_avg = (int)v - 32768;
+		sout[s].now_lpr = (int)sink.acc;
 	}
 }
 

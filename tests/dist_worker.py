@@ -19,10 +19,11 @@ from rtlsdr_amd import shard, synth  # noqa: E402
 
 def main():
     out_path, nstreams = sys.argv[1], int(sys.argv[2])
+    # (optional: buffer size and buffers per stream - the world-size-8 test runs configs[4]'s 32768 streams on tiny buffers)
+    L, nb = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (8192, 3)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     ov, sig = [(o, s) for n, o, s in CASES if n == "c2_p4_std"][0]
-    L, nb = 8192, 3
     cfg = make_cfg(ov, L, nb)
     iq_all = None
     if rank == 0:
@@ -38,7 +39,8 @@ def main():
     assert t.item() == world
     dist.barrier()
     if rank == 0:
-        np.savez(out_path, out=out.numpy(), lens=lens.numpy(), iq=iq_all.numpy())
+        np.savez(out_path, out=out.numpy(), lens=lens.numpy(), iq=iq_all.numpy(), world=world,
+                 ranges=np.array([shard.stream_range(nstreams, world, r) for r in range(world)]))
     dist.destroy_process_group()
 
 

@@ -69,6 +69,31 @@ def test_bench_gpus_2_starts_two_ranks():
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
 
 
+def test_bench_gpus_8_launcher_at_world_size_eight():
+    """`python bench.py --gpus 8` as the driver's scaling run starts it, on whatever this box has: with fewer than eight
+    devices the eight ranks share device 0 and gloo carries the barrier, the max-over-ranks time and the all_gather of the
+    per-rank report (RTLFM_BENCH_BACKEND=gloo exists for exactly this) - the launcher, the stream sharding 'n / GPU', the
+    reduction and the JSON at world size 8, which no one-GPU box otherwise sees."""
+    eight = _ndev() >= 8
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not eight:
+        env["RTLFM_BENCH_BACKEND"] = "gloo"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+           "--streams", "16", "--blocks", "2", "--no-cpu-baseline", "--e2e", "0", "--sustain", "0", "--also", "0", "--ceiling", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["ranks"] == 8 and d["scaling"] == "weak"
+    assert d["n_gpus"] == (8 if eight else 1)
+    pr = d["per_rank"]
+    assert pr["world_size"] == 8 and len(pr["ms_per_step"]) == 8 and len(pr["launch_ms"]) == 8 and len(pr["output_apart"]) == 8
+    assert min(pr["ms_per_step"]) > 0 and max(pr["ms_per_step"]) <= d["ms_per_step"] + 0.001  # (the line rounds to 1 us, the ranks to 0.1 us)
+    per_step = 8 * 16 * 2 * 262144 // 2  # weak scaling: every rank its own 16 streams
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
+
+
 @pytest.mark.parametrize("args", [
     ["--workload", "c2", "--streams", "16", "--blocks", "4"],
     ["--workload", "ns4096", "--streams", "64", "--blocks", "1"],

@@ -11,7 +11,8 @@ between the tile loads and the loop back-edge that forces one of them to
 complete (vmcnt counts in order: a wait for N forces every operation that has
 at least N younger ones).
 
-    python tools/check_prefetch.py [-DNAME=VALUE ...]      exit 1 if any kernel stalls
+    python tools/check_prefetch.py [-DNAME=VALUE ...] [rtlfm_hip.s]      exit 1 if any kernel stalls
+(an assembly file that exists already - tests/test_isa_lint.py compiles once for both of its lints - is read instead of compiling)
 """
 import os
 import re
@@ -72,15 +73,20 @@ def check(name, body):
     return problems
 
 
-def main():
-    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+def compile_asm(defs):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "fm.s")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", *defs,
                os.path.join(ROOT, "rtlsdr_amd/csrc/rtlfm_hip.hip"), "-o", out]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-        asm = open(out).read()
+        return open(out).read()
+
+
+def main():
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    given = [a for a in sys.argv[1:] if not a.startswith("-")]
+    asm = open(given[0]).read() if given else compile_asm(defs)
     bad = 0
     for name, body in kernels(asm):
         m = re.match(r"_ZN5rtlfm5fused7k_fusedILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)

@@ -12,6 +12,6 @@ mkdir -p gpurun_out/soak
   echo "== soak on $(hostname) $(date -u +%FT%TZ), RTLFM_SOAK=$REPS, library $(sha256sum rtlsdr_amd/csrc/librtlfm_hip.so | cut -c1-16)"
   rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1
 } >> gpurun_out/soak/soak_log.txt
-RTLFM_SOAK=$REPS timeout ${SOAK_TIMEOUT:-3000} python -m pytest tests/test_parity_gpu.py tests/test_soak_gpu.py -m gpu -q -x -p no:cacheprovider \
-  ${SOAK_K:+-k "$SOAK_K"} 2>&1 | tail -15 | tee -a gpurun_out/soak/soak_pytest_tail.txt
+RTLFM_SOAK=$REPS RTLFM_SOAK_CONTINUE=1 timeout ${SOAK_TIMEOUT:-3000} python -m pytest tests/test_parity_gpu.py tests/test_soak_gpu.py -m gpu -q -p no:cacheprovider \
+  ${SOAK_K:+-k "$SOAK_K"} 2>&1 | tail -40 | cut -c1-1500 | tee -a gpurun_out/soak/soak_pytest_tail.txt
 tail -12 gpurun_out/soak/soak_log.txt
