@@ -293,11 +293,13 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   lpr_scalar_stores    1: the resampler's outputs one by one
  *   lpr_chunk            most samples per lane of the one-pass deemph + low_pass_real kernel (default 5440; 256 ... 2^20,
  *                        anything else -EINVAL); shorter runs get shorter chunks so that about 64 K lanes work
- *   lpr_slim             1 (default): deemph_filter + low_pass_real behind a front end (-M wbfm) as k_lpr_slim_plan + k_deemph_lpr_slim:
+ *   lpr_slim             1: deemph_filter + low_pass_real behind a front end (-M wbfm) as k_lpr_slim_plan + k_deemph_lpr_slim:
  *                        one-wave workgroups of 32 registers and no LDS, which run as a FIFTH wave per SIMD beside the next
- *                        step's four front-end waves instead of in the place of one; 0: k_deemph_spec_lpr (round 5)
+ *                        step's four front-end waves instead of in the place of one.  Bit-exact and no faster (the /6 front
+ *                        end has no issue cycles to spare: the step stays front end + tail, LAB.md I.22): kept for A/B;
+ *                        0 (default): k_deemph_spec_lpr (round 5)
  *   lpr_slim_chunk       samples per lane of that kernel (default 6120: 16 chunks per stream and one wave per SIMD at the
- *                        wbfm shape; 256 ... 2^20)
+ *                        wbfm shape; 256 ... 2^20);  lpr_slim_prio: its waves' s_setprio, 0 ... 3 (default 3)
  *   lpr_ring             1 (default): that kernel's outputs leave through LDS in aligned 64-byte pieces; 0: 16 bytes per lane
  *   squelch_fused        1 (default): rms()'s sums per buffer inside the front end + k_squelch_apply; 0: emit mode + k_squelch_*
  *   adc_separate         1: dc_block_audio as sums / smooth / apply kernels (round 4) instead of sums + k_adc_smooth_apply

@@ -22,6 +22,7 @@
 
 #include "../../include/rtlfm_hip.h"
 #include "debug_poison.h"
+#include "stream_pool.h"
 #include "staged_kernels.h"
 #include "fused_kernel.h"
 #include "boxcar_kernel.h"
@@ -84,6 +85,7 @@ struct rtlfm_gpu {
 	unsigned step = 0;                      // parity selects res[] / d_cnt[] / the events
 	hipStream_t tail_stream = nullptr;
 	int tail_priority = 0;
+	int tail_prio_value = 0;                // the HIP priority tail_stream was taken from the pool with
 	hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
 	bool tail_pending[2] = {false, false};  // ev_tail[p] has been recorded and not yet waited for
 	bool tail_overlap = true;
@@ -121,7 +123,7 @@ struct rtlfm_gpu {
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
-		int lpr_slim = 1;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6); 0: k_deemph_spec_lpr
+		int lpr_slim = 0;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6: built, bit-exact, and no faster - LAB.md I.22); 0: k_deemph_spec_lpr
 		int lpr_slim_prio = 3;      // s_setprio of that kernel's waves (0 .. 3)
 		int lpr_slim_chunk = 6120;  // samples per lane of that kernel: 16 chunks per stream at the wbfm shape = 1024 waves, one per SIMD
 		int verify_twice = 0;  // debug: every run_device runs twice - into a shadow output, then into the caller's - and the two are compared on the device
@@ -341,7 +343,7 @@ static int create_body(rtlfm_gpu *h)
 	if (cfg->rate_out2 > 0 && cfg->resampler == RTLFM_RESAMPLE_ARBITRARY && cfg->rate_out2 > cfg->rate_out)
 		rs = (size_t)((double)rs * cfg->rate_out2 / cfg->rate_out) + 64;
 	h->rstride = (rs + 7) & ~(size_t)7;
-	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+	HIP_TRY(rtl_pool::stream_get(h->device, 0, &h->own_stream));  // (from the process-wide pool: stream_pool.h)
 	h->stream = h->own_stream;
 	const size_t S = (size_t)nstreams;
 	for (int k = 0; k < 3; k++) HIP_TRY(hipMalloc(&h->st[k], S * sizeof(state_t)));
@@ -360,8 +362,9 @@ static int create_body(rtlfm_gpu *h)
 	{
 		int lo = 0, hi = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-		HIP_TRY(hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, lo));
+		HIP_TRY(rtl_pool::stream_get(h->device, lo, &h->tail_stream));
 		h->tail_priority = -1;
+		h->tail_prio_value = lo;
 	}
 	h->tail_overlap = true;
 	{
@@ -495,11 +498,16 @@ extern "C" int rtlfm_gpu_destroy(rtlfm_gpu *h)
 		if (p) hipFree(p);
 	h->fws.release();
 	ingest_destroy(h);
-	// (RTLFM_KEEP_STREAMS=1, an experiment switch of the soak test: the handle's two streams are leaked instead of destroyed)
-	static const bool keep_streams = [] { const char *e = getenv("RTLFM_KEEP_STREAMS"); return e && *e == '1'; }();
-	if (!keep_streams) {
+	// The streams go back to the process-wide pool, never to hipStreamDestroy (stream_pool.h: the runtime releases a freed
+	// object of a destroyed stream once more, later, in whoever's memory it has become - LAB.md I.21).
+	// RTLFM_DESTROY_STREAMS=1 (tools/host_uaf_probe.py --mode destroy) restores round 5's behaviour for the comparison.
+	static const bool destroy_streams = [] { const char *e = getenv("RTLFM_DESTROY_STREAMS"); return e && *e == '1'; }();
+	if (destroy_streams) {
 		if (h->own_stream) hipStreamDestroy(h->own_stream);
 		if (h->tail_stream) hipStreamDestroy(h->tail_stream);
+	} else {
+		rtl_pool::stream_put(h->device, 0, h->own_stream);
+		rtl_pool::stream_put(h->device, h->tail_prio_value, h->tail_stream);
 	}
 	delete h;
 	return 0;
@@ -628,10 +636,12 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 		int lo = 0, hi = 0;
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = the numerically greatest = lowest priority
 		hipStream_t q = nullptr;
-		HIP_TRY(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, value < 0 ? lo : value > 0 ? hi : 0));
-		if (h->tail_stream) hipStreamDestroy(h->tail_stream);
+		const int pv = value < 0 ? lo : value > 0 ? hi : 0;
+		HIP_TRY(rtl_pool::stream_get(h->device, pv, &q));
+		rtl_pool::stream_put(h->device, h->tail_prio_value, h->tail_stream);
 		h->tail_stream = q;
 		h->tail_priority = (int)value;
+		h->tail_prio_value = pv;
 		return 0;
 	}
 	int *slot = option_slot(h, name);
@@ -1953,7 +1963,7 @@ static long placement_held_mb(rtlfm_gpu *h)
 static void ingest_free(Ingest *in)
 {
 	if (!in) return;
-	if (in->copy_stream) { hipStreamSynchronize(in->copy_stream); hipStreamDestroy(in->copy_stream); }
+	if (in->copy_stream) { int dev_ = 0; (void)hipGetDevice(&dev_); rtl_pool::stream_put(dev_, 0, in->copy_stream); }
 	for (int k = 0; k < 2; k++) {
 		if (in->h_stage[k]) hipHostFree(in->h_stage[k]);
 		for (void *p : {(void *)in->d_in[k], k == 1 && in->result_one_block ? nullptr : (void *)in->d_result[k], (void *)in->d_result_len[k]})
@@ -1974,7 +1984,7 @@ static int ingest_build(rtlfm_gpu *h, Ingest *in)
 	const size_t bytes = S * h->cap_blocks * h->cfg.block_len;
 	HIP_TRY(hipSetDevice(h->device));
 	in->ostride = ((size_t)rtlfm_result_cap(&h->cfg) * h->cap_blocks + 16 + 63) & ~(size_t)63;
-	HIP_TRY(hipStreamCreateWithFlags(&in->copy_stream, hipStreamNonBlocking));
+	HIP_TRY(rtl_pool::stream_get(h->device, 0, &in->copy_stream));
 	for (int k = 0; k < 2; k++) {
 		HIP_TRY(hipHostMalloc(&in->h_stage[k], bytes, hipHostMallocDefault));
 		HIP_TRY(hipMalloc(&in->d_in[k], bytes));

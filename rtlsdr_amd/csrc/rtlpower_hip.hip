@@ -13,6 +13,7 @@
 
 #include "../../include/rtlpower_hip.h"
 #include "debug_poison.h"
+#include "stream_pool.h"
 #include "power_kernels.h"
 
 using namespace rtlpower;
@@ -65,6 +66,7 @@ struct rtlpower_gpu {
 	int staged_batch = 0; // option "staged_batch": reads per batch, 0 = by the work buffer's size (tests: several batches of a small scan)
 	struct Pipe {
 		hipStream_t aux = nullptr;
+		int aux_prio = 0;  // the HIP priority aux was taken from the stream pool with
 		hipEvent_t start = nullptr, prep[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr}, done = nullptr;
 	} pipe;
 	bool work_two = false;  // d_work / d_ave / d_tbuf / d_part hold two batches
@@ -292,7 +294,7 @@ static int power_create_body(rtlpower_gpu *h)
 		if (cfg->boxcar && ds > 1) h->dec_elems = 2 * (((int)cfg->buf_len / 2 + ds - 1) / ds);
 		else if (h->decimates) h->dec_elems = (int)cfg->buf_len >> cfg->downsample_passes;
 	}
-	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+	HIP_TRY(rtl_pool::stream_get(h->device, 0, &h->own_stream));  // (from the process-wide pool: stream_pool.h)
 	h->stream = h->own_stream;
 	const size_t S = (size_t)nstreams;
 	HIP_TRY(hipMalloc(&h->d_avg, S * h->N * sizeof(long long)));
@@ -353,8 +355,9 @@ extern "C" int rtlpower_gpu_destroy(rtlpower_gpu *h)
 	if (h->pipe.aux) (void)hipStreamSynchronize(h->pipe.aux);
 	for (hipEvent_t e : {h->pipe.start, h->pipe.prep[0], h->pipe.prep[1], h->pipe.scanned[0], h->pipe.scanned[1], h->pipe.done})
 		if (e) (void)hipEventDestroy(e);
-	if (h->pipe.aux) (void)hipStreamDestroy(h->pipe.aux);
-	if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+	// back to the pool, never destroyed (stream_pool.h)
+	rtl_pool::stream_put(h->device, h->pipe.aux_prio, h->pipe.aux);
+	rtl_pool::stream_put(h->device, 0, h->own_stream);
 	delete h;
 	return 0;
 }
@@ -698,7 +701,8 @@ extern "C" int rtlpower_gpu_scan_device(rtlpower_gpu *h, const uint8_t *d_iq, si
 		if (piped && !h->pipe.aux) {
 			int lo = 0, hi = 0;
 			HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-			HIP_TRY(hipStreamCreateWithPriority(&h->pipe.aux, hipStreamNonBlocking, lo));  // (a priority of its own: a hardware queue of its own)
+			HIP_TRY(rtl_pool::stream_get(h->device, lo, &h->pipe.aux));  // (a priority of its own: a hardware queue of its own)
+			h->pipe.aux_prio = lo;
 			for (hipEvent_t *e : {&h->pipe.start, &h->pipe.prep[0], &h->pipe.prep[1], &h->pipe.scanned[0], &h->pipe.scanned[1], &h->pipe.done})
 				HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
 		}

@@ -1741,9 +1741,9 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates, scalar):
     _lpr_tail_case(oracle_lib, a, rates, dict(lpr_scalar_stores=scalar))
 
 
-@pytest.mark.parametrize("opts", [dict(lpr_slim=0, lpr_chunk=256), dict(lpr_slim=0, lpr_chunk=5440), dict(deemph_four_pass=1),
+@pytest.mark.parametrize("opts", [dict(lpr_chunk=256), dict(lpr_chunk=5440), dict(deemph_four_pass=1),
                                   dict(deemph_four_pass=1, lpr_chunk=256), dict(lpr_separate=1), dict(lpr_slim=0),
-                                  dict(lpr_slim=0, lpr_ring=0), dict(lpr_slim=0, lpr_scalar_stores=1)])
+                                  dict(lpr_ring=0), dict(lpr_scalar_stores=1)])
 def test_lpr_tail_options(oracle_lib, opts):
     """The same tail under its options: round 5's one-pass kernel (k_deemph_spec_lpr, `lpr_slim = 0`) with chunk lengths below
     and above the four-pass route's own chunk (the chunk tables are sized per route) and its three ways of storing, the four

@@ -2,12 +2,12 @@
 # tools/collect_profiles.sh — on the GPU box: for every measured workload the bench line, right
 # behind it the rocprofv3 kernel-trace stats of the same workload (the box drifts by a few per cent
 # over minutes at its power cap, so the two that have to agree are taken back to back), and PMC
-# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r05) (copy
+# passes for the kernels DESIGN.md quotes counters of.  Everything lands in gpurun_out/$ROUND/ (default r06) (copy
 # what should be judged into profiles/ afterwards; the raw traces are deleted, they are large).
 # One rocprofv3 run per counter set, no tracing domains mixed with --pmc.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p $OUT
 top() { # csv title

@@ -9,11 +9,12 @@ download, handle destroyed) with canaries - host arrays of exactly that size hol
 that changes, together with the host addresses of the runtime objects (streams, events, the handle) that died with the
 handles just before.  Modes change ONE thing each, so that a same-box comparison names the owner:
 
-    --mode base          the soak's pattern
-    --mode syncall       torch.cuda.synchronize() before the handle is destroyed (every stream has consumed its waits)
-    --mode norelease     no rtlfm_gpu_release_to / _wait_for: run_device + rtlfm_gpu_sync only
-    --mode keepstreams   RTLFM_KEEP_STREAMS=1: the handle's two streams are leaked instead of destroyed
-    --mode onehandle     one handle for all launches (reset between them): nothing is destroyed
+    --mode base          the soak's pattern with the library as it is: a handle's streams go back to a pool (stream_pool.h)
+    --mode destroy       RTLFM_DESTROY_STREAMS=1: round 5's behaviour, hipStreamDestroy when a handle goes - the canaries are hit
+    --mode syncall       destroy + torch.cuda.synchronize() before the handle goes (every stream has consumed its waits): hit too
+    --mode norelease     destroy, but no rtlfm_gpu_release_to / _wait_for: run_device + rtlfm_gpu_sync only - no hit
+    --mode onehandle     one handle for all launches (reset between them): nothing is destroyed - no hit
+(round 6, one box, profiles/r06_host_uaf_probe_box7.txt - there `base` still destroyed and `keepstreams` leaked the streams.)
 
     python tools/host_uaf_probe.py --mode base --launches 200000 [--canaries 64]
 """
@@ -29,13 +30,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="base", choices=["base", "syncall", "norelease", "keepstreams", "onehandle"])
+    ap.add_argument("--mode", default="base", choices=["base", "destroy", "syncall", "norelease", "onehandle"])
     ap.add_argument("--launches", type=int, default=100000)
     ap.add_argument("--canaries", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=240.0)
     a = ap.parse_args()
-    if a.mode == "keepstreams":
-        os.environ["RTLFM_KEEP_STREAMS"] = "1"
+    if a.mode in ("destroy", "syncall", "norelease"):
+        os.environ["RTLFM_DESTROY_STREAMS"] = "1"
     import faulthandler
     faulthandler.enable()
     import numpy as np
