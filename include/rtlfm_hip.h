@@ -476,6 +476,15 @@ int rtlfm_gpu_free(void *p);
  * device's staging ring should run. */
 int rtlfm_gpu_device_numa_node(int device);
 
+/*
+ * The front-end planner by itself (host only, no GPU): how a launch over `nstreams` streams of `total_tiles` 8 KiB tiles each
+ * is cut into segments (one wave per stream and segment).  fifth_order / tail_follows as the run would set them;
+ * target_waves, min_tiles, tiles_per_seg, gss_x10: the options of the same names (0 = the library's defaults).
+ * *segs = segments per stream, starts[0 .. *segs] their tile boundaries (-ENOBUFS when cap < *segs + 1).
+ */
+int rtlfm_plan_segments(int nstreams, int total_tiles, int fifth_order, int tail_follows, int target_waves, int min_tiles,
+                        int tiles_per_seg, int gss_x10, int *segs, int *starts, int cap);
+
 const char *rtlfm_gpu_strerror(int err);
 /* (major<<16)|(minor<<8)|patch */
 int rtlfm_gpu_version(void);

@@ -214,6 +214,7 @@ _SIGNATURES = [
     ("rtlfm_gpu_copy", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("rtlfm_gpu_free", C.c_int, [C.c_void_p]),
     ("rtlfm_gpu_device_numa_node", C.c_int, [C.c_int]),
+    ("rtlfm_plan_segments", C.c_int, [C.c_int] * 8 + [_P(C.c_int), _P(C.c_int), C.c_int]),
     ("rtlfm_gpu_strerror", C.c_char_p, [C.c_int]),
     ("rtlfm_gpu_version", C.c_int, []),
 ]

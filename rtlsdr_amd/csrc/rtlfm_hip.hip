@@ -2939,6 +2939,28 @@ extern "C" int rtlfm_gpu_clock_stamps(rtlfm_gpu *h, uint64_t *out, int cap_waves
 	return 0;
 }
 
+// How a front-end launch would be cut into waves (fused::plan_segments), without a GPU: for the planner's unit test.
+// starts[0 .. *segs] = tile boundaries of a stream's segments (cap entries at least *segs + 1, else -ENOBUFS).
+extern "C" int rtlfm_plan_segments(int nstreams, int total_tiles, int fifth_order, int tail_follows, int target_waves, int min_tiles,
+                                   int tiles_per_seg, int gss_x10, int *segs, int *starts, int cap)
+{
+	if (nstreams < 1 || total_tiles < 1 || !segs || !starts) return -EINVAL;
+	fused::Workspace ws;
+	ws.tail_follows = tail_follows != 0;
+	if (target_waves > 0) { ws.target_waves = target_waves; ws.target_waves_tail = target_waves; ws.target_waves_tail_fifth = 0; ws.plan_by_caller = true; }
+	if (min_tiles > 0) { ws.min_tiles = min_tiles; ws.plan_by_caller = true; }
+	ws.tiles_per_seg = tiles_per_seg;
+	ws.gss_x10 = gss_x10;
+	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, total_tiles, fifth_order != 0);
+	*segs = sp.segs;
+	if (cap < sp.segs + 1) return -ENOBUFS;
+	for (int j = 0; j <= sp.segs; j++) {
+		int at = sp.nlist > 0 ? sp.start[j] : j * sp.tiles_per_seg;
+		starts[j] = at < total_tiles ? at : total_tiles;
+	}
+	return 0;
+}
+
 extern "C" const char *rtlfm_gpu_strerror(int err)
 {
 	switch (err) {
