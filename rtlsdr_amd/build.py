@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "librtlfm_hip.so")
-SOURCES = ["rtlfm_hip.hip", "rtlpower_hip.hip"]
+SOURCES = ["rtlfm_hip.hip", "rtlpower_hip.hip", "rtlfm_place.hip"]
 HEADERS = ["dsp_device.h", "staged_kernels.h", "fused_kernel.h",
            os.path.join("..", "..", "include", "rtlfm_hip.h")]
 ARCH = "gfx950"
@@ -26,9 +26,10 @@ def _hipcc() -> str:
 OBJDIR = os.path.join(CSRC, "build")
 # which headers a translation unit sees (a header change recompiles only the units that include it)
 UNIT_HEADERS = {
-    "rtlfm_hip.hip": ["debug_poison.h", "dsp_device.h", "staged_kernels.h", "fused_kernel.h", "boxcar_kernel.h", "bw_probe_kernel.h",
+    "rtlfm_hip.hip": ["debug_poison.h", "stream_pool.h", "dsp_device.h", "staged_kernels.h", "fused_kernel.h", "boxcar_kernel.h",
                       os.path.join("..", "..", "include", "rtlfm_hip.h")],
-    "rtlpower_hip.hip": ["debug_poison.h", "dsp_device.h", "power_kernels.h", os.path.join("..", "..", "include", "rtlpower_hip.h"),
+    "rtlfm_place.hip": ["debug_poison.h", "bw_probe_kernel.h", os.path.join("..", "..", "include", "rtlfm_hip.h")],
+    "rtlpower_hip.hip": ["debug_poison.h", "stream_pool.h", "dsp_device.h", "power_kernels.h", os.path.join("..", "..", "include", "rtlpower_hip.h"),
                          os.path.join("..", "..", "include", "rtlfm_hip.h")],
 }
 # -ffile-prefix-map: __FILE__ (HIP_TRY's messages) and every other path the compiler embeds are written relative to the

@@ -20,7 +20,7 @@ def device_asm(tmp_path_factory):
     """The gfx950 assembly of both translation units, compiled once (side by side) for every lint of this file."""
     td = tmp_path_factory.mktemp("isa")
     procs = []
-    for u in ("rtlfm_hip", "rtlpower_hip"):
+    for u in ("rtlfm_hip", "rtlpower_hip", "rtlfm_place"):
         out = str(td / (u + ".s"))
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",

@@ -19,7 +19,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ["rtlsdr_amd/csrc/rtlfm_hip.hip", "rtlsdr_amd/csrc/rtlpower_hip.hip"]
+UNITS = ["rtlsdr_amd/csrc/rtlfm_hip.hip", "rtlsdr_amd/csrc/rtlpower_hip.hip", "rtlsdr_amd/csrc/rtlfm_place.hip"]
 READ_WAIT, WRITE_WAIT = 3, 2
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
