@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		}
 		// c G(1), c G(2), c G(3) as packed int16 pairs, for the buffer the tile starts in (lo) and the one that follows (hi);
 		// dc_nb: the tile's first sample of the second buffer (beyond the tile when it holds one buffer's samples only)
-		uint32_t dc1 = 0, dc2 = 0, dc3 = 0, dh1 = 0, dh2 = 0, dh3 = 0;
+		uint32_t dc1 = 0, dc2 = 0, dc3 = 0, dh1 = 0, dh2 = 0, dh3 = 0, dc_base = 0;
 		int dc_nb = 1 << 30;
 		if constexpr (RDC) {
 			const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + rdc_b);
@@ -391,6 +391,8 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			dh2 = pack_iq((int16_t)(dhI + dhQ), (int16_t)(dhQ - dhI));
 			dh3 = pack_iq((int16_t)dhQ, (int16_t)-dhI);
 			dc_nb = N0 - rdc_off;
+			if (!p.rotate && dc_nb < kTileSamples)  // nb (a_lo - a_hi), 16-bit lanes
+				dc_base = fused::as_u32(fused::as_s2((uint32_t)dc_nb * 0x00010001u) * (fused::as_s2(dc1) - fused::as_s2(dh1)));
 			rdc_off += kTileSamples;
 			if (rdc_off >= N0) { rdc_off -= N0; rdc_b++; }  // N0 >= 4096: once at most
 		}
@@ -487,11 +489,21 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				Pv = (n & 1) ? pk_add16(Pv, fs) : Pv;
 			}
 			if constexpr (RDC) {
-				const int k = n & 3;
-				const bool hi = n > dc_nb;  // (at the boundary itself k == 0: no correction either way)
-				const uint32_t c1 = hi ? dh1 : dc1, c2 = hi ? dh2 : dc2, c3 = hi ? dh3 : dc3;
-				const uint32_t corr = k == 0 ? 0u : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-				Pv = pk_sub16(Pv, corr);
+				if (p.rotate) {  // (wave-uniform)
+					const int k = n & 3;
+					const bool hi = n > dc_nb;  // (at the boundary itself k == 0: no correction either way)
+					const uint32_t c1 = hi ? dh1 : dc1, c2 = hi ? dh2 : dc2, c3 = hi ? dh3 : dc3;
+					const uint32_t corr = k == 0 ? 0u : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+					Pv = pk_sub16(Pv, corr);
+				} else {
+					// offset tuning (round 6): nothing rotates, the constant simply adds up - n samples of the tile hold
+					// min(n, nb) times the first buffer's averages and the rest times the second's: one packed multiply-add
+					// (16-bit lanes wrap as the sums do), base = nb (a_lo - a_hi) behind the boundary
+					const bool hi = n > dc_nb;
+					const uint32_t npk = (uint32_t)n * 0x00010001u;  // n < 4097: (n, n)
+					const fused::short2_t corr = fused::as_s2(npk) * fused::as_s2(hi ? dh1 : dc1) + fused::as_s2(hi ? dc_base : 0u);
+					Pv = pk_sub16(Pv, fused::as_u32(corr));
+				}
 			}
 			return Pv;
 		};
@@ -601,7 +613,17 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		last_out = lds[ScanLds::scratch + 1];
 		// ---- 5. the window the tile leaves unfinished: fewer than D <= 256 samples, exact in 16 bits
 		{
-			const iq16 part = unpack_iq(pk_sub16(tot, Plast));
+			uint32_t tot_c = tot;
+			if constexpr (RDC) {
+				// (with the rotation the constant has summed to zero over the tile's whole groups of four; without it - offset
+				// tuning - the tile's vs samples hold nb times the first buffer's averages and the rest times the second's)
+				if (!p.rotate) {
+					const bool hi = vs > dc_nb;
+					const uint32_t npk = (uint32_t)vs * 0x00010001u;
+					tot_c = pk_sub16(tot, fused::as_u32(fused::as_s2(npk) * fused::as_s2(hi ? dh1 : dc1) + fused::as_s2(hi ? dc_base : 0u)));
+				}
+			}
+			const iq16 part = unpack_iq(pk_sub16(tot_c, Plast));
 			carry_r = part.i; carry_j = part.q;
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -670,9 +692,9 @@ inline bool supported_front(const rtlfm_cfg &c)
 	// (downsample == 1, rtl_fm -s 1.2M: low_pass() hands every sample on - 4096 outputs per tile, the same kernel)
 	if (c.downsample_passes != 0 || c.downsample < 1 || c.downsample > kMaxD) return false;
 	if (c.comp_fir_size) return false;
-	// -E rdc: the rotated constant sums to zero over every four samples only when the chain rotates; a tile may hold
-	// samples of two buffers, not of three
-	if (c.dc_block_raw && (c.offset_tuning || c.block_len < (uint32_t)kTileBytes)) return false;
+	// -E rdc: a tile may hold samples of two buffers, not of three.  (With the rotation the constant sums to zero over every
+	// four samples; with offset tuning - no rotation - it adds up linearly: one packed multiply-add per look-up, round 6.)
+	if (c.dc_block_raw && c.block_len < (uint32_t)kTileBytes) return false;
 	return true;  // else any buffer length (a multiple of 512 bytes): the run is one continuous sample stream here
 }
 

@@ -343,11 +343,15 @@ def test_raw_dc_block_on_the_fused_path(oracle_lib, passes, fir9, atan, offs):
 
 
 @pytest.mark.parametrize("D,atan,extra", [(6, 1, {}), (10, 0, {}), (10, 1, {}), (10, 2, {}), (42, 0, {}), (7, 0, {}), (300, 0, {}),
-                                          (10, 0, dict(squelch_level=400)), (10, 0, dict(mode=4)), (84, 0, dict(mode=1, output_scale=3))])
+                                          (10, 0, dict(squelch_level=400)), (10, 0, dict(mode=4)), (84, 0, dict(mode=1, output_scale=3)),
+                                          (10, 0, dict(offset_tuning=1)), (6, 1, dict(offset_tuning=1)), (7, 2, dict(offset_tuning=1)),
+                                          (300, 0, dict(offset_tuning=1)), (10, 0, dict(offset_tuning=1, mode=4)),
+                                          (10, 0, dict(offset_tuning=1, squelch_level=400))])
 def test_raw_dc_block_in_front_of_the_boxcar(oracle_lib, D, atan, extra):
     """-E rdc in front of the default decimator (rtl_fm -E rdc without -F) on the one-launch path: the rotated
     constant sums to zero over every four samples, so the per-buffer averages are one correction c G(n & 3) where a
-    prefix sum is looked up (boxcar_kernel.h, RDC).  Drifting DC offsets per buffer, full-scale bytes, odd and long
+    prefix sum is looked up (boxcar_kernel.h, RDC); with offset tuning (no rotation; round 6) the constant adds up linearly
+    instead: one packed multiply-add per look-up.  Drifting DC offsets per buffer, full-scale bytes, odd and long
     boxcars (the 32-bit partial sums of D > 256), emit mode behind it, runs split over launches, segments."""
     ov = dict(downsample=D, downsample_passes=0, custom_atan=atan, dc_block_raw=1, rate_out=int(2.4e6 / D))
     ov.update(extra)
