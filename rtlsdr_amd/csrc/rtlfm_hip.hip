@@ -125,6 +125,7 @@ struct rtlfm_gpu {
 		int lpr_slim = 0;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6: built, bit-exact, and no faster - LAB.md I.22); 0: k_deemph_spec_lpr
 		int lpr_slim_prio = 3;      // s_setprio of that kernel's waves (0 .. 3)
 		int lpr_slim_chunk = 6120;  // samples per lane of that kernel: 16 chunks per stream at the wbfm shape = 1024 waves, one per SIMD
+		int verify_inject = 0; // tests: the shadow execution's first sample of stream 0 is overwritten before the comparison (it must be noticed)
 		int verify_twice = 0;  // debug: every run_device runs twice - into a shadow output, then into the caller's - and the two are compared on the device
 	} opt;
 	// verify_twice (round 6): shadow rows / lengths / state, and what the comparisons found so far
@@ -610,7 +611,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
 		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
-		{"verify_twice", &h->opt.verify_twice}, {"lpr_slim", &h->opt.lpr_slim}, {"lpr_slim_chunk", &h->opt.lpr_slim_chunk}, {"lpr_slim_prio", &h->opt.lpr_slim_prio},
+		{"verify_twice", &h->opt.verify_twice}, {"verify_inject", &h->opt.verify_inject}, {"lpr_slim", &h->opt.lpr_slim}, {"lpr_slim_chunk", &h->opt.lpr_slim_chunk}, {"lpr_slim_prio", &h->opt.lpr_slim_prio},
 	};
 	for (auto &t : tab)
 		if (!strcmp(t.n, name)) return t.p;
@@ -1835,6 +1836,13 @@ static int run_device_verified(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_
 	if (r < 0) return r;
 	HIP_TRY(sync_all(h));
 	HIP_TRY(hipMemcpy(h->vt_state, sout, S * sizeof(state_t), hipMemcpyDeviceToDevice));
+	if (h->opt.verify_inject) {
+		// (tests: a difference the comparison must report - the shadow's first sample with every bit turned over)
+		int16_t v = 0;
+		HIP_TRY(hipMemcpy(&v, h->vt_out, sizeof(v), hipMemcpyDeviceToHost));
+		v = (int16_t)~v;
+		HIP_TRY(hipMemcpy(h->vt_out, &v, sizeof(v), hipMemcpyHostToDevice));
+	}
 	int32_t *len2 = d_out_len ? d_out_len : h->vt_len2;
 	r = run_device_once(h, d_iq, stream_stride, nblocks, d_out, out_stride, len2);
 	if (r < 0) return r;

@@ -236,3 +236,8 @@ def test_verify_twice_sees_a_difference_and_none_where_there_is_none(oracle_lib)
         plain, _, _ = gpu_run(cfg, iq, splits=[(0, 2), (2, 4)])
         for s in range(ns):
             assert np.array_equal(plain[s], outs[s]), (name, s)
+        # ... and it does see a difference: the shadow execution's first sample turned over before the comparison
+        # (the caller's rows are untouched: the results are still the oracle's)
+        outs, sts, info = _launch(cfg, iq, [(0, 2), (2, 4)], dict(verify_inject=1), True)
+        assert info["verify_runs"] == 2 and info["verify_mismatches"] == 2, (name, info)
+        assert not _differs(outs, sts, want, want_len, wst), name
