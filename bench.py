@@ -1283,6 +1283,9 @@ def main():
         if pl:
             res["placement"] = {"output_apart": getattr(job, "output_apart", None), "searches": pl.get("searches"), "budget_gb": pl.get("budget_gb"),
                                 "search_ms": pl.get("search_ms"), "walked_mb": pl.get("walked_mb"), "library_default_budget_gb": 16,
+                                # would a caller with the library's default budget and no input move have got this placement?
+                                "within_default_budget": (pl.get("searches") == 1 and (pl.get("walked_mb") or 0) <= 16 * 1024
+                                                          and bool(getattr(job, "output_apart", False))),
                                 "colocated_frac": (also or {}).get("ns4096_colocated", {}).get("frac") if isinstance(also, dict) else None}
         if also:
             res["also"] = also
