@@ -27,6 +27,7 @@
 namespace rtlfm {
 namespace boxfused {
 
+constexpr int kRdcMany = 18;  // buffers of 512 bytes: sixteen in a tile, and the two it may begin and end inside
 constexpr int kMaxD = 2047;
 constexpr int kTileBytes = 8192;
 constexpr int kTileSamples = 4096;
@@ -58,6 +59,10 @@ struct Params {
 	uint32_t *emit_iq;
 	size_t emit_iq_stride;      // dwords between streams
 	const int2 *rdc_avg;        // RDC kernels: [stream][nblocks] (avgI, avgQ) of dc_block_raw_filter (k_rdc_sums_wide / k_rdc_smooth)
+	// RDC on buffers shorter than a tile (round 6): a tile then holds up to kRdcMany buffers' averages - a table in LDS at
+	// dword rdc_tab ((a_j, base_j) per buffer of the tile), and x / (N0 / 256) for x < 64 as a multiply and a shift
+	int rdc_many, rdc_tab;
+	uint32_t rdc_m_magic;       // ceil(65536 / (N0 / 256))
 	// SQ kernels (the power squelch / -L behind the boxcar, round 5): [stream][nblocks] (sum of squares, sum) of every
 	// buffer's decimated elements, both modulo 2^32 as rms() has them (src/rtl_fm.c:1093-1098) - zeroed by the host, added
 	// to with atomics (a buffer's outputs come from several waves); k_squelch_apply makes the decisions
@@ -340,10 +345,15 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 
 	// (RDC) the buffer tile gt's first sample lies in and that sample's place inside it, carried from tile to tile
 	int rdc_b = 0, rdc_off = 0;
+	// (RDC, buffers shorter than a tile, round 6) lane j's averages of the j-th buffer of the NEXT tile to be worked on: loaded a
+	// tile ahead and in front of the tile prefetch, so that the in-order vmcnt never makes the prefetch land for them
+	// (the table behind p.rdc_avg has kRdcMany entries of slack behind the last stream's last buffer: rtlfm_hip.hip)
+	int2 a_tab = make_int2(0, 0);
 	if constexpr (RDC) {
 		const long long g = (long long)gt_begin * kTileSamples;
 		rdc_b = (int)(g / N0);
 		rdc_off = (int)(g - (long long)rdc_b * N0);
+		if (p.rdc_many && lane < kRdcMany) a_tab = p.rdc_avg[(size_t)s * p.nblocks + rdc_b + lane];
 	}
 	// fm_demod's first output of every buffer (below, behind the output loop): xs = where the next buffer start that no
 	// tile has looked at yet lies, as a sample position relative to tile gt's first sample.  The outputs that complete
@@ -378,7 +388,34 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		// dc_nb: the tile's first sample of the second buffer (beyond the tile when it holds one buffer's samples only)
 		uint32_t dc1 = 0, dc2 = 0, dc3 = 0, dh1 = 0, dh2 = 0, dh3 = 0, dc_base = 0;
 		int dc_nb = 1 << 30;
+		int rdc_off0 = 0;  // (RDC, many buffers per tile) this tile's first sample's place in its buffer
 		if constexpr (RDC) {
+		if (p.rdc_many) {
+			// Buffers shorter than a tile: the tile holds up to kRdcMany buffers' averages.  Entry j of a table in LDS =
+			// (a_j, base_j) of the j-th buffer that has samples in this tile; P_n finds j from n with a shift and a multiply.
+			// base_j (offset tuning only: the constant adds up) = what the buffers in front of j contributed minus start_j a_j,
+			// so that the correction of a prefix of n samples is n a_j + base_j; all in 16-bit lanes, which wrap as the sums do.
+			rdc_off0 = rdc_off;
+			uint32_t *tab = lds + p.rdc_tab;
+			__builtin_amdgcn_wave_barrier();
+			const uint32_t apk = pack_iq((int16_t)a_tab.x, (int16_t)a_tab.y);
+			if (lane < kRdcMany) tab[2 * lane] = apk;
+			__builtin_amdgcn_wave_barrier();
+			if (!p.rotate && lane < kRdcMany) {
+				fused::short2_t acc = {(short)0, (short)0};
+				for (int i = 0; i < lane; i++) {
+					const uint32_t len = (uint32_t)(i == 0 ? N0 - rdc_off : N0) & 0xffffu;
+					acc = acc + fused::as_s2(len * 0x00010001u) * fused::as_s2(tab[2 * i]);
+				}
+				const uint32_t start = (uint32_t)(lane == 0 ? 0 : lane * N0 - rdc_off) & 0xffffu;
+				tab[2 * lane + 1] = fused::as_u32(acc - fused::as_s2(start * 0x00010001u) * fused::as_s2(apk));
+			}
+			__builtin_amdgcn_wave_barrier();
+			rdc_off += kTileSamples;
+			while (rdc_off >= N0) { rdc_off -= N0; rdc_b++; }  // wave-uniform: sixteen times at most
+			// the next tile's averages, in front of the tile prefetch below
+			if (lane < kRdcMany) a_tab = p.rdc_avg[(size_t)s * p.nblocks + rdc_b + lane];
+		} else {
 			const int idx = __builtin_amdgcn_readfirstlane(s * p.nblocks + rdc_b);
 			const int idx2 = __builtin_amdgcn_readfirstlane(s * p.nblocks + (rdc_b + 1 < p.nblocks ? rdc_b + 1 : rdc_b));
 			const int2 a = p.rdc_avg[idx], a2 = p.rdc_avg[idx2];  // scalar loads: a vector one would share the in-order vmcnt with the tile prefetch
@@ -396,6 +433,36 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			rdc_off += kTileSamples;
 			if (rdc_off >= N0) { rdc_off -= N0; rdc_b++; }  // N0 >= 4096: once at most
 		}
+		}
+		// (RDC) what dc_block_raw_filter has taken off the tile's first n samples' sum, as packed (I, Q) in 16-bit lanes
+		auto rdc_corr = [&](int n) -> uint32_t {
+			if (p.rdc_many) {
+				const uint32_t x = (uint32_t)((n > 0 ? n : 1) - 1 + rdc_off0) >> 8;   // < 64
+				const uint32_t j = (x * p.rdc_m_magic) >> 16;                          // x / (N0 / 256): the buffer sample n - 1 lies in
+				const uint2 e = *reinterpret_cast<const uint2 *>(lds + p.rdc_tab + 2 * j);
+				if (p.rotate) {
+					// the rotated constant sums to zero over every four samples, and buffers are whole groups of four:
+					// a G(n & 3) of the buffer the prefix ends in - a, (aI + aQ, aQ - aI), (aQ, -aI)
+					const int k = n & 3;
+					const uint32_t c3 = fused::as_u32(fused::as_s2(__builtin_amdgcn_alignbit(e.x, e.x, 16)) * fused::short2_t{(short)1, (short)-1});
+					return k == 0 ? 0u : (k == 1 ? e.x : (k == 2 ? pk_add16(e.x, c3) : c3));
+				}
+				const uint32_t npk = (uint32_t)n * 0x00010001u;
+				return n > 0 ? fused::as_u32(fused::as_s2(npk) * fused::as_s2(e.x) + fused::as_s2(e.y)) : 0u;
+			}
+			if (p.rotate) {  // (wave-uniform)
+				const int k = n & 3;
+				const bool hi = n > dc_nb;  // (at the boundary itself k == 0: no correction either way)
+				const uint32_t c1 = hi ? dh1 : dc1, c2 = hi ? dh2 : dc2, c3 = hi ? dh3 : dc3;
+				return k == 0 ? 0u : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+			}
+			// offset tuning (round 6): nothing rotates, the constant simply adds up - n samples of the tile hold
+			// min(n, nb) times the first buffer's averages and the rest times the second's: one packed multiply-add
+			// (16-bit lanes wrap as the sums do), base = nb (a_lo - a_hi) behind the boundary
+			const bool hi = n > dc_nb;
+			const uint32_t npk = (uint32_t)n * 0x00010001u;  // n < 4097: (n, n)
+			return fused::as_u32(fused::as_s2(npk) * fused::as_s2(hi ? dh1 : dc1) + fused::as_s2(hi ? dc_base : 0u));
+		};
 
 		// ---- 1. stage S: chunk c = 64k + lane -> row c >> 3, 16-byte slot c & 7
 #pragma unroll
@@ -488,23 +555,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 				fs = plus ? fs : pk_sub16(0u, fs);
 				Pv = (n & 1) ? pk_add16(Pv, fs) : Pv;
 			}
-			if constexpr (RDC) {
-				if (p.rotate) {  // (wave-uniform)
-					const int k = n & 3;
-					const bool hi = n > dc_nb;  // (at the boundary itself k == 0: no correction either way)
-					const uint32_t c1 = hi ? dh1 : dc1, c2 = hi ? dh2 : dc2, c3 = hi ? dh3 : dc3;
-					const uint32_t corr = k == 0 ? 0u : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-					Pv = pk_sub16(Pv, corr);
-				} else {
-					// offset tuning (round 6): nothing rotates, the constant simply adds up - n samples of the tile hold
-					// min(n, nb) times the first buffer's averages and the rest times the second's: one packed multiply-add
-					// (16-bit lanes wrap as the sums do), base = nb (a_lo - a_hi) behind the boundary
-					const bool hi = n > dc_nb;
-					const uint32_t npk = (uint32_t)n * 0x00010001u;  // n < 4097: (n, n)
-					const fused::short2_t corr = fused::as_s2(npk) * fused::as_s2(hi ? dh1 : dc1) + fused::as_s2(hi ? dc_base : 0u);
-					Pv = pk_sub16(Pv, fused::as_u32(corr));
-				}
-			}
+			if constexpr (RDC) Pv = pk_sub16(Pv, rdc_corr(n));
 			return Pv;
 		};
 		auto P_at = [&](int e) -> uint32_t { return P_n((e + 1) * D - ph); };  // P(n_e) for e >= 0
@@ -614,15 +665,9 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		// ---- 5. the window the tile leaves unfinished: fewer than D <= 256 samples, exact in 16 bits
 		{
 			uint32_t tot_c = tot;
-			if constexpr (RDC) {
-				// (with the rotation the constant has summed to zero over the tile's whole groups of four; without it - offset
-				// tuning - the tile's vs samples hold nb times the first buffer's averages and the rest times the second's)
-				if (!p.rotate) {
-					const bool hi = vs > dc_nb;
-					const uint32_t npk = (uint32_t)vs * 0x00010001u;
-					tot_c = pk_sub16(tot, fused::as_u32(fused::as_s2(npk) * fused::as_s2(hi ? dh1 : dc1) + fused::as_s2(hi ? dc_base : 0u)));
-				}
-			}
+			// (with the rotation the constant has summed to zero over the tile's whole groups of four - vs is a multiple of
+			// four -; without it - offset tuning - the tile's vs samples hold their buffers' averages times their counts)
+			if constexpr (RDC) tot_c = pk_sub16(tot, rdc_corr(vs));
 			const iq16 part = unpack_iq(pk_sub16(tot_c, Plast));
 			carry_r = part.i; carry_j = part.q;
 		}
@@ -692,9 +737,9 @@ inline bool supported_front(const rtlfm_cfg &c)
 	// (downsample == 1, rtl_fm -s 1.2M: low_pass() hands every sample on - 4096 outputs per tile, the same kernel)
 	if (c.downsample_passes != 0 || c.downsample < 1 || c.downsample > kMaxD) return false;
 	if (c.comp_fir_size) return false;
-	// -E rdc: a tile may hold samples of two buffers, not of three.  (With the rotation the constant sums to zero over every
-	// four samples; with offset tuning - no rotation - it adds up linearly: one packed multiply-add per look-up, round 6.)
-	if (c.dc_block_raw && c.block_len < (uint32_t)kTileBytes) return false;
+	// -E rdc: any buffer size (round 6: a tile of buffers shorter than itself looks its averages up in a table in LDS);
+	// with the rotation the constant sums to zero over every four samples, with offset tuning - no rotation - it adds up
+	// linearly: one packed multiply-add per look-up
 	return true;  // else any buffer length (a multiple of 512 bytes): the run is one continuous sample stream here
 }
 
@@ -772,7 +817,15 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 		p.store_lines_nt = ws.box_store >= 0 ? (ws.box_store ? 1 : 0) : (out_bytes > 192.0 * 1048576.0 ? 1 : 0);
 	}
 	p.R = (p.q4096 + 1 + 63) / 64;
-	const size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0, emit_iq != nullptr) * 4;
+	size_t lds_bytes = (size_t)ScanLds::total(p.out_cap, p.has_first != 0, emit_iq != nullptr) * 4;
+	if (rdc_avg && c.block_len < (uint32_t)kTileBytes) {
+		// buffers shorter than a tile: the tile's table of averages behind everything else in LDS
+		p.rdc_many = 1;
+		p.rdc_tab = (int)(((lds_bytes / 4) + 1) & ~(size_t)1);
+		lds_bytes = (size_t)(p.rdc_tab + 2 * kRdcMany) * 4;
+		const uint32_t m = c.block_len / 512;  // N0 / 256, 1 .. 15
+		p.rdc_m_magic = (65536u + m - 1) / m;
+	}
 	const bool fast_fm = c.custom_atan == RTLFM_ATAN_FAST && c.mode == RTLFM_MODE_FM;
 #define RTLFM_BOX_GO(VV, RR, SS) hipLaunchKernelGGL((k_boxcar_scan<VV, RR, SS>), dim3(waves), dim3(64), lds_bytes, q, p)
 	const int vsel = emit_iq ? 3 : std_fm ? 1 : fast_fm ? 2 : 0;

@@ -380,7 +380,7 @@ static int create_body(rtlfm_gpu *h)
 	HIP_TRY(hipMalloc(&h->d_levels, S * h->cap_blocks * sizeof(int32_t)));
 	HIP_TRY(hipMalloc(&h->d_sums, S * h->cap_blocks * 2 * sizeof(long long)));
 	HIP_TRY(hipMalloc(&h->d_adc_sums, S * h->cap_blocks * sizeof(long long)));
-	HIP_TRY(hipMalloc(&h->d_rdc_avg, S * h->cap_blocks * sizeof(int2)));
+	HIP_TRY(hipMalloc(&h->d_rdc_avg, (S * h->cap_blocks + 32) * sizeof(int2)));  // (+ slack: k_boxcar_scan reads kRdcMany entries from a tile's first buffer on)
 	HIP_TRY(hipMalloc(&h->d_sq_sums, S * h->cap_blocks * 2 * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc(&h->d_adc_avg, S * h->cap_blocks * sizeof(int32_t)));
 	if (cfg->custom_atan == RTLFM_ATAN_LUT) {
@@ -1440,7 +1440,11 @@ static const int2 *rdc_prepass(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_
 	const rtlfm_cfg &c = h->cfg;
 	if (!c.dc_block_raw) return nullptr;
 	const int S = h->nstreams;
-	k_rdc_sums_wide<<<(unsigned)((size_t)S * nblocks), 256, 0, h->stream>>>(d_iq, stream_stride, c.block_len, nblocks, h->d_sums);
+	if (c.block_len < 8192) {  // buffers shorter than a tile: a wave per buffer (staged_kernels.h)
+		const size_t total = (size_t)S * nblocks;
+		k_rdc_sums_small<<<(unsigned)((total + 3) / 4), 256, 0, h->stream>>>(d_iq, stream_stride, c.block_len, nblocks, total, h->d_sums);
+	} else
+		k_rdc_sums_wide<<<(unsigned)((size_t)S * nblocks), 256, 0, h->stream>>>(d_iq, stream_stride, c.block_len, nblocks, h->d_sums);
 	k_rdc_smooth<<<grid_for(S, 64), 64, 0, h->stream>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, h->st[h->st_cur],
 	                                                  h->st[(h->st_cur + 1) % 3], h->d_rdc_avg);
 	return h->d_rdc_avg;

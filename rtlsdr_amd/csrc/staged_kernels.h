@@ -154,6 +154,41 @@ k_rdc_sums_wide(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L
 	}
 }
 
+// The same for buffers shorter than a tile of the front ends (-W 1 ... 15: 512 ... 7680 bytes; round 6): a WAVE per
+// (stream, buffer), four to a workgroup, no barrier - a workgroup of 256 threads per 512-byte buffer was a million
+// workgroups per 4 GiB whose launch alone took longer than the front end.
+__global__ void __launch_bounds__(256)
+k_rdc_sums_small(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t L, int nblocks, size_t total, long long *__restrict__ sums /* [s][b][2] */)
+{
+	const size_t sb = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (sb >= total) return;
+	const int lane = threadIdx.x & 63;
+	const size_t s = sb / (unsigned)nblocks;
+	const int b = (int)(sb % (unsigned)nblocks);
+	const uint8_t *src = iq + s * stream_stride + (size_t)b * L;
+	unsigned si = 0, sq = 0;
+	const uint32_t n16 = L / 16;  // L is a multiple of 512
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	const v4u *src4 = reinterpret_cast<const v4u *>(src);
+	for (uint32_t k = lane; k < n16; k += 64) {
+		const v4u v = __builtin_nontemporal_load(src4 + k);
+		si = __builtin_amdgcn_udot4(v.x, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.x, 0x01000100u, sq, false);
+		si = __builtin_amdgcn_udot4(v.y, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.y, 0x01000100u, sq, false);
+		si = __builtin_amdgcn_udot4(v.z, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.z, 0x01000100u, sq, false);
+		si = __builtin_amdgcn_udot4(v.w, 0x00010001u, si, false); sq = __builtin_amdgcn_udot4(v.w, 0x01000100u, sq, false);
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		si += __shfl_down(si, off, 64);
+		sq += __shfl_down(sq, off, 64);
+	}
+	if (lane == 0) {
+		const long long pairs = L / 2;
+		sums[sb * 2] = (long long)si - 127 * pairs;
+		sums[sb * 2 + 1] = (long long)sq - 127 * pairs;
+	}
+}
+
+
 // The smoothing recurrence of dc_block_raw_filter (src/rtl_fm.c:1054-1057,
 // :1062-1063), sequential over a stream's blocks.  One thread per stream.
 __global__ void k_rdc_smooth(const long long *__restrict__ sums, uint32_t L, int nblocks, int nstreams,

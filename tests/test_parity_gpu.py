@@ -378,6 +378,42 @@ def test_raw_dc_block_in_front_of_the_boxcar(oracle_lib, D, atan, extra):
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
 
 
+@pytest.mark.parametrize("L", [512, 1024, 1536, 3584, 4096, 7680])
+@pytest.mark.parametrize("D,atan,extra", [(10, 0, {}), (6, 1, {}), (7, 2, {}), (10, 0, dict(offset_tuning=1)), (6, 1, dict(offset_tuning=1)),
+                                          (42, 0, dict(offset_tuning=1)), (10, 0, dict(mode=4)), (10, 0, dict(mode=4, offset_tuning=1)),
+                                          (84, 0, dict(mode=1, output_scale=3)), (1, 0, {}), (1, 0, dict(offset_tuning=1))])
+def test_raw_dc_block_in_front_of_the_boxcar_on_buffers_shorter_than_a_tile(oracle_lib, D, atan, extra, L):
+    """-E rdc without -F on buffers below 8192 bytes (-W 1 ... 15): a tile of the boxcar kernel then holds up to eighteen
+    buffers' averages - a table in LDS, the buffer of a prefix found with a shift and a multiply (round 6; until then the
+    last `-E rdc` case on the stage-by-stage kernels: 13.4 ms per 4 GiB).  With and without the rotation, every 512 n below a
+    tile, drifting DC offsets per buffer, full-scale bytes, split launches, segments that start anywhere."""
+    if D > L // 2:
+        pytest.skip("a boxcar longer than the buffer: outside the reference's domain")
+    ov = dict(downsample=D, downsample_passes=0, custom_atan=atan, dc_block_raw=1, rate_out=int(2.4e6 / D))
+    ov.update(extra)
+    nb, ns = 37, 5
+    cfg = make_cfg(ov, L, nb)
+    amp = max(2.0, min(25.0, 400.0 / D)) if atan == 1 else 50.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=9100 + D + L, fs=2.4e6, dev_hz=75e3, amplitude=amp)
+    rng = np.random.default_rng(D + L)
+    for s_ in range(ns - 1):
+        for b in range(nb):
+            off = rng.integers(-30, 31, size=2) if atan == 1 else rng.integers(-60, 61, size=2)
+            blk = iq[s_, b * L:(b + 1) * L].astype(np.int32)
+            blk[0::2] += off[0]; blk[1::2] += off[1]
+            iq[s_, b * L:(b + 1) * L] = np.clip(blk, 0, 255).astype(np.uint8)
+    if atan != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=D + L)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits, opts in ((None, None), ([(0, 1), (1, 20), (20, nb)], None), (None, dict(fused_waves=1)), (None, dict(fused_tiles_per_seg=1))):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits, options=opts)
+        assert used == 2, "the raw DC block in front of the boxcar must not fall back to the staged kernels"
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_]
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"rdc box D={D} L={L} {extra} {splits} {opts} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
+
+
 @pytest.mark.parametrize("L", [24576, 40960, 8192 * 7])
 @pytest.mark.parametrize("front", ["p4", "p4rdc", "p5fir", "box10"])
 def test_buffer_sizes_that_are_not_powers_of_two(oracle_lib, front, L):
@@ -464,8 +500,6 @@ def round_four_case(front, L):
     if front.startswith("box"):
         D = int("".join(ch for ch in front[3:6] if ch.isdigit()))
         ov = dict(downsample=D, downsample_passes=0, rate_out=int(2.4e6 / D))
-        if rdc and L < 8192:
-            pytest.skip("the raw DC block in front of the boxcar needs buffers of a tile at least (shorter: the staged kernels)")
     else:
         passes = int(front[1])
         ov = dict(downsample=1 << passes, downsample_passes=passes, comp_fir_size=9 if "fir" in front else 0)
