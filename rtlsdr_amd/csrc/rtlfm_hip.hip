@@ -1303,7 +1303,7 @@ static int run_staged(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, i
 	const int2 *rdc = nullptr;
 	if (c.dc_block_raw) {
 		k_rdc_sums<<<S * nblocks, 256, 0, q>>>(d_iq, stream_stride, L, nblocks, h->d_sums);
-		k_rdc_smooth<<<grid_for(S, 64), 64, 0, q>>>(h->d_sums, L, nblocks, S, c.rdc_block_const, sin, sout,
+		k_rdc_smooth<<<(unsigned)S, 64, 0, q>>>(h->d_sums, L, nblocks, S, c.rdc_block_const, sin, sout,
 		                                           h->d_rdc_avg);
 		rdc = h->d_rdc_avg;
 	}
@@ -1445,7 +1445,7 @@ static const int2 *rdc_prepass(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_
 		k_rdc_sums_small<<<(unsigned)((total + 3) / 4), 256, 0, h->stream>>>(d_iq, stream_stride, c.block_len, nblocks, total, h->d_sums);
 	} else
 		k_rdc_sums_wide<<<(unsigned)((size_t)S * nblocks), 256, 0, h->stream>>>(d_iq, stream_stride, c.block_len, nblocks, h->d_sums);
-	k_rdc_smooth<<<grid_for(S, 64), 64, 0, h->stream>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, h->st[h->st_cur],
+	k_rdc_smooth<<<(unsigned)S, 64, 0, h->stream>>>(h->d_sums, c.block_len, nblocks, S, c.rdc_block_const, h->st[h->st_cur],
 	                                                  h->st[(h->st_cur + 1) % 3], h->d_rdc_avg);
 	return h->d_rdc_avg;
 }
@@ -1839,7 +1839,11 @@ static int run_device_verified(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_
 	int r = run_device_once(h, d_iq, stream_stride, nblocks, h->vt_out, out_stride, h->vt_len);
 	if (r < 0) return r;
 	HIP_TRY(sync_all(h));
-	HIP_TRY(hipMemcpy(h->vt_state, sout, S * sizeof(state_t), hipMemcpyDeviceToDevice));
+	// (on the handle's own stream and waited for: a device-to-device hipMemcpy is only ordered on the NULL stream and returns
+	// before it has run - the second execution, on a non-blocking stream, then overwrote the record while it was being copied,
+	// and the comparison reported state words that had never differed: one red run of the suite in round 6)
+	HIP_TRY(hipMemcpyAsync(h->vt_state, sout, S * sizeof(state_t), hipMemcpyDeviceToDevice, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
 	if (h->opt.verify_inject) {
 		// (tests: a difference the comparison must report - the shadow's first sample with every bit turned over)
 		int16_t v = 0;

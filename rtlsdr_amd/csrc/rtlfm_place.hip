@@ -297,6 +297,7 @@ extern "C" int rtlfm_gpu_copy(int device, void *dst, const void *src, size_t byt
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -ENODEV;
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+	HIP_TRY(hipStreamSynchronize(nullptr));  // (a device-to-device hipMemcpy is ordered on the null stream but may return before it has run)
 	return 0;
 }
 

@@ -189,23 +189,43 @@ k_rdc_sums_small(const uint8_t *__restrict__ iq, size_t stream_stride, uint32_t 
 }
 
 
-// The smoothing recurrence of dc_block_raw_filter (src/rtl_fm.c:1054-1057,
-// :1062-1063), sequential over a stream's blocks.  One thread per stream.
-__global__ void k_rdc_smooth(const long long *__restrict__ sums, uint32_t L, int nblocks, int nstreams,
-                             int k, const state_t *__restrict__ sin, state_t *__restrict__ sout,
-                             int2 *__restrict__ avg)
+// The smoothing recurrence of dc_block_raw_filter (src/rtl_fm.c:1054-1057, :1062-1063), sequential over a stream's
+// buffers.  One WAVE per stream (round 6): the block means - a 64-bit division each, independent of each other - are taken
+// by 64 lanes at a time, and only the recurrence itself, avg = (mean + avg k) / (k + 1), runs down one lane, out of LDS,
+// with the division by the fixed k + 1 as sdiv_trunc.  (Until then one lane per stream did everything, a dependent load and
+// four divisions a step: 1.2 us per buffer - 5 ms of the 5.8 ms of `-E rdc` on 4096-byte buffers, 0.3 ms per 256 buffers.)
+__global__ void __launch_bounds__(64)
+k_rdc_smooth(const long long *__restrict__ sums, uint32_t L, int nblocks, int nstreams,
+             int k, const state_t *__restrict__ sin, state_t *__restrict__ sout,
+             int2 *__restrict__ avg)
 {
-	RTLFM_GRID_STRIDE(s, nstreams) {
-		int pi = sin[s].dc_avgI, pq = sin[s].dc_avgQ;
-		const int pairs = (int)(L / 2);
-		for (int b = 0; b < nblocks; b++) {
-			int mi = (int)(sums[(s * nblocks + b) * 2] / pairs);
-			int mq = (int)(sums[(s * nblocks + b) * 2 + 1] / pairs);
-			mi = (mi + pi * k) / (k + 1);
-			mq = (mq + pq * k) / (k + 1);
-			avg[s * nblocks + b] = make_int2(mi, mq);
-			pi = mi; pq = mq;
+	const size_t s = blockIdx.x;
+	if (s >= (size_t)nstreams) return;
+	const int lane = (int)threadIdx.x;
+	__shared__ int2 m[64];
+	int pi = sin[s].dc_avgI, pq = sin[s].dc_avgQ;
+	const int pairs = (int)(L / 2);
+	for (int base = 0; base < nblocks; base += 64) {
+		const int b = base + lane;
+		if (b < nblocks) {
+			m[lane] = make_int2((int)(sums[(s * nblocks + b) * 2] / pairs), (int)(sums[(s * nblocks + b) * 2 + 1] / pairs));
 		}
+		__syncthreads();
+		if (lane == 0) {
+			const int cnt = nblocks - base < 64 ? nblocks - base : 64;
+			for (int t = 0; t < cnt; t++) {
+				const int2 v = m[t];
+				const int ni = (int)((uint32_t)v.x + (uint32_t)pi * (uint32_t)k), nq = (int)((uint32_t)v.y + (uint32_t)pq * (uint32_t)k);
+				pi = k + 1 != 0 ? sdiv_trunc(ni, k + 1) : 0;
+				pq = k + 1 != 0 ? sdiv_trunc(nq, k + 1) : 0;
+				m[t] = make_int2(pi, pq);
+			}
+		}
+		__syncthreads();
+		if (b < nblocks) avg[s * nblocks + b] = m[lane];
+		__syncthreads();
+	}
+	if (lane == 0) {
 		sout[s].dc_avgI = pi;
 		sout[s].dc_avgQ = pq;
 	}
