@@ -2315,8 +2315,15 @@ __device__ __forceinline__ void arb_upsample_wave(const int16_t *a, int16_t *bo,
 // One workgroup of `wpw` waves per stream; wave w takes the spans w, w + wpw, ... of its stream, each wave with an
 // LDS region of its own (the span's traffic is wave-private: wave barriers, no workgroup barrier inside the loop).
 constexpr int kSpecArbMaxWaves = 8;
+// (A/B builds, tools/build_variant.sh arb64 -DRTLFM_ARB_WAVES8: the kernel held to 64 registers so that TWO of its waves fit
+// the hole one front-end wave leaves on a SIMD - LAB.md I.28)
+#ifdef RTLFM_ARB_WAVES8
+#define RTLFM_ARB_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define RTLFM_ARB_ATTR
+#endif
 template <int MAGIC>
-__global__ void __launch_bounds__(64 * kSpecArbMaxWaves)
+__global__ void __launch_bounds__(64 * kSpecArbMaxWaves) RTLFM_ARB_ATTR
 k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
                   int N, int len2, int nblocks, const int32_t *__restrict__ tab_i, const double *__restrict__ tab_frac,
                   int16_t *__restrict__ B, size_t bstride,
