@@ -242,6 +242,13 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		ph = (int)(n % D);
 		kb = (int)(n / D);
 	}
+	// (ph + x) / D for a position inside the tile's range of outputs: a multiply-high while n D < 2^32; beyond /2047
+	// (round 6) a tile completes two outputs at most, so the quotient is 0, 1 or 2: two compares
+	auto div_D = [&](int n) -> int {
+		if (D == 1) return n;
+		if (D > kMaxD) return (n >= D ? 1 : 0) + (n >= 2 * D ? 1 : 0);
+		return (int)__umulhi((uint32_t)n, p.D_magic);
+	};
 	// 4096 is even, so the parity of the phase is that of p0 when D is even: wave-uniform for the run
 	const bool need_odd = (D & 1) || (ph & 1);
 	const bool first_in_lds = need_odd && p.has_first;
@@ -566,7 +573,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		int sq_eb = 1 << 30;
 		uint32_t sq_p0 = 0, sq_t0 = 0, sq_p1 = 0, sq_t1 = 0;
 		if constexpr (SQ) {
-			if (xs < Et * D - ph) sq_eb = D == 1 ? ph + xs : (int)__umulhi((uint32_t)(ph + xs), p.D_magic);
+			if (xs < Et * D - ph) sq_eb = div_D(ph + xs);
 		}
 		uint32_t prevP, b;
 		{
@@ -644,7 +651,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 					// numbers, one multiply-high per buffer start (round 5; three 64-bit divisions per tile until then).
 					__builtin_amdgcn_wave_barrier();
 					for (int x = xs + lane * N0; x < lim; x += 64 * N0) {
-						const int e = D == 1 ? ph + x : (int)__umulhi((uint32_t)(ph + x), p.D_magic);
+						const int e = div_D(ph + x);
 						const uint32_t Pe = P_at(e), P1 = e > 0 ? P_at(e - 1) : edgeP, P2 = e > 1 ? P_at(e - 2) : edgeP;
 						const uint32_t z0 = pk_sub16(Pe, P1), b0 = e > 0 ? pk_sub16(P1, P2) : last_out;
 						const uint32_t bsw = __builtin_amdgcn_alignbit(b0, b0, 16);
@@ -660,8 +667,10 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		}
 		xs -= kTileSamples;
 		__builtin_amdgcn_wave_barrier();
-		const uint32_t Plast = lds[ScanLds::scratch];
-		last_out = lds[ScanLds::scratch + 1];
+		// (a tile that completes no output - boxcars beyond /4096, round 6 - leaves the last output where it was and adds
+		// all of itself to the unfinished window: "the boundary" is then the carried sum's negative, as at the tile's start)
+		const uint32_t Plast = Et > 0 ? lds[ScanLds::scratch] : edgeP;
+		if (Et > 0) last_out = lds[ScanLds::scratch + 1];
 		// ---- 5. the window the tile leaves unfinished: fewer than D <= 256 samples, exact in 16 bits
 		{
 			uint32_t tot_c = tot;
@@ -735,7 +744,9 @@ inline bool supported_front(const rtlfm_cfg &c)
 	// at least two outputs per 4096-sample tile: a wave that starts mid-stream takes its first
 	// "previous output" from its warm-up tile
 	// (downsample == 1, rtl_fm -s 1.2M: low_pass() hands every sample on - 4096 outputs per tile, the same kernel)
-	if (c.downsample_passes != 0 || c.downsample < 1 || c.downsample > kMaxD) return false;
+	// (beyond /2047 - rtl_fm -s 400 - a tile completes two outputs at most and a mid-stream wave could not warm up on one
+	// tile: those runs take ONE wave per stream, launch(); round 6)
+	if (c.downsample_passes != 0 || c.downsample < 1) return false;
 	if (c.comp_fir_size) return false;
 	// -E rdc: any buffer size (round 6: a tile of buffers shorter than itself looks its averages up in a table in LDS);
 	// with the rotation the constant sums to zero over every four samples, with offset tuning - no rotation - it adds up
@@ -797,7 +808,10 @@ inline int launch(fused::Workspace &ws, const rtlfm_cfg &c, int nstreams, const 
 	p.D_magic = p.D == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)p.D - 1) / (uint64_t)p.D);  // (D == 1: no division)
 	p.out_cap = kTileSamples / p.D + 2;
 	const long long run_bytes = (long long)nblocks * c.block_len;
-	const fused::SegPlan sp = fused::plan_segments(ws, nstreams, (int)((run_bytes + kTileBytes - 1) / kTileBytes));
+	const int total_tiles_run = (int)((run_bytes + kTileBytes - 1) / kTileBytes);
+	fused::SegPlan sp;
+	if (p.D > kMaxD) { sp.segs = 1; sp.tiles_per_seg = total_tiles_run; sp.nlist = 0; }  // every carried quantity reaches back up to 2 D samples
+	else sp = fused::plan_segments(ws, nstreams, total_tiles_run);
 	p.segs = sp.segs; p.tiles_per_seg = sp.tiles_per_seg; p.nlist = sp.nlist;
 	if (sp.nlist) memcpy(p.seg_start, sp.start, sizeof(int) * (size_t)(sp.nlist + 1));
 	const int waves = nstreams * sp.segs;

@@ -414,6 +414,35 @@ def test_raw_dc_block_in_front_of_the_boxcar_on_buffers_shorter_than_a_tile(orac
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False)
 
 
+@pytest.mark.parametrize("extra", [{}, dict(custom_atan=1), dict(custom_atan=2), dict(dc_block_raw=1), dict(dc_block_raw=1, offset_tuning=1),
+                                   dict(mode=4), dict(mode=1, output_scale=2), dict(squelch_level=40), dict(offset_tuning=1)])
+@pytest.mark.parametrize("D", [2048, 2400, 4095, 4096, 4097, 9000, 65536, 131072])
+def test_boxcars_beyond_2047(oracle_lib, D, extra):
+    """low_pass() with downsample > 2047 (rtl_fm -s 400: optimal_settings gives 1000000 / 400 + 1 = 2501; src/rtl_fm.c:461-481,
+    1415) on the one-launch front end (round 6; the last configurations the stage-by-stage kernels had to themselves: 18.9 ms
+    per 4 GiB).  A tile of 4096 samples then completes two outputs at most and often none - the unfinished window grows
+    across tiles -, and a wave could not warm up on one tile: one wave per stream.  Through every discriminator, the raw DC
+    block with and without the rotation, -M raw, AM, the squelch; runs split over launches; the window carried across runs."""
+    L, nb, ns = 262144, 5, 4
+    if D > L // 2:
+        pytest.skip("a boxcar longer than the buffer: outside the reference's domain")
+    ov = dict(downsample=D, downsample_passes=0, rate_out=max(1, int(2.4e6 / D)))
+    ov.update(extra)
+    cfg = make_cfg(ov, L, nb)
+    amp = max(0.05, min(25.0, 300.0 / D)) if extra.get("custom_atan") == 1 else 20.0
+    iq = synth.fm_iq_u8(ns, L // 2 * nb, seed=1300 + D, fs=2.4e6, dev_hz=30.0, amplitude=amp)
+    if extra.get("custom_atan") != 1:
+        iq[ns - 1] = synth.random_u8(1, L * nb, seed=D)[0]
+    want, want_len, wst = oracle_lib.run_batch(cfg, iq, nthreads=4)
+    for splits in (None, [(0, 1), (1, 3), (3, nb)]):
+        outs, sts, used = gpu_run(cfg, iq, path=0, splits=splits)
+        assert used == 2, "boxcars beyond 2047 must not fall back to the staged kernels"
+        for s_ in range(ns):
+            assert len(outs[s_]) == want_len[s_], (D, extra, splits, s_, len(outs[s_]), want_len[s_])
+            assert_parity(outs[s_], want[s_, :want_len[s_]], cfg, f"box D={D} {extra} {splits} stream {s_}")
+            assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (D, extra, splits, s_)
+
+
 @pytest.mark.parametrize("L", [24576, 40960, 8192 * 7])
 @pytest.mark.parametrize("front", ["p4", "p4rdc", "p5fir", "box10"])
 def test_buffer_sizes_that_are_not_powers_of_two(oracle_lib, front, L):

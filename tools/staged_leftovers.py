@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""What is left to the stage-by-stage kernels (tools/path_census.py: 7 of 561 random configurations), with its cost stated and
-frozen (task 9): `-E rdc` with offset tuning in front of the boxcar, `-E rdc` in front of the boxcar on buffers
-below 8192 bytes, a boxcar beyond /2047 - each timed on 4 GiB resident in HBM beside its nearest one-launch neighbour.
+"""What round 5 had left to the stage-by-stage kernels (tools/path_census.py: 7 of 561 random configurations; VERDICT r5, task
+9) - `-E rdc` with offset tuning in front of the boxcar, `-E rdc` in front of the boxcar on buffers below 8192 bytes, a
+boxcar beyond /2047 - each timed on 4 GiB resident in HBM beside its nearest neighbour.  Round 6 moved all three onto the
+one-launch front end (profiles/r06_staged_leftovers.txt: 7.75 -> 1.54, 13.4 -> 2.5, 18.9 -> 4.1 ms; the last at 256
+streams = 256 waves - beyond /2047 a run is one wave per stream).
 ms per 4 GiB step, the path the run took (1 = staged, 2 = one-launch front end), fraction of 8 TB/s for the algorithmic bytes."""
 import ctypes as C
 import os
@@ -18,11 +20,11 @@ from rtlsdr_amd.demod import GpuDemod  # noqa: E402
 # (what, cfg overrides, block_len)
 LINES = [
     ("boxcar /10 -E rdc (one launch + sums pre-pass)", dict(downsample=10, dc_block_raw=1, rate_out=240000), 262144),
-    ("boxcar /10 -E rdc, offset tuning  [staged]", dict(downsample=10, dc_block_raw=1, offset_tuning=1, rate_out=240000), 262144),
-    ("boxcar /10 -E rdc, 4096-byte buffers  [staged]", dict(downsample=10, dc_block_raw=1, rate_out=240000), 4096),
+    ("boxcar /10 -E rdc, offset tuning (r5: staged)", dict(downsample=10, dc_block_raw=1, offset_tuning=1, rate_out=240000), 262144),
+    ("boxcar /10 -E rdc, 4096-byte buffers (r5: staged)", dict(downsample=10, dc_block_raw=1, rate_out=240000), 4096),
     ("boxcar /10, 4096-byte buffers (one launch)", dict(downsample=10, rate_out=240000), 4096),
     ("boxcar /2047 (one launch)", dict(downsample=2047, rate_out=1000), 262144),
-    ("boxcar /2400  [staged]", dict(downsample=2400, rate_out=1000), 262144),
+    ("boxcar /2400 (r5: staged)", dict(downsample=2400, rate_out=1000), 262144),
 ]
 
 
