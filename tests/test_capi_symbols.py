@@ -125,6 +125,23 @@ def test_create_without_gpu_fails_loudly(lib):
     assert b"no CPU fallback" in lib.rtlfm_gpu_strerror(-19)
 
 
+def test_device_memory_helpers_without_gpu_fail_loudly(lib):
+    """The placement and device-memory entry points (rtlfm_place.hip) say -ENODEV / -EINVAL without a device - no fallback, no
+    host memory dressed as device memory - and reject bad arguments before they look for one."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_parity_gpu.py covers these")
+    a, b = C.c_void_p(), C.c_void_p()
+    ap, tr = C.c_int(), C.c_int()
+    assert lib.rtlfm_gpu_place_pair(0, 1 << 20, 1 << 20, 1 << 30, 0, C.byref(a), C.byref(b), C.byref(ap), C.byref(tr), None, None) == -22  # max_tries < 1
+    assert lib.rtlfm_gpu_place_pair(0, 0, 1 << 20, 1 << 30, 2, C.byref(a), C.byref(b), None, None, None, None) == -22
+    assert lib.rtlfm_gpu_place_pair(0, 1 << 20, 1 << 20, 1 << 30, 2, C.byref(a), C.byref(b), C.byref(ap), C.byref(tr), None, None) == -19
+    assert a.value is None and b.value is None
+    assert lib.rtlfm_gpu_malloc(0, 4096, C.byref(a)) < 0 and a.value is None
+    assert lib.rtlfm_gpu_copy(0, None, None, 16) == -22
+    assert lib.rtlfm_gpu_copy(0, 16, 32, 16) == -19
+
+
 def test_product_does_not_touch_oracle():
     """No file of the shipped package may reference the checker."""
     pkg = os.path.join(ROOT, "rtlsdr_amd")
