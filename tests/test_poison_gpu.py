@@ -25,7 +25,8 @@ def test_parity_suites_under_poison():
     assert "poison 1" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_parity_gpu.py"), os.path.join(ROOT, "tests", "test_power_gpu.py"),
-                        "-k", "golden or random or any_512n or one_frame_per_read or several_frames"],
+                        "-k", "golden or random or any_512n or one_frame_per_read or several_frames or beyond_2047 or shorter_than_a_tile "
+                              "or lpr_slim or passes_do_not_divide"],  # (+ round 6's kernels: the LDS array of k_fifth_irregular, the table of averages of k_boxcar_scan, k_deemph_lpr_slim)
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
