@@ -177,6 +177,9 @@ __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return fu
 #define BOX_PHASE(k) do { } while (0)
 #endif
 
+#ifndef RTLFM_BOX_UNROLL2
+#define RTLFM_BOX_UNROLL2 0
+#endif
 #ifndef RTLFM_BOXSCAN_WAVES_PER_SIMD
 #define RTLFM_BOXSCAN_WAVES_PER_SIMD 4
 #endif
@@ -585,6 +588,50 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 		int n_next = (e0 + 2) * D - ph;  // n of output e + 1: D further per round (a 32-bit multiply per look-up issues at quarter rate)
 		// (The per-lane `if`s below are cheaper than they look: a branch-free form - outputs past Et computed
 		// and dumped, the last output's boundary kept in registers - measured 8-13 % SLOWER.)
+#if RTLFM_BOX_UNROLL2
+		// (A/B builds, tools/build_variant.sh box_unroll2 -DRTLFM_BOX_UNROLL2=1: two outputs per round - the three register
+		// moves that hand (previous boundary, previous output, next boundary) on to the next round and half of the loop's
+		// own bookkeeping go; LAB.md I.29)
+		auto out1 = [&](const int e, const uint32_t cP, const uint32_t pP, const uint32_t bb, const bool on) -> uint32_t {
+			const uint32_t z = pk_sub16(cP, pP);  // lowpassed[] is int16 (src/rtl_fm.c:473-474)
+			if (EMIT) {
+				if (on && e < Et) {
+					lds[pcm_at + pcm_idx(e)] = z;
+					if (e == Et - 1) { lds[ScanLds::scratch] = cP; lds[ScanLds::scratch + 1] = z; }
+				}
+			} else if (on && e < Et) {
+				if constexpr (SQ) {
+					// rms()'s two sums over the elements of this output (I and Q), by the buffer the output belongs to
+					const fused::short2_t zz = fused::as_s2(z), ones = {(short)1, (short)1};
+					const uint32_t sq = (uint32_t)__builtin_amdgcn_sdot2(zz, zz, 0, false), sm = (uint32_t)__builtin_amdgcn_sdot2(zz, ones, 0, false);
+					if (e < sq_eb) { sq_p0 += sq; sq_t0 += sm; } else { sq_p1 += sq; sq_t1 += sm; }
+				}
+				const uint32_t bsw = __builtin_amdgcn_alignbit(bb, bb, 16);
+				const uint32_t bx = fused::as_u32(fused::as_s2(bsw) * fused::short2_t{(short)-1, (short)1});
+				int cr, cj;
+				fused::dot2_pair(z, bb, bx, cr, cj);
+				int v;
+				if (V == 0 && p.mode != RTLFM_MODE_FM) v = simple_demod(p.mode, z, p.output_scale);
+				else if (V == 1) v = atan2_q14(cj, cr, nodes);
+				else if (V == 2) v = fast_atan2_q14(cj, cr);
+				else if (p.variant == RTLFM_ATAN_FAST) v = fast_atan2_q14(cj, cr);
+				else v = lut_atan2_q14_direct(cj, cr, nodes);
+				pcm[pcm_idx(e)] = (uint16_t)(int16_t)v;
+				if (e == Et - 1) {  // the last complete output: its boundary and its value
+					lds[ScanLds::scratch] = cP;
+					lds[ScanLds::scratch + 1] = z;
+				}
+			}
+			return z;
+		};
+		for (int r = 0; r < R; r += 2) {
+			const uint32_t P1 = P_n(n_next), P2 = P_n(n_next + D);
+			n_next += 2 * D;
+			const uint32_t z0 = out1(e0 + r, curP, prevP, b, true);
+			const uint32_t z1 = out1(e0 + r + 1, P1, curP, z0, r + 1 < R);  // (an odd R: the lane's range ends in the middle of the round)
+			prevP = P1; b = z1; curP = P2;
+		}
+#else
 		for (int r = 0; r < R; r++) {
 			const int e = e0 + r;
 			const uint32_t nxtP = P_n(n_next);
@@ -620,6 +667,7 @@ __global__ void __launch_bounds__(64, RTLFM_BOXSCAN_WAVES_PER_SIMD) k_boxcar_sca
 			}
 			prevP = curP; b = z; curP = nxtP;
 		}
+#endif
 		if constexpr (SQ) {
 			if (emit && Et > 0) {
 				// the wave's sums into the buffers' (an atomic per sum: four per tile at most; buffers whose outputs this tile
