@@ -642,6 +642,32 @@ def test_dc_block_audio_in_one_launch(oracle_lib, ov, L, nb, ns):
             assert gu.state_dict(sts[s_], False) == gu.state_dict(wst[s_], False), (ov, L, splits, opts, s_)
 
 
+def test_a_handle_takes_its_streams_from_the_pool_and_gives_them_back():
+    """The library never destroys a HIP stream (csrc/stream_pool.h; LAB.md I.21: the runtime releases a freed object of a
+    destroyed stream once more, later, in whoever's heap block it has become): the streams of a handle that has gone are the
+    streams of the next one, front end and tail alike, also through a change of the tail's priority and for rtl_power."""
+    from rtlsdr_amd.demod import GpuDemod
+    cfg = make_cfg(dict(downsample=16, downsample_passes=4), 16384, 2)
+    seen = []
+    for _ in range(4):
+        with GpuDemod(cfg, 3, 0) as g:
+            seen.append((g.get_option("dbg_own_stream"), g.get_option("dbg_tail_stream")))
+    assert all(a and b and a != b for a, b in seen), seen
+    assert len(set(seen)) == 1, seen
+    # two handles alive at once have streams of their own; both pairs come back
+    with GpuDemod(cfg, 3, 0) as g1, GpuDemod(cfg, 3, 0) as g2:
+        p1 = (g1.get_option("dbg_own_stream"), g1.get_option("dbg_tail_stream"))
+        p2 = (g2.get_option("dbg_own_stream"), g2.get_option("dbg_tail_stream"))
+        assert len({*p1, *p2}) == 4 and p1 == seen[0]
+        g2.set_option("tail_priority", 0)   # another pool (another HIP priority): the old tail stream goes back to its own
+        t2 = g2.get_option("dbg_tail_stream")
+        assert t2 not in (*p1, *p2)
+    # ... and nothing new is created for the next two: every stream they get has been seen before
+    with GpuDemod(cfg, 3, 0) as g1, GpuDemod(cfg, 3, 0) as g2:
+        again = {g1.get_option("dbg_own_stream"), g1.get_option("dbg_tail_stream"), g2.get_option("dbg_own_stream"), g2.get_option("dbg_tail_stream")}
+        assert len(again) == 4 and again <= {*p1, *p2, t2}, (again, p1, p2, t2)
+
+
 def test_options_by_name():
     """rtlfm_gpu_set_option / _get_option: the library's tunables live on the handle, not in the environment."""
     from rtlsdr_amd.demod import GpuDemod
