@@ -266,6 +266,11 @@ int rtlfm_gpu_set_stream(rtlfm_gpu *h, void *hip_stream);
  *   rtlfm_gpu_release_to(h, c)  work enqueued on c from now on starts after everything the handle
  *                               has launched so far (the consumer of d_out / d_out_len).
  * NULL names the legacy default stream.  A caller that uses neither must rtlfm_gpu_sync().
+ * (The handle's own streams come from a process-wide pool and go back to it when the handle is destroyed; the library
+ * never calls hipStreamDestroy.  Not an economy: on the runtime this was written against, a stream that had been ordered
+ * against another stream this way and was then destroyed had a freed object of its own released once more, later, in
+ * whoever's heap block it had become - csrc/stream_pool.h, LAB.md I.21.  A caller that creates and destroys streams of
+ * its own around these calls at a high rate may want to pool them too.)
  */
 int rtlfm_gpu_wait_for(rtlfm_gpu *h, void *producer_stream);
 int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
