@@ -1,17 +1,25 @@
-"""Soak of the launches behind LAB.md I.17: oracle-checked repetitions inside one pytest process, with replay dumps.
+"""Soak of the launches behind LAB.md I.17 / I.21: oracle-checked repetitions inside one pytest process, with replay dumps.
 
-Round 5's record holds one wrong decimated sample in one launch of `test_what_round_four_left_on_the_staged_kernels
+Round 5's record held one wrong sample pair in one launch of `test_what_round_four_left_on_the_staged_kernels
 [p6firrdc-11776]` (the partial-tile + raw-DC-block kernel), once in seventeen full suites, never reproduced.  This file
 (task 1a) repeats that group - the same configurations, inputs, launch shapes and fresh handles, in a process that
 has the allocation history of the files collected before it (`test_parity_gpu.py` sorts in front) - and compares EVERY
 launch with the oracle.  Every other repetition runs under the library's `verify_twice` option (two executions of the run
 compared on the device), which tells a transient fault of the device code from a deterministic one or one outside the
-launch.  On the first mismatch the input, both outputs, the oracle's output, the carried states, the options, the device
-pointers and the handle's placement go to `gpurun_out/soak/` and the same launch is replayed 50 times, before the test fails.
+launch.  On a mismatch the input, both outputs, the oracle's output, the carried states, the options, the device
+pointers, the host addresses of the runtime objects behind the handle and of the result arrays go to `gpurun_out/soak/`, the
+diagnostics that say WHERE the difference arose run while the handle is still alive (the upload read back, the results
+downloaded again, the same run again on the same handle), and the same launch is replayed 50 times, before the test fails.
 
-`RTLFM_SOAK` = repetitions per (configuration, buffer size) of the four launch shapes (default 100 in the ordinary suite = 5400 launches, about a minute;
-`tools/soak.sh` runs 1000 and keeps the log under `profiles/`).  Reference lines the kernels must equal:
-src/rtl_fm.c:1043-1065 (dc_block_raw_filter), 777-831 (fifth_order, generic_fir), 932-959 (fm_demod), 1083-1112 (rms).
+What it found (round 6, LAB.md I.21; 2.8 million launches on seven boxes): no launch ever differed on the device.  The four
+mismatches it caught were the stream's 920-byte HOST array changing between a first and a second look - byte 152 one less,
+bytes 888-891 zero: the HIP runtime releasing a freed object of a destroyed stream once more, in a heap block that numpy
+had been given since (tools/host_uaf_probe.py).  The library pools its streams since (csrc/stream_pool.h) and the soak has
+been silent; it stays in the suite as the guard.
+
+`RTLFM_SOAK` = repetitions per (configuration, buffer size) of the four launch shapes (default 100 in the ordinary suite = 5400
+launches, a few seconds; `tools/soak.sh` runs 10000 and keeps the log under `profiles/`).  Reference lines the kernels must
+equal: src/rtl_fm.c:1043-1065 (dc_block_raw_filter), 777-831 (fifth_order, generic_fir), 932-959 (fm_demod), 1083-1112 (rms).
 """
 import ctypes as C
 import json

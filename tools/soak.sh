@@ -1,11 +1,11 @@
 #!/bin/bash
 # tools/soak.sh [reps] — on the GPU box: the parity file (its allocation history first, as in the run that once failed),
-# then tests/test_soak_gpu.py with RTLFM_SOAK=reps (default 1000) in the SAME pytest process; the log lands in
+# then tests/test_soak_gpu.py with RTLFM_SOAK=reps (default 10000) in the SAME pytest process; the log lands in
 # gpurun_out/soak/ (copy soak_log.txt into profiles/ as rNN_soak_boxK.txt).  9 cases x 4 shapes x reps launches, every
 # one compared with the oracle, every second repetition executed twice and compared on the device (verify_twice).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-REPS=${1:-1000}
+REPS=${1:-10000}
 cd $ROOT
 mkdir -p gpurun_out/soak
 {
