@@ -55,6 +55,10 @@ import sys
 import tempfile
 import time
 
+# several ranks on one node share device memory handles over dmabuf only (this image exports it already; a launcher
+# that builds its own environment may not) - before anything loads the HIP runtime
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
