@@ -323,6 +323,8 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        a four-instruction filter step for a == 2) instead of k_deemph_spec_arb: 18 % fewer instructions,
  *                        the same time - kept for A/B
  *   arb_chunk            samples per lane of k_deemph_arb_span: 32 (default) or 64, anything else -EINVAL
+ *   arb_waves            waves per stream of k_deemph_spec_arb (each takes every arb_waves-th span of 2048 samples): 0
+ *                        (default) = as many as make about 16384 waves of all streams, else 1 .. 8; outside -EINVAL
  *   verify_twice         debugging: 1 = every rtlfm_gpu_run_device() executes its run TWICE from the same carried state - into
  *                        shadow rows first, then into the caller's, the device idle in between - and compares rows, lengths and
  *                        the state records on the device; a difference is reported on stderr and counted.  Separates a transient

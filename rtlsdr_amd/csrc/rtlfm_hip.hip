@@ -122,6 +122,7 @@ struct rtlfm_gpu {
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
+		int arb_waves = 0;     // waves per stream of k_deemph_spec_arb: 0 = about 16384 waves in all, else 1 .. 8
 		int lpr_slim = 0;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6: built, bit-exact, and no faster - LAB.md I.22); 0: k_deemph_spec_lpr
 		int lpr_slim_prio = 3;      // s_setprio of that kernel's waves (0 .. 3)
 		int lpr_slim_chunk = 6120;  // samples per lane of that kernel: 16 chunks per stream at the wbfm shape = 1024 waves, one per SIMD
@@ -610,7 +611,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"arb_waves", &h->opt.arb_waves}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
 		{"verify_twice", &h->opt.verify_twice}, {"verify_inject", &h->opt.verify_inject}, {"lpr_slim", &h->opt.lpr_slim}, {"lpr_slim_chunk", &h->opt.lpr_slim_chunk}, {"lpr_slim_prio", &h->opt.lpr_slim_prio},
 	};
 	for (auto &t : tab)
@@ -655,6 +656,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	// the chunk tables of the one-pass deemph + low_pass_real kernel are sized from it: keep it in a sane range
 	if ((!strcmp(name, "lpr_chunk") || !strcmp(name, "lpr_slim_chunk")) && (value < 256 || value > (1 << 20))) return -EINVAL;
 	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;
+	if (!strcmp(name, "arb_waves") && (value < 0 || value > kSpecArbMaxWaves)) return -EINVAL;
 	// ... then what an accepted value implies
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
 	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
@@ -972,9 +974,10 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				if (h->arb_len2 != arb_l2 || h->arb_len1 != Nblk) {
 					// (i, frac) of every output of a buffer, as arbitrary_upsample's loop (src/rtl_fm.c:1114-1135)
 					// has them when it writes buf2[j]: walked once here, shared by every stream and buffer
-					std::vector<int32_t> ti((size_t)arb_l2);
-					std::vector<double> tf((size_t)arb_l2);
-					std::vector<ArbTab> tt((size_t)arb_l2);
+					// (64 entries of slack behind each: a lane may request the entry one round ahead of its last output)
+					std::vector<int32_t> ti((size_t)arb_l2 + 64);
+					std::vector<double> tf((size_t)arb_l2 + 64);
+					std::vector<ArbTab> tt((size_t)arb_l2 + 64 * 8);
 					int i = 1, tick = 0;
 					for (int j = 0; j < arb_l2; j++) {
 						ti[j] = i;
@@ -1020,15 +1023,17 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 					return 0;
 				}
 				const int arb_spans = (T + 64 * kArbChunk - 1) / (64 * kArbChunk);
-				// a workgroup per stream (nothing crosses workgroups), its spans dealt to up to eight waves: enough
-				// waves in all to fill the GPU when the streams alone do not
-				int wpw = 8192 / S;
+				// a workgroup per stream (nothing crosses workgroups), its spans dealt to up to eight waves: about 16384
+				// waves in all - two and a half rounds of what the GPU holds, so that the last round is a small part of
+				// the launch (8192: config 3's tail alone 70 us instead of 65, LAB.md I.31)
+				int wpw = h->opt.arb_waves > 0 ? h->opt.arb_waves : 16384 / S;
 				if (wpw > arb_spans) wpw = arb_spans;
 				if (wpw > kSpecArbMaxWaves) wpw = kSpecArbMaxWaves;
 				if (wpw < 1) wpw = 1;
 #define RTLFM_SPEC_ARB(MM) k_deemph_spec_arb<MM><<<(unsigned)S, 64 * wpw, arb_lds * wpw, q>>>(cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, \
-				h->d_arb_i, h->d_arb_frac, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
-				if (M == 2) RTLFM_SPEC_ARB(2); else if (M == 1) RTLFM_SPEC_ARB(1); else RTLFM_SPEC_ARB(0);
+				h->d_arb_i, h->d_arb_frac, h->d_arb_tab, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
+				// a == 2 (rtl_fm -s 24k -E deemp): the filter step is (x + avg + [x > avg]) >> 1
+				if (c.deemph_a == 2) RTLFM_SPEC_ARB(3); else if (M == 2) RTLFM_SPEC_ARB(2); else if (M == 1) RTLFM_SPEC_ARB(1); else RTLFM_SPEC_ARB(0);
 #undef RTLFM_SPEC_ARB
 				RTLFM_DBG_SYNC("one pass (arb)");
 				return 0;  // the one operation of this tail: filter, resampler, state and counts

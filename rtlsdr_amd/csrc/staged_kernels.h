@@ -2315,8 +2315,17 @@ __device__ __forceinline__ void arb_upsample_wave(const int16_t *a, int16_t *bo,
 // One workgroup of `wpw` waves per stream; wave w takes the spans w, w + wpw, ... of its stream, each wave with an
 // LDS region of its own (the span's traffic is wave-private: wave barriers, no workgroup barrier inside the loop).
 constexpr int kSpecArbMaxWaves = 8;
+// (i, frac) of one output as one 16-byte entry (the host fills it beside tab_i / tab_frac)
+struct alignas(16) ArbTab { double frac; int32_t i; int32_t pad; };
+static_assert(sizeof(ArbTab) == 16, "one 16-byte load per output");
 // (A/B builds, tools/build_variant.sh arb64 -DRTLFM_ARB_WAVES8: the kernel held to 64 registers so that TWO of its waves fit
 // the hole one front-end wave leaves on a SIMD - LAB.md I.28)
+#ifndef RTLFM_ARB_LOOP
+#define RTLFM_ARB_LOOP 1  // 0: round 5's loads and resampling loop (A/B builds, LAB.md I.31)
+#endif
+#ifndef RTLFM_ARB_BATCH
+#define RTLFM_ARB_BATCH 4
+#endif
 #ifdef RTLFM_ARB_WAVES8
 #define RTLFM_ARB_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #else
@@ -2326,7 +2335,7 @@ template <int MAGIC>
 __global__ void __launch_bounds__(64 * kSpecArbMaxWaves) RTLFM_ARB_ATTR
 k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
                   int N, int len2, int nblocks, const int32_t *__restrict__ tab_i, const double *__restrict__ tab_frac,
-                  int16_t *__restrict__ B, size_t bstride,
+                  const ArbTab *__restrict__ tab, int16_t *__restrict__ B, size_t bstride,
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, size_t lds_per_wave,
                   int32_t *__restrict__ cnt_out)
 {
@@ -2359,6 +2368,26 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 	bool unsettled = false;
 	wave_sync();  // the span before is done with this wave's LDS region
 	// samples [k0 - W, k0 + span), zero outside the run
+#if RTLFM_ARB_LOOP == 1
+	constexpr int kGroupsAtOnce = 5;  // W = 128: 272 groups of eight samples, 4.25 per lane
+	const int G = (pre + 64) * (C / 8);
+	if (k0 >= W && k0 + span <= T && G <= kGroupsAtOnce * 64) {
+		// the window lies inside the run (all but a stream's first and last span): a lane's loads in flight together,
+		// then its writes - one trip to memory per span instead of one per group
+		uint4 v5[kGroupsAtOnce];
+		const uint4 *src = reinterpret_cast<const uint4 *>(r + (k0 - W));
+#pragma unroll
+		for (int u = 0; u < kGroupsAtOnce; u++) {
+			const int g = lane + 64 * u;
+			v5[u] = g < G ? src[g] : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int u = 0; u < kGroupsAtOnce; u++) {
+			const int g = lane + 64 * u;
+			if (g < G) *reinterpret_cast<uint4 *>(y + (g >> 2) * Cp + (g & 3) * 8) = v5[u];
+		}
+	} else
+#endif
 	for (int g = lane; g < (pre + 64) * (C / 8); g += 64) {
 		const int q = g >> 2, w = g & 3;
 		const int k = k0 - W + g * 8;
@@ -2434,7 +2463,15 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 			cp[k] = (int16_t)(uint16_t)(v ^ 0x8000u);
 		}
 		if (end == T) sout[s].deemph_avg = (int)v - 32768;
+#if RTLFM_ARB_LOOP == 1
+		// ... and the chunk's last filtered sample once more in the padding in front of the next chunk: the resampler
+		// finds sample p - 1 two bytes below sample p wherever p lies
+		cp[Cp - 1] = (int16_t)(uint16_t)(v ^ 0x8000u);
+#endif
 	}
+#if RTLFM_ARB_LOOP == 1
+	if (lane == 0) y[pre * Cp - 1] = y[pre * Cp - (Cp - C) - 1];
+#endif
 	wave_sync();
 	// arbitrary_upsample (src/rtl_fm.c:1114-1135) of the buffers that intersect the span
 	const int poff = pre * C;
@@ -2457,11 +2494,39 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		const int rel0 = base - k0;
 		const int32_t *ti = tab_i + j;
 		const double *tf = tab_frac + j;
+#if RTLFM_ARB_LOOP == 1
+		// (i, frac) as one 16-byte entry, the next round's requested before this round's arithmetic (the tables end in 64
+		// entries of slack); the padded address of sample p as 2 p + 16 (p >> 5), sample p - 1 two bytes below it (the
+		// filter left every chunk's last sample in the padding behind it as well)
+		static_assert(C == 32 && Cp == 40, "the address form");
+		const char *yb = reinterpret_cast<const char *>(y);
+		const int off = rel0 + poff;
+		auto emit = [&](const ArbTab &e, int jj) {
+			const int p = off + e.i;
+			const char *q = yb + (2 * p + ((p >> 5) << 4) - 2);
+			const int a0 = *reinterpret_cast<const int16_t *>(q), a1 = *reinterpret_cast<const int16_t *>(q + 2);
+			bo[jj] = (int16_t)(a0 * (1 - e.frac) + a1 * e.frac);
+		};
+		// whole rounds of U outputs per lane while the wave has them (a uniform test: no guard per output) - the U entries
+		// requested together, then the arithmetic -, the rest one by one
+		constexpr int U = RTLFM_ARB_BATCH;
+		int jw = j0;
+		for (; jw + 64 * U <= j1; jw += 64 * U) {
+			const ArbTab *tp = tab + jw + lane;
+			ArbTab e[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) e[u] = tp[64 * u];
+#pragma unroll
+			for (int u = 0; u < U; u++) emit(e[u], jw + lane + 64 * u);
+		}
+		for (j = jw + lane; j < j1; j += 64) emit(tab[j], j);
+#else
 		for (; j < j1; j += 64, ti += 64, tf += 64) {
 			const int ii = *ti;
 			const double frac = *tf;
 			bo[j] = (int16_t)(at(rel0 + ii - 1) * (1 - frac) + at(rel0 + ii) * frac);
 		}
+#endif
 	}
 	if (__any(unsettled) && lane == 0) wg_unsettled = 1;
 	}  // spans of this wave
@@ -2491,8 +2556,6 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 //   * a = 2 (16 and 24 kHz) takes the four-instruction step (DeemphStep::step<3>) instead of six;
 //   * the settle window grows in steps of 32 samples whatever the chunk length C is, so C = 64 halves the settling per
 //     sample (two walks over 32 samples per chunk of 64).
-struct ArbTab { double frac; int32_t i; int32_t pad; };
-static_assert(sizeof(ArbTab) == 16, "one 16-byte load per output");
 constexpr int kArbSettle = 32;  // samples per settling step
 
 template <int MAGIC, int C>
