@@ -122,6 +122,7 @@ struct rtlfm_gpu {
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
+		int lpr_threads = 256; // lanes per workgroup of k_deemph_spec_lpr: 64, 128, 192 or 256
 		int arb_waves = 0;     // waves per stream of k_deemph_spec_arb: 0 = about 16384 waves in all, else 1 .. 8
 		int lpr_slim = 0;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6: built, bit-exact, and no faster - LAB.md I.22); 0: k_deemph_spec_lpr
 		int lpr_slim_prio = 3;      // s_setprio of that kernel's waves (0 .. 3)
@@ -611,7 +612,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"arb_waves", &h->opt.arb_waves}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"arb_waves", &h->opt.arb_waves}, {"lpr_threads", &h->opt.lpr_threads}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
 		{"verify_twice", &h->opt.verify_twice}, {"verify_inject", &h->opt.verify_inject}, {"lpr_slim", &h->opt.lpr_slim}, {"lpr_slim_chunk", &h->opt.lpr_slim_chunk}, {"lpr_slim_prio", &h->opt.lpr_slim_prio},
 	};
 	for (auto &t : tab)
@@ -657,6 +658,7 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if ((!strcmp(name, "lpr_chunk") || !strcmp(name, "lpr_slim_chunk")) && (value < 256 || value > (1 << 20))) return -EINVAL;
 	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;
 	if (!strcmp(name, "arb_waves") && (value < 0 || value > kSpecArbMaxWaves)) return -EINVAL;
+	if (!strcmp(name, "lpr_threads") && (value < 64 || value > kSpecLprThreads || value % 64)) return -EINVAL;
 	// ... then what an accepted value implies
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
 	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
@@ -974,15 +976,16 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				if (h->arb_len2 != arb_l2 || h->arb_len1 != Nblk) {
 					// (i, frac) of every output of a buffer, as arbitrary_upsample's loop (src/rtl_fm.c:1114-1135)
 					// has them when it writes buf2[j]: walked once here, shared by every stream and buffer
-					// (64 entries of slack behind each: a lane may request the entry one round ahead of its last output)
-					std::vector<int32_t> ti((size_t)arb_l2 + 64);
-					std::vector<double> tf((size_t)arb_l2 + 64);
-					std::vector<ArbTab> tt((size_t)arb_l2 + 64 * 8);
+					// (ti: the i, a gap, then the padded LDS offset of sample i - 1 for k_deemph_spec_arb's resampler)
+					std::vector<int32_t> ti(2 * (size_t)arb_l2 + kArbTabGap);
+					std::vector<double> tf((size_t)arb_l2);
+					std::vector<ArbTab> tt((size_t)arb_l2);
 					int i = 1, tick = 0;
 					for (int j = 0; j < arb_l2; j++) {
 						ti[j] = i;
 						tf[j] = (double)tick / (double)arb_l2;
 						tt[j] = ArbTab{tf[j], i, 0};
+						ti[(size_t)arb_l2 + kArbTabGap + j] = 2 * i + 16 * (i >> 5) - 2;
 						tick += Nblk;
 						if (tick > arb_l2) { tick -= arb_l2; i++; }
 						if (i >= Nblk) { i = Nblk - 1; tick = arb_l2; }
@@ -1031,7 +1034,7 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				if (wpw > kSpecArbMaxWaves) wpw = kSpecArbMaxWaves;
 				if (wpw < 1) wpw = 1;
 #define RTLFM_SPEC_ARB(MM) k_deemph_spec_arb<MM><<<(unsigned)S, 64 * wpw, arb_lds * wpw, q>>>(cur, cur_stride, T, S, st, Ws, arb_spans, Nblk, arb_l2, nblocks, \
-				h->d_arb_i, h->d_arb_frac, h->d_arb_tab, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
+				h->d_arb_i, h->d_arb_frac, arb_dst, arb_ds, sin, sout, arb_lds, cnt_dst)
 				// a == 2 (rtl_fm -s 24k -E deemp): the filter step is (x + avg + [x > avg]) >> 1
 				if (c.deemph_a == 2) RTLFM_SPEC_ARB(3); else if (M == 2) RTLFM_SPEC_ARB(2); else if (M == 1) RTLFM_SPEC_ARB(1); else RTLFM_SPEC_ARB(0);
 #undef RTLFM_SPEC_ARB
@@ -1123,11 +1126,12 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 				// it (1), else one by one (staged_kernels.h, LprSink)
 				int lpr_vec = (uintptr_t)lpr_dst % 16 == 0 && lpr_ds % 8 == 0 && !h->opt.lpr_scalar_stores;
 				if (h->opt.lpr_ring && !h->opt.lpr_scalar_stores) lpr_vec = 2;
-				const size_t lpr_lds = lpr_vec == 2 ? (size_t)kSpecLprThreads * kLprRingStride * sizeof(int16_t) : 0;
+				const int nthr = h->opt.lpr_threads;
+				const size_t lpr_lds = lpr_vec == 2 ? (size_t)nthr * kLprRingStride * sizeof(int16_t) : 0;
 				// a workgroup owns whole streams: 256 / chunks of them, or one with a loop over its chunks
-				const int spw = mcsp >= kSpecLprThreads ? 1 : kSpecLprThreads / mcsp;
+				const int spw = mcsp >= nthr ? 1 : nthr / mcsp;
 				const unsigned gsp = (unsigned)((S + spw - 1) / spw);
-#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, kSpecLprThreads, lpr_lds, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
+#define RTLFM_SPEC_LPR(MM) k_deemph_spec_lpr<MM><<<gsp, nthr, lpr_lds, q>>>(cur, cur_stride, T, cnt, S, st, mcsp, Ls, Ws, lpr_dst, lpr_ds, \
 				c.rate_out, c.rate_out2, sin, sout, h->d_lpr_chunks, lpr_vec, cnt_dst)
 				if (M == 2) RTLFM_SPEC_LPR(2); else if (M == 1) RTLFM_SPEC_LPR(1); else RTLFM_SPEC_LPR(0);
 #undef RTLFM_SPEC_LPR

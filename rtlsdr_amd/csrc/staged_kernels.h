@@ -18,6 +18,8 @@
 
 #include "dsp_device.h"
 
+#include <type_traits>
+
 #ifndef RTLFM_TAIL_PRIO
 #define RTLFM_TAIL_PRIO 3
 #endif
@@ -1554,8 +1556,13 @@ __device__ __forceinline__ void lpr_totals(long long p0, int n, int slow, int fa
 // against 1.378, same box, alternating.  Every lane walks a row of its own, 16 bytes at a time: the kernel waits for
 // its 64 separate lines per load instruction.)
 constexpr int kSpecLprThreads = 256;
+#ifdef RTLFM_LPR_WAVES4
+#define RTLFM_LPR_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define RTLFM_LPR_ATTR
+#endif
 template <int MAGIC>
-__global__ void __launch_bounds__(kSpecLprThreads)
+__global__ void __launch_bounds__(kSpecLprThreads) RTLFM_LPR_ATTR
 k_deemph_spec_lpr(int16_t *R, size_t rstride, int T, const int32_t *__restrict__ cnt, int nstreams,
                   DeemphStep ds, int max_chunks, int L, int W, int16_t *__restrict__ B, size_t bstride, int fast, int slow,
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, LprChunk *lc, int vec,
@@ -2315,8 +2322,9 @@ __device__ __forceinline__ void arb_upsample_wave(const int16_t *a, int16_t *bo,
 // One workgroup of `wpw` waves per stream; wave w takes the spans w, w + wpw, ... of its stream, each wave with an
 // LDS region of its own (the span's traffic is wave-private: wave barriers, no workgroup barrier inside the loop).
 constexpr int kSpecArbMaxWaves = 8;
-// (i, frac) of one output as one 16-byte entry (the host fills it beside tab_i / tab_frac)
+// (i, frac) of one output as one 16-byte entry (k_deemph_arb_span; the host fills it beside tab_i / tab_frac)
 struct alignas(16) ArbTab { double frac; int32_t i; int32_t pad; };
+constexpr int kArbTabGap = 64;  // tab_i: i of every output, a gap, then k_deemph_spec_arb's padded offset 2 i + 16 (i >> 5) - 2
 static_assert(sizeof(ArbTab) == 16, "one 16-byte load per output");
 // (A/B builds, tools/build_variant.sh arb64 -DRTLFM_ARB_WAVES8: the kernel held to 64 registers so that TWO of its waves fit
 // the hole one front-end wave leaves on a SIMD - LAB.md I.28)
@@ -2325,6 +2333,15 @@ static_assert(sizeof(ArbTab) == 16, "one 16-byte load per output");
 #endif
 #ifndef RTLFM_ARB_BATCH
 #define RTLFM_ARB_BATCH 4
+#endif
+#ifndef RTLFM_ARB_SCALAR_WAVE
+#define RTLFM_ARB_SCALAR_WAVE 1
+#endif
+#ifndef RTLFM_ARB_ADDITIVE
+#define RTLFM_ARB_ADDITIVE 1
+#endif
+#ifndef RTLFM_ARB_ABLATE
+#define RTLFM_ARB_ABLATE 0  // timing builds only: 1 no resampling, 2 no settling walk, 4 no filter walk, 8 no loads
 #endif
 #ifdef RTLFM_ARB_WAVES8
 #define RTLFM_ARB_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -2335,7 +2352,7 @@ template <int MAGIC>
 __global__ void __launch_bounds__(64 * kSpecArbMaxWaves) RTLFM_ARB_ATTR
 k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds, int W, int spans,
                   int N, int len2, int nblocks, const int32_t *__restrict__ tab_i, const double *__restrict__ tab_frac,
-                  const ArbTab *__restrict__ tab, int16_t *__restrict__ B, size_t bstride,
+                  int16_t *__restrict__ B, size_t bstride,
                   const state_t *__restrict__ sin, state_t *__restrict__ sout, size_t lds_per_wave,
                   int32_t *__restrict__ cnt_out)
 {
@@ -2344,7 +2361,9 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 #endif
 	extern __shared__ uint4 arb_lds[];
 	__shared__ int wg_unsettled;
-	const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, wpw = (int)blockDim.x >> 6;
+	// (the wave's number in a scalar register: everything a span derives from it - k0, the buffers it intersects, their
+	// first and last outputs with their divisions - is then scalar work)
+	const int lane = (int)threadIdx.x & 63, wave = RTLFM_ARB_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : (int)threadIdx.x >> 6, wpw = (int)blockDim.x >> 6;
 	int16_t *y = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(arb_lds) + (size_t)wave * lds_per_wave);
 	const size_t s = blockIdx.x;
 	constexpr int C = kArbChunk, Cp = kArbStride, span = 64 * C;
@@ -2368,6 +2387,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 	bool unsettled = false;
 	wave_sync();  // the span before is done with this wave's LDS region
 	// samples [k0 - W, k0 + span), zero outside the run
+	if (!(RTLFM_ARB_ABLATE & 8)) {
 #if RTLFM_ARB_LOOP == 1
 	constexpr int kGroupsAtOnce = 5;  // W = 128: 272 groups of eight samples, 4.25 per lane
 	const int G = (pre + 64) * (C / 8);
@@ -2401,6 +2421,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		}
 		*reinterpret_cast<uint4 *>(y + q * Cp + w * 8) = v;
 	}
+	}
 	wave_sync();
 	// the state at the start of this lane's chunk (chunk pre + lane of the array): from the `pre` chunks before it
 	const int begin = k0 + lane * C, end = min(begin + C, T);
@@ -2413,7 +2434,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		// samples twice for its 32: nine filter steps per sample where three do.
 		const bool mine = begin > 0 && begin < T;
 		uint32_t lo = 0, hi = 65535;
-		for (int nch = 1;; nch = nch * 2 < pre ? nch * 2 : pre) {
+		for (int nch = 1; !(RTLFM_ARB_ABLATE & 2); nch = nch * 2 < pre ? nch * 2 : pre) {
 			lo = 0; hi = 65535;
 			if (begin < nch * C) lo = hi = v;  // the run starts inside the window: from the carried state, over the samples there are
 			for (int c = pre - nch; c < pre; c++) {
@@ -2433,6 +2454,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 			}
 			if (nch >= pre || !__any(mine && lo != hi)) break;
 		}
+		if (RTLFM_ARB_ABLATE & 2) lo = hi = v;
 		if (mine) {
 			unsettled = lo != hi;  // what this workgroup writes for the stream is replaced afterwards
 			v = lo;
@@ -2441,7 +2463,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 	wave_sync();
 	// the filtered sample before the span (left neighbour of its first sample), then the chunk in place
 	if (lane == 0) y[pre * Cp - (Cp - C) - 1] = (int16_t)(uint16_t)(v ^ 0x8000u);
-	if (begin < T) {
+	if (begin < T && !(RTLFM_ARB_ABLATE & 4)) {
 		int16_t *cp = y + (pre + lane) * Cp;
 		const int cntc = end - begin;
 		int k = 0;
@@ -2484,7 +2506,7 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 	// per output that every stream shares.  Computing them per output (a 32-bit division to start, then a carry
 	// chain and a two-fma quotient for frac) was 18 of the 35 instructions an output cost.
 	const int len1 = N;
-	for (int b = k0 / N; b <= (k1 - 1) / N; b++) {
+	for (int b = k0 / N; b <= (k1 - 1) / N && !(RTLFM_ARB_ABLATE & 1); b++) {
 		const int base = b * N;
 		const int ia = max(k0, base) - base, ib = min(k1, base + N) - base;
 		const int j0 = arb_first_output(ia, len1, len2), j1 = arb_first_output(ib, len1, len2);
@@ -2495,31 +2517,44 @@ k_deemph_spec_arb(int16_t *R, size_t rstride, int T, int nstreams, DeemphStep ds
 		const int32_t *ti = tab_i + j;
 		const double *tf = tab_frac + j;
 #if RTLFM_ARB_LOOP == 1
-		// (i, frac) as one 16-byte entry, the next round's requested before this round's arithmetic (the tables end in 64
-		// entries of slack); the padded address of sample p as 2 p + 16 (p >> 5), sample p - 1 two bytes below it (the
-		// filter left every chunk's last sample in the padding behind it as well)
+		// the padded address of sample p is 2 p + 16 (p >> 5), sample p - 1 two bytes below it (the filter left every
+		// chunk's last sample in the padding behind it as well).  Where the buffer starts on a chunk boundary of the span
+		// (buffers of a multiple of 32 samples) that address is additive: the host left 2 i + 16 (i >> 5) - 2 behind the
+		// i of tab_i (from entry len2 + kArbTabGap on), and a sample's address is one addition.
+		// (i and frac in tables of their own: a wave's loads touch 2 + 4 lines per output; as one 16-byte entry 8 - and
+		// the loop is as much the L1's as the VALU's: with the entry split 4 + 8 + 4 into two loads of eight lines each,
+		// 30 us of 65 more, LAB.md I.31)
 		static_assert(C == 32 && Cp == 40, "the address form");
 		const char *yb = reinterpret_cast<const char *>(y);
 		const int off = rel0 + poff;
-		auto emit = [&](const ArbTab &e, int jj) {
-			const int p = off + e.i;
-			const char *q = yb + (2 * p + ((p >> 5) << 4) - 2);
-			const int a0 = *reinterpret_cast<const int16_t *>(q), a1 = *reinterpret_cast<const int16_t *>(q + 2);
-			bo[jj] = (int16_t)(a0 * (1 - e.frac) + a1 * e.frac);
-		};
+		const bool additive = RTLFM_ARB_ADDITIVE && (off & (C - 1)) == 0;
+		const char *yo = yb + (2 * off + ((off >> 5) << 4));
 		// whole rounds of U outputs per lane while the wave has them (a uniform test: no guard per output) - the U entries
 		// requested together, then the arithmetic -, the rest one by one
-		constexpr int U = RTLFM_ARB_BATCH;
-		int jw = j0;
-		for (; jw + 64 * U <= j1; jw += 64 * U) {
-			const ArbTab *tp = tab + jw + lane;
-			ArbTab e[U];
+		auto rounds = [&](auto additive_t) {
+			constexpr bool ADD = decltype(additive_t)::value;
+			const int32_t *tq = ADD ? tab_i + (len2 + kArbTabGap) : tab_i;
+			auto emit = [&](int ii, double frac, int jj) {
+				const int p = off + ii;
+				const char *q = ADD ? yo + ii : yb + (2 * p + ((p >> 5) << 4) - 2);
+				const int a0 = *reinterpret_cast<const int16_t *>(q), a1 = *reinterpret_cast<const int16_t *>(q + 2);
+				bo[jj] = (int16_t)(a0 * (1 - frac) + a1 * frac);
+			};
+			constexpr int U = RTLFM_ARB_BATCH;
+			int jw = j0;
+			for (; jw + 64 * U <= j1; jw += 64 * U) {
+				const int32_t *pi = tq + jw + lane;
+				const double *pf = tab_frac + jw + lane;
+				int ei[U];
+				double ef[U];
 #pragma unroll
-			for (int u = 0; u < U; u++) e[u] = tp[64 * u];
+				for (int u = 0; u < U; u++) { ei[u] = pi[64 * u]; ef[u] = pf[64 * u]; }
 #pragma unroll
-			for (int u = 0; u < U; u++) emit(e[u], jw + lane + 64 * u);
-		}
-		for (j = jw + lane; j < j1; j += 64) emit(tab[j], j);
+				for (int u = 0; u < U; u++) emit(ei[u], ef[u], jw + lane + 64 * u);
+			}
+			for (j = jw + lane; j < j1; j += 64) emit(tq[j], tab_frac[j], j);
+		};
+		if (additive) rounds(std::true_type{}); else rounds(std::false_type{});
 #else
 		for (; j < j1; j += 64, ti += 64, tf += 64) {
 			const int ii = *ti;

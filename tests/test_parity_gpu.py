@@ -1836,7 +1836,8 @@ def test_deemph_replay_feeds_low_pass_real(oracle_lib, a, rates, scalar):
 
 @pytest.mark.parametrize("opts", [dict(lpr_chunk=256), dict(lpr_chunk=5440), dict(deemph_four_pass=1),
                                   dict(deemph_four_pass=1, lpr_chunk=256), dict(lpr_separate=1), dict(lpr_slim=0),
-                                  dict(lpr_ring=0), dict(lpr_scalar_stores=1)])
+                                  dict(lpr_ring=0), dict(lpr_scalar_stores=1), dict(lpr_threads=64), dict(lpr_threads=192),
+                                  dict(lpr_threads=128, lpr_chunk=256)])
 def test_lpr_tail_options(oracle_lib, opts):
     """The same tail under its options: round 5's one-pass kernel (k_deemph_spec_lpr, `lpr_slim = 0`) with chunk lengths below
     and above the four-pass route's own chunk (the chunk tables are sized per route) and its three ways of storing, the four
@@ -1868,6 +1869,10 @@ def test_lpr_chunk_range():
                 g.set_option("lpr_chunk", bad)
         g.set_option("lpr_chunk", 256)
         assert g.get_option("lpr_chunk") == 256
+        for name, bad in (("lpr_threads", 0), ("lpr_threads", 96), ("lpr_threads", 320), ("arb_waves", -1), ("arb_waves", 9)):
+            with pytest.raises(Exception):
+                g.set_option(name, bad)
+        assert g.get_option("lpr_threads") == 256 and g.get_option("arb_waves") == 0
 
 
 def _lpr_tail_case(oracle_lib, a, rates, options, weird_phase=False):
@@ -1910,6 +1915,8 @@ def _lpr_tail_case(oracle_lib, a, rates, options, weird_phase=False):
 @pytest.mark.parametrize("passes,L,nb,a,rates", [(6, 262144, 4, 2, (16000, 22050)),     # config 3: a span per buffer
                                                  (5, 98304, 12, 2, (16000, 22050)),     # buffers of 1536 straddle the spans of 2048
                                                  (6, 262144, 3, 5, (16000, 16100)),     # len2 = len1 + 12
+                                                 (4, 33280, 9, 2, (16000, 22050)),      # buffers of 1040 samples: not whole chunks of 32 (the resampler's general address form)
+                                                 (4, 33280, 5, 7, (16000, 16031)),      # ... with the division by 7 and len2 = len1 + 2
                                                  (4, 32768, 9, 12, (48000, 96000)),     # W = 256, the longest settling window it takes
                                                  (4, 32768, 9, 13, (48000, 96000))])    # W = 320: the separate kernels
 def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
@@ -1933,8 +1940,10 @@ def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
     st_copy = [capi.RtlfmStreamState.from_buffer_copy(bytes(st0[s])) for s in range(ns)]
     want, want_len, wst = oracle_lib.run_batch(cfg, iq, states=st0, nthreads=2)
     # arb_span: round 5's form of the kernel (k_deemph_arb_span: the span linear in LDS), with 32 and 64 samples per lane
+    # arb_waves: the spans of a stream dealt to 1 .. 8 waves (default: as many as make about 16384 waves of all streams)
     for splits, options in ((None, {}), ([(0, 1), (1, nb)], {}), (None, dict(arb_span=1)), ([(0, 1), (1, nb)], dict(arb_span=1, arb_chunk=64)),
-                            (None, dict(arb_span=1, arb_chunk=64))):
+                            (None, dict(arb_span=1, arb_chunk=64)), (None, dict(arb_waves=1)), ([(0, 1), (1, nb)], dict(arb_waves=3)),
+                            (None, dict(arb_waves=8))):
         outs = [[] for _ in range(ns)]
         with GpuDemod(cfg, ns, 0, options=options) as g:
             for s in range(ns):
