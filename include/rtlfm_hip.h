@@ -298,6 +298,8 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *   lpr_scalar_stores    1: the resampler's outputs one by one
  *   lpr_chunk            most samples per lane of the one-pass deemph + low_pass_real kernel (default 5440; 256 ... 2^20,
  *                        anything else -EINVAL); shorter runs get shorter chunks so that about 64 K lanes work
+ *   lpr_threads          lanes per workgroup of that kernel: 64, 128, 192 or 256 (default; anything else -EINVAL).  A
+ *                        workgroup owns whole streams (lpr_threads / chunks of them, or one with a loop over its chunks)
  *   lpr_slim             1: deemph_filter + low_pass_real behind a front end (-M wbfm) as k_lpr_slim_plan + k_deemph_lpr_slim:
  *                        one-wave workgroups of 32 registers and no LDS, which run as a FIFTH wave per SIMD beside the next
  *                        step's four front-end waves instead of in the place of one.  Bit-exact and no faster (the /6 front
