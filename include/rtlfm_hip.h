@@ -325,6 +325,9 @@ int rtlfm_gpu_release_to(rtlfm_gpu *h, void *consumer_stream);
  *                        a four-instruction filter step for a == 2) instead of k_deemph_spec_arb: 18 % fewer instructions,
  *                        the same time - kept for A/B
  *   arb_chunk            samples per lane of k_deemph_arb_span: 32 (default) or 64, anything else -EINVAL
+ *   arb_serial           where deemph_filter + arbitrary_upsample (config 3's tail) runs: 1 = on the front end's stream, behind
+ *                        it; 0 = on the tail's own stream beside the next front end, as every other tail; -1 (default) = in
+ *                        line from 2048 streams on (1.5 % of config 3's step).  Setting it waits for the handle's work
  *   arb_waves            waves per stream of k_deemph_spec_arb (each takes every arb_waves-th span of 2048 samples): 0
  *                        (default) = as many as make about 16384 waves of all streams, else 1 .. 8; outside -EINVAL
  *   verify_twice         debugging: 1 = every rtlfm_gpu_run_device() executes its run TWICE from the same carried state - into

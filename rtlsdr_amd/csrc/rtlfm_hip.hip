@@ -122,6 +122,7 @@ struct rtlfm_gpu {
 		int lpr_ring = 1;      // 0: the one-pass deemph + low_pass_real kernel's outputs leave in 16-byte groups from registers (round 3) instead of 64-byte pieces from LDS
 		int arb_span = 0;      // 1: k_deemph_arb_span instead of k_deemph_spec_arb for config 3's tail (18 % fewer instructions, the same time: LAB.md)
 		int arb_chunk = 32;    // samples per lane of k_deemph_arb_span: 32 or 64
+		int arb_serial = -1;   // deemph + arbitrary_upsample behind the front end on ITS stream: -1 = from 2048 streams on, 0 never, 1 always
 		int lpr_threads = 256; // lanes per workgroup of k_deemph_spec_lpr: 64, 128, 192 or 256
 		int arb_waves = 0;     // waves per stream of k_deemph_spec_arb: 0 = about 16384 waves in all, else 1 .. 8
 		int lpr_slim = 0;      // 1: -M wbfm's tail as k_lpr_slim_plan + k_deemph_lpr_slim - 32 registers, no LDS, one-wave workgroups: a fifth wave beside the next step's four front-end waves per SIMD instead of in place of one (round 6: built, bit-exact, and no faster - LAB.md I.22); 0: k_deemph_spec_lpr
@@ -612,7 +613,7 @@ static int *option_slot(rtlfm_gpu *h, const char *name)
 		{"deemph_sequential", &h->opt.deemph_sequential}, {"deemph_four_pass", &h->opt.deemph_four_pass},
 		{"lpr_separate", &h->opt.lpr_separate}, {"lpr_scalar_stores", &h->opt.lpr_scalar_stores}, {"lpr_chunk", &h->opt.lpr_chunk},
 		{"tail_sync", &h->opt.tail_sync}, {"apart_budget_gb", &h->place.budget_gb}, {"ring_force_retry", &h->place.force_retry},
-		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"arb_waves", &h->opt.arb_waves}, {"lpr_threads", &h->opt.lpr_threads}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
+		{"arb_span", &h->opt.arb_span}, {"arb_chunk", &h->opt.arb_chunk}, {"arb_waves", &h->opt.arb_waves}, {"lpr_threads", &h->opt.lpr_threads}, {"arb_serial", &h->opt.arb_serial}, {"lpr_ring", &h->opt.lpr_ring}, {"squelch_fused", &h->opt.squelch_fused}, {"adc_separate", &h->opt.adc_separate}, {"deep_rest", &h->opt.deep_rest}, {"box_store", &h->fws.box_store}, {"fused_store", &h->fws.fused_store},
 		{"verify_twice", &h->opt.verify_twice}, {"verify_inject", &h->opt.verify_inject}, {"lpr_slim", &h->opt.lpr_slim}, {"lpr_slim_chunk", &h->opt.lpr_slim_chunk}, {"lpr_slim_prio", &h->opt.lpr_slim_prio},
 	};
 	for (auto &t : tab)
@@ -659,6 +660,10 @@ extern "C" int rtlfm_gpu_set_option(rtlfm_gpu *h, const char *name, long value)
 	if (!strcmp(name, "arb_chunk") && value != 32 && value != 64) return -EINVAL;
 	if (!strcmp(name, "arb_waves") && (value < 0 || value > kSpecArbMaxWaves)) return -EINVAL;
 	if (!strcmp(name, "lpr_threads") && (value < 64 || value > kSpecLprThreads || value % 64)) return -EINVAL;
+	if (!strcmp(name, "arb_serial")) {
+		if (value < -1 || value > 1) return -EINVAL;
+		HIP_TRY(sync_all(h));  // the tail may change streams: nothing of either in flight
+	}
 	// ... then what an accepted value implies
 	if (!strcmp(name, "fused_waves")) h->fws.target_waves_tail = (int)value;  // one number for both unless fused_waves_tail follows
 	if (!strcmp(name, "fused_waves") || !strcmp(name, "fused_waves_tail")) h->fws.target_waves_tail_fifth = 0;  // an explicit number rules
@@ -872,7 +877,13 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	// config 3 the tail is a quarter of the step but 3 % of the bytes.  rtlfm_gpu_run_device() makes
 	// the step after next wait for it before it reuses this parity's buffers.
 	hipStream_t q = h->stream;
-	const bool own_stream = tp.any() && h->tail_overlap;
+	// ... but config 3's own tail (deemph + arbitrary_upsample: 16384 short waves that fill the GPU by themselves, 63 us
+	// alone) behind a front end of thousands of streams is better off in line: beside the next front end it takes 1.5 %
+	// more of the step than behind this one (LAB.md I.31).  A rule of the configuration and the stream count only - a
+	// handle's tail never changes streams between runs.
+	const bool arb_in_line = tp.deemph && tp.arb && !tp.post && !tp.adc && !tp.lpr && c.rate_out2 > c.rate_out &&
+	                         (h->opt.arb_serial > 0 || (h->opt.arb_serial < 0 && S >= 2048));
+	const bool own_stream = tp.any() && h->tail_overlap && !arb_in_line;
 	if (own_stream) {
 		HIP_TRY(hipEventRecord(h->ev_front[par], h->stream));
 		HIP_TRY(hipStreamWaitEvent(h->tail_stream, h->ev_front[par], 0));

@@ -1869,10 +1869,11 @@ def test_lpr_chunk_range():
                 g.set_option("lpr_chunk", bad)
         g.set_option("lpr_chunk", 256)
         assert g.get_option("lpr_chunk") == 256
-        for name, bad in (("lpr_threads", 0), ("lpr_threads", 96), ("lpr_threads", 320), ("arb_waves", -1), ("arb_waves", 9)):
+        for name, bad in (("lpr_threads", 0), ("lpr_threads", 96), ("lpr_threads", 320), ("arb_waves", -1), ("arb_waves", 9),
+                          ("arb_serial", -2), ("arb_serial", 2)):
             with pytest.raises(Exception):
                 g.set_option(name, bad)
-        assert g.get_option("lpr_threads") == 256 and g.get_option("arb_waves") == 0
+        assert g.get_option("lpr_threads") == 256 and g.get_option("arb_waves") == 0 and g.get_option("arb_serial") == -1
 
 
 def _lpr_tail_case(oracle_lib, a, rates, options, weird_phase=False):
@@ -1943,7 +1944,9 @@ def test_deemph_feeds_arbitrary_upsample(oracle_lib, passes, L, nb, a, rates):
     # arb_waves: the spans of a stream dealt to 1 .. 8 waves (default: as many as make about 16384 waves of all streams)
     for splits, options in ((None, {}), ([(0, 1), (1, nb)], {}), (None, dict(arb_span=1)), ([(0, 1), (1, nb)], dict(arb_span=1, arb_chunk=64)),
                             (None, dict(arb_span=1, arb_chunk=64)), (None, dict(arb_waves=1)), ([(0, 1), (1, nb)], dict(arb_waves=3)),
-                            (None, dict(arb_waves=8))):
+                            (None, dict(arb_waves=8)),
+                            # arb_serial: this tail on the front end's stream (what handles of 2048 streams and more do by themselves)
+                            ([(0, 1), (1, nb)], dict(arb_serial=1)), (None, dict(arb_serial=0))):
         outs = [[] for _ in range(ns)]
         with GpuDemod(cfg, ns, 0, options=options) as g:
             for s in range(ns):
