@@ -842,6 +842,18 @@ static void tail_route(rtlfm_gpu *h, const TailPlan &tp, int16_t *final_dst, siz
 	}
 }
 
+// Config 3's own tail (deemph + arbitrary_upsample: 16384 short waves that fill the GPU by themselves, 63 us alone) behind a
+// front end of thousands of streams is better off IN LINE, on the front end's stream: beside the next front end it takes
+// 1.5 % more of the step than behind this one, and a front end with nothing beside it runs best in few long segments
+// (the planner's no-tail target: another 3 %, LAB.md I.31).  A rule of the configuration and the stream count only - a
+// handle's tail never changes streams between runs.
+static bool arb_tail_in_line(const rtlfm_gpu *h, const TailPlan &tp)
+{
+	const rtlfm_cfg &c = h->cfg;
+	return tp.deemph && tp.arb && !tp.post && !tp.adc && !tp.lpr && c.rate_out2 > c.rate_out &&
+	       (h->opt.arb_serial > 0 || (h->opt.arb_serial < 0 && h->nstreams >= 2048));
+}
+
 // Does this tail run as ONE kernel (run_tail: k_deemph_spec_arb = 1, k_deemph_spec_lpr = 2), 0 if not?
 static int one_pass_tail(const rtlfm_gpu *h, const TailPlan &tp, const int16_t *cur, size_t cur_stride, int T, bool varcnt,
                          int nblocks, int Nblk, int D)
@@ -877,13 +889,8 @@ static int run_tail(rtlfm_gpu *h, const TailPlan &tp, int16_t *cur, size_t cur_s
 	// config 3 the tail is a quarter of the step but 3 % of the bytes.  rtlfm_gpu_run_device() makes
 	// the step after next wait for it before it reuses this parity's buffers.
 	hipStream_t q = h->stream;
-	// ... but config 3's own tail (deemph + arbitrary_upsample: 16384 short waves that fill the GPU by themselves, 63 us
-	// alone) behind a front end of thousands of streams is better off in line: beside the next front end it takes 1.5 %
-	// more of the step than behind this one (LAB.md I.31).  A rule of the configuration and the stream count only - a
-	// handle's tail never changes streams between runs.
-	const bool arb_in_line = tp.deemph && tp.arb && !tp.post && !tp.adc && !tp.lpr && c.rate_out2 > c.rate_out &&
-	                         (h->opt.arb_serial > 0 || (h->opt.arb_serial < 0 && S >= 2048));
-	const bool own_stream = tp.any() && h->tail_overlap && !arb_in_line;
+	// ... but config 3's own tail in line (arb_tail_in_line above)
+	const bool own_stream = tp.any() && h->tail_overlap && !arb_tail_in_line(h, tp);
 	if (own_stream) {
 		HIP_TRY(hipEventRecord(h->ev_front[par], h->stream));
 		HIP_TRY(hipStreamWaitEvent(h->tail_stream, h->ev_front[par], 0));
@@ -1490,7 +1497,8 @@ static int run_fused(rtlfm_gpu *h, const uint8_t *d_iq, size_t stream_stride, in
 	if (r < 0) return r;
 	const int2 *rdc = rdc_prepass(h, d_iq, stream_stride, nblocks);
 	const bool sq = c.squelch_level || c.report_levels;  // the front end takes rms()'s sums, k_squelch_apply decides (fused_kernel.h)
-	h->fws.tail_follows = tp.any() || sq;
+	// (a tail in line leaves the next front end alone: the plan of a front end that nothing runs beside)
+	h->fws.tail_follows = (tp.any() && !arb_tail_in_line(h, tp)) || sq;
 	if (sq) HIP_TRY(hipMemsetAsync(h->d_sq_sums, 0, (size_t)S * nblocks * 2 * sizeof(uint32_t), q));
 	r = fused::launch(h->fws, c, S, d_iq, stream_stride, nblocks, dd, dds, sin, sout, h->d_lut, q, nullptr, 0, rdc,
 	                  sq ? h->d_sq_sums : nullptr);
